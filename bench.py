@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py - graph-pairs/sec of the message-passing forward hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (embedding gather, S x (BondMatrixMessage,
+Reduce, GatedUpdate), GlobalSumPool, for the cation AND the anion branch) over one resident batch
+of synthetic padded graph pairs: BASELINE.json configs[1] (N=40, E=80, D=32, K=8, S=3, batch 4096
+per GPU; weak scaling: every rank owns its own 4096 pairs, no data-path collective).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_HBM_GBS = 8000.0          # HBM3E spec
+
+
+def algorithmic_flops_per_pair(N, E, D, S):
+    """SURVEY.md 8(d), per-bond-type schedule: 2 ions * S * (2 D^2 E + 12 D^2 N)."""
+    return 2 * S * (2 * D * D * E + 12 * D * D * N)
+
+
+def algorithmic_bytes_per_pair(N, E, D):
+    """SURVEY.md 8(d), fused forward: 2*(4N + 12E + 4D) (+8 for T and the output scalar)."""
+    return 2 * (4 * N + 12 * E + 4 * D) + 8
+
+
+def cpu_baseline(inputs, w, budget_s=20.0):
+    """Reference-schedule torch-CPU forward (oracle/torch_ref.py) on a bounded sample of the same
+    workload, all host cores.  Reported beside the GPU number; never the thing measured as `value`."""
+    from oracle import torch_ref as TR
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sample = 128
+    sub = {k: v[:sample] for k, v in inputs.items()}
+    t0 = time.perf_counter()
+    TR.pooled_pair(w, sub)  # warm-up / page-in
+    first = time.perf_counter() - t0
+    iters = int(max(2, min(50, (budget_s - first) / max(first, 1e-3))))
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        TR.pooled_pair(w, sub)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": sample / med, "unit": "graph-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{sample} pairs x {iters} iterations (median), torch-CPU fp32, reference op schedule "
+                      f"materialising (B,E,D,D); restatement, not TensorFlow itself"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4096, help="graph pairs per GPU")
+    ap.add_argument("--mp-steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--schedule", choices=["fused", "layered"], default="fused")
+    args = ap.parse_args()
+
+    from ionic_mpnn_amd import _lib, dist as idist, model, synthetic, weights
+
+    rank, local_rank, world = idist.env_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 through torch.distributed.run (see module docstring)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    rehearsal = world > ndev  # more ranks than GPUs (1-GPU box rehearsal): share devices, gloo
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        idist.init_distributed(backend="gloo" if rehearsal else "nccl")
+    import torch.distributed as dist
+
+    N, E, D, K, S, B = 40, 80, 32, 8, args.mp_steps, args.batch
+    # every rank draws its own shard of the global batch (seed offset by rank); weights replicated
+    inputs = synthetic.make_batch(B, max_atoms=N, max_edges=E, seed=0 + rank)
+    w = weights.init_weights("viscosity", synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, atom_dim=D, bond_dim=K,
+                             num_steps=S, seed=1)
+    m = model.build_model(synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, atom_dim=D, bond_dim=K, num_steps=S, device=dev)
+    m.load_weights(w)
+    d_in = {k: torch.from_numpy(v).to(dev) for k, v in inputs.items()}  # resident in HBM before timing
+    fused = args.schedule == "fused"
+
+    def step():
+        return m.encode_pooled(d_in, fused=fused)
+
+    lib = _lib.load()
+    check_sum = torch.zeros(2, dtype=torch.float64, device="cpu" if rehearsal else dev)
+    works = []
+    for _ in range(args.warmup):
+        pc, pa = step()
+    torch.cuda.synchronize()
+
+    if fused:
+        _lib.check(lib.impnn_profile_enable(args.steps))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pc, pa = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    # epilogue collective (outside the per-sample data path): global fingerprint checksum
+    local_sum = torch.stack([pc.double().sum() + pa.double().sum(),
+                             torch.tensor(float(B), dtype=torch.float64, device=dev)])
+    if world > 1:
+        t = local_sum.cpu() if rehearsal else local_sum
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        local_sum = t
+    total_pairs = float(local_sum[1].item())
+
+    kernel_ms = None
+    if fused:
+        buf = (C.c_float * args.steps)()
+        n = C.c_int32(0)
+        _lib.check(lib.impnn_profile_collect(buf, args.steps, C.byref(n)))
+        lib.impnn_profile_disable()
+        if n.value:
+            kernel_ms = float(np.mean(np.frombuffer(buf, dtype=np.float32, count=n.value)))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_pairs * args.steps / elapsed
+    flops_launch = algorithmic_flops_per_pair(N, E, D, S) * B
+    bytes_launch = algorithmic_bytes_per_pair(N, E, D) * B
+    out = {
+        "metric": "molecule-graph pairs/sec (fwd), batch 4096 per MI355X",
+        "value": value, "unit": "graph-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE.json configs[1]: message-passing forward (embedding gather -> {S}x"
+                               f"(BondMatrixMessage, Reduce, GatedUpdate) -> GlobalSumPool), cation+anion, synthetic "
+                               f"padded graphs N<={N} E<={E}, D={D}, K={K}, batch {B} pairs/GPU, schedule={args.schedule}",
+                   "global_batch": int(total_pairs), "parallelism": f"batch-sharded x{world}, weights replicated, "
+                   "no data-path collective; one all-reduce of the fingerprint checksum after the timed region",
+                   "checksum": float(local_sum[0].item())},
+    }
+    if rehearsal:
+        out["config"]["rehearsal"] = f"{world} ranks share {ndev} GPU(s) over gloo - not a scaling number"
+    if kernel_ms:
+        ach = flops_launch / (kernel_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "encoder_fused_kernel", "achieved": ach,
+                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                           "traffic": None, "kernel_ms": kernel_ms,
+                           "algorithmic_flops_per_launch": flops_launch,
+                           "hbm": {"algorithmic_bytes_per_launch": bytes_launch,
+                                   "achieved_GBs": bytes_launch / (kernel_ms * 1e-3) / 1e9,
+                                   "frac_of_8TBs": bytes_launch / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(inputs, w)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,145 @@
+/*
+ * impnn.h - C ABI of libimpnn.so: the MI355X (gfx950) implementation of the ionic-mpnn
+ * message-passing forward path.
+ *
+ * The reference (goalheart/ionic-mpnn) is pure Python on TensorFlow/Keras and has no FFI of
+ * its own; the interface replaced here is the set of TF ops each Keras layer's call() issues.
+ * Every entry point cites the reference lines (relative to the reference root) it replaces.
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM), caller-allocated, row-major contiguous;
+ *     float = IEEE fp32, ids / connectivity = int32 exactly as the reference's
+ *     Input(dtype=tf.int32) tensors (train_viscosity.py:150-157);
+ *   - B batch (one ion each), N padded atoms, E padded directed edge slots, D atom_dim,
+ *     K bond_dim, S message-passing steps, Va/Vb vocabulary sizes including padding id 0;
+ *   - `stream` is a hipStream_t passed as void*; all calls are asynchronous enqueues that never
+ *     allocate, free, synchronise or retain pointers past return (hipGraph-capturable);
+ *   - return value: 0 = ok, negative = error (IMPNN_E_*); impnn_last_error_string() gives the
+ *     thread-local text of the last failure.  No C++ exception crosses this boundary;
+ *   - indices are never trusted: an edge whose src or tgt is outside [0,N) is treated as a
+ *     padding edge (contributes nothing), an embedding id outside [0,V) yields a zero row -
+ *     the behaviour of TF's GPU gather/scatter kernels; tf-CPU's "raise" behaviour is
+ *     available through impnn_validate_indices + the Python wrapper's debug mode.
+ */
+#ifndef IMPNN_H_
+#define IMPNN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMPNN_OK 0
+#define IMPNN_E_BADARG (-1)      /* null pointer, non-positive size, misaligned buffer */
+#define IMPNN_E_UNSUPPORTED (-2) /* shape outside what the kernel set covers */
+#define IMPNN_E_LAUNCH (-3)      /* hipLaunch / hipGetLastError failure */
+#define IMPNN_E_WORKSPACE (-4)   /* workspace too small */
+
+typedef void* impnn_stream_t; /* hipStream_t */
+
+/* library identity: returns IMPNN_ABI_VERSION */
+#define IMPNN_ABI_VERSION 1
+int impnn_abi_version(void);
+/* text of the calling thread's last error ("" if none) */
+const char* impnn_last_error_string(void);
+/* name of the code object target the library was built for ("gfx950") */
+const char* impnn_target_arch(void);
+
+/* ---- a1/a2: keras Embedding lookup (train_viscosity.py:163-164,171-172;
+ *      train_melting_point.py:149-150,157-158).  out[r,:] = table[ids[r],:], r < rows. */
+int impnn_embed_gather(const int32_t* ids, const float* table, float* out, int64_t rows,
+                       int32_t vocab, int32_t dim, impnn_stream_t stream);
+
+/* ---- a4: BondMatrixMessage.call with a dense bond_state (models/layers.py:100-117).
+ *      h (B,N,D), bond_state (B,E,K), conn (B,E,2)=[src,tgt], W=bond_transform (K,D,D)
+ *      -> messages (B,E,D); rows with src==0 or tgt==0 are zero (models/layers.py:114-115). */
+int impnn_bmm_message(const float* h, const float* bond_state, const int32_t* conn, const float* W,
+                      float* messages, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K,
+                      impnn_stream_t stream);
+
+/* ---- per-bond-type matrices (schedule A): A[v,i,j] = sum_k bond_table[v,k]*W[k,i,j].
+ *      Equals tf.tensordot(bond_state, W) of models/layers.py:108 evaluated once per bond type
+ *      instead of once per edge, valid because bond_state is always an Embedding lookup
+ *      (train_viscosity.py:172, train_melting_point.py:158). out (Vb,D,D). */
+int impnn_bond_type_matrices(const float* bond_table, const float* W, float* out, int32_t Vb,
+                             int32_t K, int32_t D, impnn_stream_t stream);
+
+/* ---- a4 from bond ids: messages[b,e,:] = A[bond_ids[b,e]] @ h[b,src[b,e],:], masked as a4. */
+int impnn_bmm_message_typed(const float* h, const int32_t* bond_ids, const int32_t* conn,
+                            const float* type_mats, float* messages, int32_t B, int32_t N,
+                            int32_t E, int32_t D, int32_t Vb, impnn_stream_t stream);
+
+/* ---- a5: Reduce.call (models/layers.py:57-83): agg[b,t,:] = sum_{e: tgt[b,e]=t, t>0} m[b,e,:],
+ *      accumulated in edge-slot order (deterministic, == sequential scatter_nd on CPU).
+ *      tgt is read as tgt[(b*E+e)*tgt_stride]: stride 1 for a contiguous (B,E) tensor, 2 to read
+ *      conn[:,:,1] in place (pass conn+1), as the caller does at train_viscosity.py:182. */
+int impnn_reduce_scatter_add(const float* messages, const int32_t* tgt, int32_t tgt_stride,
+                             float* agg, int32_t B, int32_t N, int32_t E, int32_t D,
+                             impnn_stream_t stream);
+
+/* ---- a10: the orphan models/bond_matrix_message.py:37-65 signature: a4 then a5 in one launch,
+ *      [h, bond_state, conn] -> agg (B,N,D).  W is (K,D*D) flat == (K,D,D) row-major. */
+int impnn_bmm_fused(const float* h, const float* bond_state, const int32_t* conn, const float* W,
+                    float* agg, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K,
+                    impnn_stream_t stream);
+
+/* ---- a7: GatedUpdate.call (models/layers.py:142-156) over `rows` = B*N atom rows (padding rows
+ *      included, as the reference computes them).  Wz/Wr/Wh are keras Dense kernels (2D,D)
+ *      (input-major), b* (D,), LayerNormalization gamma/beta (D,), eps = 1e-3 by keras default. */
+int impnn_gated_update(const float* h, const float* agg, const float* Wz, const float* bz,
+                       const float* Wr, const float* br, const float* Wh, const float* bh,
+                       const float* gamma, const float* beta, float ln_eps, float* out,
+                       int64_t rows, int32_t D, impnn_stream_t stream);
+
+/* ---- a8: GlobalSumPool.call (models/layers.py:161-164): out[b,:] = sum_n h[b,n,:]*[ids[b,n]>0]. */
+int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, int32_t B,
+                          int32_t N, int32_t D, impnn_stream_t stream);
+
+/* ---- a9: encode() (train_viscosity.py:166-187; train_melting_point.py:152-171) up to and
+ *      including GlobalSumPool, for `n_ions` independent ion branches in ONE launch
+ *      (cation and anion: train_viscosity.py:193-194).
+ *
+ *  Per ion g < n_ions:  atom_ids[g] (B,N), bond_ids[g] (B,E), conn[g] (B,E,2), step weights
+ *  weights[g] in the canonical packed layout below, pooled[g] (B,D).
+ *  atom_table (Va,D) and bond_table (Vb,K) are shared by the ions (train_viscosity.py:163-164).
+ *
+ *  Canonical packed step-weight layout (floats), repeated S times per ion:
+ *     bond_transform K*D*D | Wz 2D*D | bz D | Wr 2D*D | br D | Wh 2D*D | bh D | gamma D | beta D
+ *  impnn_encoder_step_floats(D,K) returns that per-step count.
+ *
+ *  The arrays of pointers are HOST arrays of device pointers (length n_ions, n_ions <= 2). */
+int64_t impnn_encoder_step_floats(int32_t D, int32_t K);
+int impnn_encoder_workspace_bytes(int32_t n_ions, int32_t B, int32_t N, int32_t E, int32_t D,
+                                  int32_t K, int32_t S, int32_t Vb, size_t* bytes);
+int impnn_encoder_fused(int32_t n_ions, const int32_t* const* atom_ids,
+                        const int32_t* const* bond_ids, const int32_t* const* conn,
+                        const float* atom_table, int32_t Va, const float* bond_table, int32_t Vb,
+                        const float* const* weights, float* const* pooled, int32_t B, int32_t N,
+                        int32_t E, int32_t D, int32_t K, int32_t S, float ln_eps, void* workspace,
+                        size_t workspace_bytes, impnn_stream_t stream);
+
+/* ---- measurement: HIP-event timing of the dominant kernel (encoder_fused_kernel), recorded on the
+ *      stream the kernel is launched on.  After impnn_profile_enable(capacity) every
+ *      impnn_encoder_fused call of this thread records one (start, stop) event pair around that
+ *      kernel alone (the two small plan kernels are outside the pair) until `capacity` pairs exist.
+ *      impnn_profile_collect synchronises the recorded events, writes up to max_n durations in
+ *      milliseconds, returns their count in *n_out and rewinds.  Used by bench.py's roofline leg. */
+int impnn_profile_enable(int32_t capacity);
+int impnn_profile_collect(float* ms_out, int32_t max_n, int32_t* n_out);
+int impnn_profile_disable(void);
+
+/* ---- debug: counts indices the reference's CPU path would raise on.  counts[0] += #conn
+ *      entries outside [0,N), counts[1] += #atom ids outside [0,Va), counts[2] += #bond ids
+ *      outside [0,Vb).  Any of conn/atom_ids/bond_ids may be NULL.  counts: 3 device int32,
+ *      zeroed by the caller. */
+int impnn_validate_indices(const int32_t* conn, const int32_t* atom_ids, const int32_t* bond_ids,
+                           int32_t* counts, int32_t B, int32_t N, int32_t E, int32_t Va,
+                           int32_t Vb, impnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMPNN_H_ */

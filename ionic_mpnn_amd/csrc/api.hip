@@ -1,0 +1,236 @@
+// extern "C" boundary of libimpnn.so: argument checks, then launches.  See include/impnn.h.
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace impnn {
+
+char* error_buffer() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_buffer(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+namespace {
+struct Profiler {
+  std::vector<hipEvent_t> start, stop;
+  int used = 0;
+  bool enabled = false;
+  bool open = false;  // a start without its stop
+};
+thread_local Profiler g_prof;
+}  // namespace
+
+void profile_record_start(hipStream_t s) {
+  Profiler& p = g_prof;
+  if (!p.enabled || p.used >= (int)p.start.size()) return;
+  if (hipEventRecord(p.start[p.used], s) == hipSuccess) p.open = true;
+}
+
+void profile_record_stop(hipStream_t s) {
+  Profiler& p = g_prof;
+  if (!p.enabled || !p.open) return;
+  (void)hipEventRecord(p.stop[p.used], s);
+  p.open = false;
+  ++p.used;
+}
+
+}  // namespace impnn
+
+using namespace impnn;
+
+#define REQUIRE(cond, what)                                              \
+  do {                                                                   \
+    if (!(cond)) return fail(IMPNN_E_BADARG, "%s: %s", __func__, what); \
+  } while (0)
+
+extern "C" {
+
+int impnn_abi_version(void) { return IMPNN_ABI_VERSION; }
+const char* impnn_last_error_string(void) { return error_buffer(); }
+const char* impnn_target_arch(void) { return "gfx950"; }
+
+int impnn_embed_gather(const int32_t* ids, const float* table, float* out, int64_t rows, int32_t vocab,
+                       int32_t dim, impnn_stream_t stream) {
+  REQUIRE(rows >= 0 && vocab > 0 && dim > 0, "rows>=0, vocab>0, dim>0 required");
+  REQUIRE(rows == 0 || (ids && table && out), "null pointer");
+  return launch_embed_gather(ids, table, out, rows, vocab, dim, as_stream(stream));
+}
+
+int impnn_bmm_message(const float* h, const float* bond_state, const int32_t* conn, const float* W,
+                      float* messages, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K,
+                      impnn_stream_t stream) {
+  REQUIRE(B >= 0 && N > 0 && E >= 0 && D > 0 && K > 0, "bad shape");
+  if (B == 0 || E == 0) return IMPNN_OK;
+  REQUIRE(h && bond_state && conn && W && messages, "null pointer");
+  return launch_bmm_message(h, bond_state, conn, W, messages, nullptr, B, N, E, D, K, as_stream(stream));
+}
+
+int impnn_bond_type_matrices(const float* bond_table, const float* W, float* out, int32_t Vb, int32_t K,
+                             int32_t D, impnn_stream_t stream) {
+  REQUIRE(Vb > 0 && K > 0 && D > 0, "bad shape");
+  REQUIRE(bond_table && W && out, "null pointer");
+  return launch_bond_type_matrices(bond_table, W, out, Vb, K, D, as_stream(stream));
+}
+
+int impnn_bmm_message_typed(const float* h, const int32_t* bond_ids, const int32_t* conn,
+                            const float* type_mats, float* messages, int32_t B, int32_t N, int32_t E,
+                            int32_t D, int32_t Vb, impnn_stream_t stream) {
+  REQUIRE(B >= 0 && N > 0 && E >= 0 && D > 0 && Vb > 0, "bad shape");
+  if (B == 0 || E == 0) return IMPNN_OK;
+  REQUIRE(h && bond_ids && conn && type_mats && messages, "null pointer");
+  return launch_bmm_message_typed(h, bond_ids, conn, type_mats, messages, B, N, E, D, Vb, as_stream(stream));
+}
+
+int impnn_reduce_scatter_add(const float* messages, const int32_t* tgt, int32_t tgt_stride, float* agg,
+                             int32_t B, int32_t N, int32_t E, int32_t D, impnn_stream_t stream) {
+  REQUIRE(B >= 0 && N > 0 && E >= 0 && D > 0, "bad shape");
+  REQUIRE(tgt_stride >= 1, "tgt_stride must be >= 1");
+  if (B == 0) return IMPNN_OK;
+  REQUIRE(agg && (E == 0 || (messages && tgt)), "null pointer");
+  return launch_reduce_scatter_add(messages, tgt, tgt_stride, agg, B, N, E, D, as_stream(stream));
+}
+
+int impnn_bmm_fused(const float* h, const float* bond_state, const int32_t* conn, const float* W, float* agg,
+                    int32_t B, int32_t N, int32_t E, int32_t D, int32_t K, impnn_stream_t stream) {
+  REQUIRE(B >= 0 && N > 0 && E > 0 && D > 0 && K > 0, "bad shape");
+  if (B == 0) return IMPNN_OK;
+  REQUIRE(h && bond_state && conn && W && agg, "null pointer");
+  return launch_bmm_message(h, bond_state, conn, W, nullptr, agg, B, N, E, D, K, as_stream(stream));
+}
+
+int impnn_gated_update(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
+                       const float* br, const float* Wh, const float* bh, const float* gamma,
+                       const float* beta, float ln_eps, float* out, int64_t rows, int32_t D,
+                       impnn_stream_t stream) {
+  REQUIRE(rows >= 0 && D > 0, "bad shape");
+  if (rows == 0) return IMPNN_OK;
+  REQUIRE(h && agg && Wz && bz && Wr && br && Wh && bh && gamma && beta && out, "null pointer");
+  REQUIRE(ln_eps >= 0.f, "ln_eps must be >= 0");
+  return launch_gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, ln_eps, out, rows, D,
+                             as_stream(stream));
+}
+
+int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, int32_t B, int32_t N,
+                          int32_t D, impnn_stream_t stream) {
+  REQUIRE(B >= 0 && N > 0 && D > 0, "bad shape");
+  if (B == 0) return IMPNN_OK;
+  REQUIRE(h && atom_ids && out, "null pointer");
+  return launch_global_sum_pool(h, atom_ids, out, B, N, D, as_stream(stream));
+}
+
+int64_t impnn_encoder_step_floats(int32_t D, int32_t K) {
+  if (D <= 0 || K <= 0) return -1;
+  const int64_t d = D, k = K;
+  return k * d * d + 3 * (2 * d * d + d) + 2 * d;
+}
+
+int impnn_encoder_workspace_bytes(int32_t n_ions, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K,
+                                  int32_t S, int32_t Vb, size_t* bytes) {
+  REQUIRE(bytes, "null pointer");
+  REQUIRE(n_ions >= 1 && n_ions <= 2 && B >= 0 && N > 0 && E >= 0 && D > 0 && K > 0 && S >= 0 && Vb > 0,
+          "bad shape");
+  if (!encoder_fused_supported(N, E, D, K, S, Vb))
+    return fail(IMPNN_E_UNSUPPORTED, "encoder_fused: shape N=%d E=%d D=%d K=%d S=%d Vb=%d not covered", N, E, D,
+                K, S, Vb);
+  *bytes = encoder_fused_workspace_bytes(n_ions, B, N, E, D, K, S, Vb);
+  return IMPNN_OK;
+}
+
+int impnn_encoder_fused(int32_t n_ions, const int32_t* const* atom_ids, const int32_t* const* bond_ids,
+                        const int32_t* const* conn, const float* atom_table, int32_t Va,
+                        const float* bond_table, int32_t Vb, const float* const* weights,
+                        float* const* pooled, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K, int32_t S,
+                        float ln_eps, void* workspace, size_t workspace_bytes, impnn_stream_t stream) {
+  REQUIRE(n_ions >= 1 && n_ions <= 2, "n_ions must be 1 or 2");
+  REQUIRE(B >= 0 && N > 0 && E >= 0 && D > 0 && K > 0 && S >= 0 && Va > 0 && Vb > 0, "bad shape");
+  REQUIRE(atom_ids && bond_ids && conn && weights && pooled && atom_table && bond_table, "null pointer");
+  if (!encoder_fused_supported(N, E, D, K, S, Vb))
+    return fail(IMPNN_E_UNSUPPORTED, "encoder_fused: shape N=%d E=%d D=%d K=%d S=%d Vb=%d not covered", N, E, D,
+                K, S, Vb);
+  if (B == 0) return IMPNN_OK;
+  EncoderArgs a{};
+  a.n_ions = n_ions;
+  for (int g = 0; g < n_ions; ++g) {
+    REQUIRE(atom_ids[g] && pooled[g] && (E == 0 || (bond_ids[g] && conn[g])) && (S == 0 || weights[g]),
+            "null per-ion pointer");
+    a.atom_ids[g] = atom_ids[g];
+    a.bond_ids[g] = bond_ids[g];
+    a.conn[g] = conn[g];
+    a.weights[g] = weights[g];
+    a.pooled[g] = pooled[g];
+  }
+  a.atom_table = atom_table;
+  a.bond_table = bond_table;
+  a.Va = Va; a.Vb = Vb; a.B = B; a.N = N; a.E = E; a.D = D; a.K = K; a.S = S;
+  a.ln_eps = ln_eps;
+  a.workspace = workspace;
+  a.workspace_bytes = workspace_bytes;
+  const size_t need = encoder_fused_workspace_bytes(n_ions, B, N, E, D, K, S, Vb);
+  if (need > 0 && (!workspace || workspace_bytes < need))
+    return fail(IMPNN_E_WORKSPACE, "encoder_fused: workspace %zu < %zu bytes", workspace_bytes, need);
+  return launch_encoder_fused(a, as_stream(stream));
+}
+
+int impnn_profile_enable(int32_t capacity) {
+  REQUIRE(capacity > 0 && capacity <= (1 << 20), "capacity out of range");
+  impnn_profile_disable();
+  g_prof.start.resize(capacity);
+  g_prof.stop.resize(capacity);
+  for (int i = 0; i < capacity; ++i) {
+    if (hipEventCreate(&g_prof.start[i]) != hipSuccess || hipEventCreate(&g_prof.stop[i]) != hipSuccess) {
+      g_prof.start.resize(i);
+      g_prof.stop.resize(i);
+      impnn_profile_disable();
+      return fail(IMPNN_E_LAUNCH, "impnn_profile_enable: hipEventCreate failed");
+    }
+  }
+  g_prof.used = 0;
+  g_prof.open = false;
+  g_prof.enabled = true;
+  return IMPNN_OK;
+}
+
+int impnn_profile_collect(float* ms_out, int32_t max_n, int32_t* n_out) {
+  REQUIRE(n_out && (ms_out || max_n == 0) && max_n >= 0, "bad arguments");
+  int n = g_prof.used < max_n ? g_prof.used : max_n;
+  for (int i = 0; i < n; ++i) {
+    if (hipEventSynchronize(g_prof.stop[i]) != hipSuccess ||
+        hipEventElapsedTime(&ms_out[i], g_prof.start[i], g_prof.stop[i]) != hipSuccess)
+      return fail(IMPNN_E_LAUNCH, "impnn_profile_collect: event %d not readable", i);
+  }
+  *n_out = n;
+  g_prof.used = 0;
+  g_prof.open = false;
+  return IMPNN_OK;
+}
+
+int impnn_profile_disable(void) {
+  for (auto e : g_prof.start) (void)hipEventDestroy(e);
+  for (auto e : g_prof.stop) (void)hipEventDestroy(e);
+  g_prof.start.clear();
+  g_prof.stop.clear();
+  g_prof.used = 0;
+  g_prof.enabled = false;
+  g_prof.open = false;
+  return IMPNN_OK;
+}
+
+int impnn_validate_indices(const int32_t* conn, const int32_t* atom_ids, const int32_t* bond_ids,
+                           int32_t* counts, int32_t B, int32_t N, int32_t E, int32_t Va, int32_t Vb,
+                           impnn_stream_t stream) {
+  REQUIRE(counts, "null pointer");
+  REQUIRE(B >= 0 && N > 0 && E >= 0, "bad shape");
+  if (B == 0) return IMPNN_OK;
+  return launch_validate_indices(conn, atom_ids, bond_ids, counts, B, N, E, Va, Vb, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,74 @@
+// Shared host-side helpers for libimpnn.so (gfx950 only; no other target is supported).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/impnn.h"
+
+namespace impnn {
+
+// thread-local last-error text (impnn_last_error_string)
+char* error_buffer();
+int fail(int code, const char* fmt, ...);
+
+inline hipStream_t as_stream(impnn_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(IMPNN_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return IMPNN_OK;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// ---- layer-at-a-time launches (layer_kernels.hip)
+int launch_embed_gather(const int32_t* ids, const float* table, float* out, int64_t rows, int vocab,
+                        int dim, hipStream_t s);
+int launch_bmm_message(const float* h, const float* bs, const int32_t* conn, const float* W, float* m,
+                       float* agg, int B, int N, int E, int D, int K, hipStream_t s);
+int launch_bond_type_matrices(const float* tb, const float* W, float* out, int Vb, int K, int D,
+                              hipStream_t s);
+int launch_bmm_message_typed(const float* h, const int32_t* bond_ids, const int32_t* conn,
+                             const float* type_mats, float* m, int B, int N, int E, int D, int Vb,
+                             hipStream_t s);
+int launch_reduce_scatter_add(const float* m, const int32_t* tgt, int tgt_stride, float* agg, int B,
+                              int N, int E, int D, hipStream_t s);
+int launch_gated_update(const float* h, const float* agg, const float* Wz, const float* bz,
+                        const float* Wr, const float* br, const float* Wh, const float* bh,
+                        const float* gamma, const float* beta, float eps, float* out, int64_t rows,
+                        int D, hipStream_t s);
+int launch_global_sum_pool(const float* h, const int32_t* ids, float* out, int B, int N, int D,
+                           hipStream_t s);
+int launch_validate_indices(const int32_t* conn, const int32_t* atom_ids, const int32_t* bond_ids,
+                            int32_t* counts, int B, int N, int E, int Va, int Vb, hipStream_t s);
+
+// ---- event-pair profiler (api.hip); record_* are no-ops unless enabled on this thread
+void profile_record_start(hipStream_t s);
+void profile_record_stop(hipStream_t s);
+
+// ---- fused encoder (encoder_fused.hip)
+struct EncoderArgs {
+  int n_ions;
+  const int32_t* atom_ids[2];
+  const int32_t* bond_ids[2];
+  const int32_t* conn[2];
+  const float* weights[2];
+  float* pooled[2];
+  const float* atom_table;
+  const float* bond_table;
+  int Va, Vb, B, N, E, D, K, S;
+  float ln_eps;
+  void* workspace;
+  size_t workspace_bytes;
+};
+bool encoder_fused_supported(int N, int E, int D, int K, int S, int Vb);
+size_t encoder_fused_workspace_bytes(int n_ions, int B, int N, int E, int D, int K, int S, int Vb);
+int launch_encoder_fused(const EncoderArgs& a, hipStream_t s);
+
+}  // namespace impnn

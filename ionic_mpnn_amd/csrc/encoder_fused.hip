@@ -1,0 +1,683 @@
+// Fused message-passing encoder for gfx950 (MI355X): encode() of train_viscosity.py:166-187 up to
+// and including GlobalSumPool, for both ions in one launch, D = 32, K <= 8.
+//
+// Shape of the computation (all fp32, exact-f32 MFMA v_mfma_f32_16x16x4_f32):
+//   * molecules are cut into CHUNKS of <= 256 packed atom rows (padding atoms are not carried;
+//     see "rows" below); one 512-thread workgroup owns a chunk for all S steps, its node state
+//     h lives in LDS (double-buffered), weights of the current (ion, step) live in LDS;
+//   * atoms sit on the MFMA N dimension (lane & 15), features on M: every GEMM is computed
+//     transposed, out^T = W^T * in^T, so an accumulator tile (feature = 4*(lane>>4)+reg) is
+//     directly the B operand of the next GEMM - no LDS round trip between message, gates,
+//     candidate and LayerNorm;
+//   * message + Reduce (models/layers.py:100-117, 57-83) in "pull" form: each atom row walks its
+//     in-edges in edge-slot order (CSR built once per chunk, deterministic), forming
+//         G[k][j] = sum_{e -> atom} bond_table[bond_id_e][k] * h[src_e][j]
+//     in registers, then agg^T = sum_k W_k * G_k on the matrix cores (128 MFMA / 16 atoms);
+//   * GatedUpdate (models/layers.py:142-156): 96 MFMA / 16 atoms, sigmoid/tanh/LayerNorm on the
+//     accumulator registers, LayerNorm row reduction = 8 in-lane adds + 2 cross-lane steps;
+//   * GlobalSumPool (models/layers.py:161-164): segmented sum over the chunk's rows from LDS.
+//
+// rows: molecule b keeps rows [0, r_b), r_b = 1 + max(last n with atom_ids[b,n] > 0, largest atom
+// index on a valid edge).  Rows >= r_b can never send (no valid edge names them) and are masked
+// by the pool, so dropping them cannot change the output; the kept set is closed under
+// "is a source of", which makes the skip exact, not approximate.
+//
+// Three launches per call: plan_stats (+ weight image prep), plan_scan, encoder_fused.
+#include "common.h"
+
+namespace impnn {
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kD = 32;
+constexpr int kKMax = 8;
+constexpr int kRCap = 256;   // packed rows per chunk
+constexpr int kECap = 1024;  // valid edges per chunk (= 4 * kRCap, enforced through "virtual rows")
+constexpr int kHS = 36;      // LDS row stride of h (floats): 16B aligned, conflict-free b128 tile writes
+constexpr int kMsgRS = 36;   // row stride of the message-weight image
+constexpr int kUpdRS = 68;   // row stride of the update-weight image (2D + 4)
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int kTbCapFloats = 2048;  // bond table copy in LDS (Vb*K floats)
+
+__host__ __device__ constexpr int img_msg_floats(int K) { return K * kD * kMsgRS; }
+__host__ __device__ constexpr int img_upd_floats() { return 3 * kD * kUpdRS; }
+__host__ __device__ constexpr int img_vec_floats() { return 5 * kD; }
+__host__ __device__ constexpr int img_floats(int K) {
+  return img_msg_floats(K) + img_upd_floats() + img_vec_floats();
+}
+
+// workspace layout (bytes, all 256-aligned sections)
+struct Ws {
+  size_t img_off, rows_off, vr_off, start_off, first_off, nchunks_off, total;
+  int ub;  // upper bound of chunks per ion
+};
+
+__host__ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+__host__ inline int vr_max_of(int N, int E) {
+  int v = (E + 3) / 4;
+  int m = N > v ? N : v;
+  return m < 1 ? 1 : m;
+}
+
+__host__ inline Ws ws_layout(int n_ions, int B, int N, int E, int K, int S) {
+  Ws w{};
+  const int vrmax = vr_max_of(N, E);
+  const int win = kRCap - vrmax + 1;
+  w.ub = (int)(((int64_t)B * vrmax) / win) + 1;
+  size_t off = 0;
+  w.img_off = off;
+  off = align_up(off + (size_t)n_ions * (S > 0 ? S : 1) * img_floats(K) * sizeof(float), 256);
+  w.rows_off = off;
+  off = align_up(off + (size_t)n_ions * B * sizeof(int32_t), 256);
+  w.vr_off = off;
+  off = align_up(off + (size_t)n_ions * B * sizeof(int32_t), 256);
+  w.start_off = off;
+  off = align_up(off + (size_t)n_ions * (B + 1) * sizeof(int32_t), 256);
+  w.first_off = off;
+  off = align_up(off + (size_t)n_ions * (w.ub + 2) * sizeof(int32_t), 256);
+  w.nchunks_off = off;
+  off = align_up(off + 2 * sizeof(int32_t), 256);
+  w.total = off;
+  return w;
+}
+
+struct PlanParams {
+  const int32_t* atom_ids[2];
+  const int32_t* bond_ids[2];
+  const int32_t* conn[2];
+  const float* weights[2];
+  float* img;      // [n_ions][S][img_floats(K)]
+  int32_t* rows;   // [n_ions][B]
+  int32_t* vr;     // [n_ions][B]
+  int32_t* start;  // [n_ions][B+1]
+  int32_t* first;  // [n_ions][ub+2]
+  int32_t* nchunks;  // [2]
+  int n_ions, B, N, E, K, S, Vb, win, ub;
+  int mol_blocks;  // blocks of plan_stats that handle molecules
+  int64_t step_floats;
+};
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    int t = __shfl_xor(v, o);
+    v = v > t ? v : t;
+  }
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ bool edge_valid(int s, int t, int bid, int N, int Vb) {
+  // models/layers.py:114-115 (src>0 & tgt>0); out-of-range indices behave as padding (impnn.h)
+  return s > 0 && t > 0 && s < N && t < N && (unsigned)bid < (unsigned)Vb;
+}
+
+// -----------------------------------------------------------------------------------------
+// plan_stats: one wave per (ion, molecule): kept rows r_b, valid edges v_b, virtual rows
+// vr_b = max(1, r_b, ceil(v_b/4)).  Extra blocks convert the canonical packed step weights into
+// the LDS image the encoder copies verbatim (message rows padded to 36, gate kernels transposed).
+// -----------------------------------------------------------------------------------------
+__global__ void plan_stats_kernel(PlanParams p) {
+  const int lane = threadIdx.x & 63;
+  if ((int)blockIdx.x < p.mol_blocks) {
+    const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (item >= (int64_t)p.n_ions * p.B) return;
+    const int g = (int)(item / p.B);
+    const int b = (int)(item - (int64_t)g * p.B);
+    const int32_t* ids = p.atom_ids[g] + (int64_t)b * p.N;
+    const int32_t* cn = p.conn[g] + (int64_t)b * p.E * 2;
+    const int32_t* bd = p.bond_ids[g] + (int64_t)b * p.E;
+    int rmax = 0, cnt = 0;
+    for (int n = lane; n < p.N; n += 64)
+      if (ids[n] > 0) rmax = n + 1;  // ascending n per lane: last hit is the largest
+    for (int e = lane; e < p.E; e += 64) {
+      const int2 st = *reinterpret_cast<const int2*>(cn + 2 * e);
+      if (edge_valid(st.x, st.y, bd[e], p.N, p.Vb)) {
+        ++cnt;
+        const int m = (st.x > st.y ? st.x : st.y) + 1;
+        rmax = rmax > m ? rmax : m;
+      }
+    }
+    rmax = wave_max_i(rmax);
+    cnt = wave_sum_i(cnt);
+    if (lane == 0) {
+      int vr = (cnt + 3) >> 2;
+      vr = vr > rmax ? vr : rmax;
+      vr = vr < 1 ? 1 : vr;
+      p.rows[item] = rmax;
+      p.vr[item] = vr;
+    }
+  } else {
+    // weight image for (ion g, step s)
+    const int gs = blockIdx.x - p.mol_blocks;
+    const int g = gs / p.S, s = gs - g * p.S;
+    const float* w = p.weights[g] + (int64_t)s * p.step_floats;
+    const int K = p.K;
+    const float* W = w;                                 // (K,32,32)
+    const float* Wz = W + (int64_t)K * kD * kD;          // (64,32)
+    const float* bz = Wz + 2 * kD * kD;
+    const float* Wr = bz + kD;
+    const float* br = Wr + 2 * kD * kD;
+    const float* Wh = br + kD;
+    const float* bh = Wh + 2 * kD * kD;
+    const float* gamma = bh + kD;
+    const float* beta = gamma + kD;
+    float* img = p.img + (int64_t)gs * img_floats(K);
+    const int nmsg = img_msg_floats(K), nupd = img_upd_floats();
+    for (int t = threadIdx.x; t < nmsg; t += blockDim.x) {
+      const int row = t / kMsgRS, j = t - row * kMsgRS;  // row = k*32 + i_out
+      img[t] = j < kD ? W[(int64_t)row * kD + j] : 0.f;
+    }
+    for (int t = threadIdx.x; t < nupd; t += blockDim.x) {
+      const int row = t / kUpdRS, jj = t - row * kUpdRS;  // row = gate*32 + i_out
+      const int gate = row / kD, io = row - gate * kD;
+      const float* Wg = gate == 0 ? Wz : (gate == 1 ? Wr : Wh);
+      img[nmsg + t] = jj < 2 * kD ? Wg[(int64_t)jj * kD + io] : 0.f;
+    }
+    for (int t = threadIdx.x; t < img_vec_floats(); t += blockDim.x) {
+      const int v = t / kD, i = t - v * kD;
+      const float* src = v == 0 ? bz : v == 1 ? br : v == 2 ? bh : v == 3 ? gamma : beta;
+      img[nmsg + nupd + t] = src[i];
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// plan_scan: one 1024-thread workgroup per ion: start[b] = exclusive prefix of vr, chunk of
+// molecule b = start[b] / win (win = 256 - vr_max + 1 guarantees <= 256 rows per chunk), and
+// first[c] = first molecule of chunk c (empty chunks get an empty range).
+// -----------------------------------------------------------------------------------------
+__global__ void plan_scan_kernel(PlanParams p) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int g = blockIdx.x;
+  const int B = p.B;
+  const int32_t* vr = p.vr + (int64_t)g * B;
+  int32_t* start = p.start + (int64_t)g * (B + 1);
+  int32_t* first = p.first + (int64_t)g * (p.ub + 2);
+  const int T = blockDim.x;
+  const int per = (B + T - 1) / T;
+  const int b0 = threadIdx.x * per;
+  const int b1 = (b0 + per) < B ? (b0 + per) : B;
+  int local = 0;
+  for (int b = b0; b < b1; ++b) local += vr[b];
+  // block exclusive scan of `local`
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int incl = local;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wsum[wv] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int i = 0; i < (T >> 6); ++i) {
+      int t = wsum[i];
+      wsum[i] = c;
+      c += t;
+    }
+    carry_s = c;
+  }
+  __syncthreads();
+  int run = wsum[wv] + incl - local;
+  int prev_chunk = (b0 == 0 || b0 >= B) ? -1 : 0;
+  // chunk of the molecule just before b0 (needed to detect a chunk boundary at b0)
+  if (b0 > 0 && b0 < B) prev_chunk = (run - vr[b0 - 1]) / p.win;
+  for (int b = b0; b < b1; ++b) {
+    start[b] = run;
+    const int c = run / p.win;
+    if (c != prev_chunk) {
+      for (int cc = prev_chunk + 1; cc <= c; ++cc) first[cc] = b;
+      prev_chunk = c;
+    }
+    run += vr[b];
+  }
+  if (threadIdx.x == 0) {
+    const int total = carry_s;
+    start[B] = total;
+    const int last_chunk = B > 0 ? (total - vr[B - 1]) / p.win : -1;
+    p.nchunks[g] = last_chunk + 1;
+    first[last_chunk + 1] = B;
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// the encoder
+// -----------------------------------------------------------------------------------------
+struct EncParams {
+  const int32_t* atom_ids[2];
+  const int32_t* bond_ids[2];
+  const int32_t* conn[2];
+  float* pooled[2];
+  const float* atom_table;
+  const float* bond_table;
+  const float* img;
+  const int32_t* rows;
+  const int32_t* start;
+  const int32_t* first;
+  const int32_t* nchunks;
+  int n_ions, B, N, E, K, S, Va, Vb, ub;
+  float ln_eps;
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177793f * x));
+}
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// LDS carve (floats unless noted)
+struct Lds {
+  float* wimg;      // img_floats(K)
+  float* hbuf0;     // kRCap*kHS
+  float* hbuf1;     // kRCap*kHS
+  float* tb;        // kTbCapFloats (row stride 8)
+  uint32_t* ent;    // kECap
+  int32_t* rowptr;  // kRCap+1 (+pad)
+  int32_t* rowinfo; // kRCap : (mol_local<<16 | n) or -1 for slack rows
+  int32_t* moloff;  // kRCap+1
+  int32_t* molrows; // kRCap
+  int32_t* scratch; // 32
+};
+
+__host__ __device__ inline size_t lds_bytes(int K) {
+  return sizeof(float) * ((size_t)img_floats(K) + 2 * kRCap * kHS + kTbCapFloats) +
+         sizeof(uint32_t) * kECap + sizeof(int32_t) * ((kRCap + 4) + kRCap + (kRCap + 4) + kRCap + 32);
+}
+
+__global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p) {
+  extern __shared__ __align__(16) float smem[];
+  const int K = p.K;
+  Lds L;
+  {
+    float* f = smem;
+    L.wimg = f; f += img_floats(K);
+    L.hbuf0 = f; f += kRCap * kHS;
+    L.hbuf1 = f; f += kRCap * kHS;
+    L.tb = f; f += kTbCapFloats;
+    L.ent = reinterpret_cast<uint32_t*>(f); f += kECap;
+    L.rowptr = reinterpret_cast<int32_t*>(f); f += kRCap + 4;
+    L.rowinfo = reinterpret_cast<int32_t*>(f); f += kRCap;
+    L.moloff = reinterpret_cast<int32_t*>(f); f += kRCap + 4;
+    L.molrows = reinterpret_cast<int32_t*>(f); f += kRCap;
+    L.scratch = reinterpret_cast<int32_t*>(f);
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = p.n_ions == 2 ? (blockIdx.x & 1) : 0;
+  const int c = p.n_ions == 2 ? (blockIdx.x >> 1) : blockIdx.x;
+  if (c >= p.nchunks[g]) return;
+  const int32_t* first = p.first + (int64_t)g * (p.ub + 2);
+  const int m0 = first[c], m1 = first[c + 1];
+  const int M = m1 - m0;
+  if (M <= 0) return;
+  const int32_t* start = p.start + (int64_t)g * (p.B + 1);
+  const int32_t* rows_g = p.rows + (int64_t)g * p.B;
+  const int base = start[m0];
+  const int R = start[m1] - base;  // <= kRCap by construction of the plan
+  const int ntiles = (R + 15) >> 4;
+  const int N = p.N, E = p.E;
+  const int32_t* ids_g = p.atom_ids[g];
+  const int32_t* conn_g = p.conn[g];
+  const int32_t* bond_g = p.bond_ids[g];
+  const int img_f = img_floats(K);
+  const float* img_g = p.img + (int64_t)g * (p.S > 0 ? p.S : 1) * img_f;
+
+  // ---- prologue ------------------------------------------------------------------------
+  for (int m = tid; m <= M; m += kThreads) {
+    L.moloff[m] = start[m0 + m] - base;
+    if (m < M) L.molrows[m] = rows_g[m0 + m];
+  }
+  for (int t = tid; t < p.Vb * K; t += kThreads) {
+    const int v = t / K, k = t - v * K;
+    L.tb[v * kKMax + k] = p.bond_table[t];
+  }
+  if (K < kKMax)
+    for (int t = tid; t < p.Vb * (kKMax - K); t += kThreads) {
+      const int v = t / (kKMax - K), k = K + (t - v * (kKMax - K));
+      L.tb[v * kKMax + k] = 0.f;
+    }
+  // weights of step 0
+  if (p.S > 0)
+    for (int t = tid; t < img_f / 4; t += kThreads) st4(L.wimg + 4 * t, ld4(img_g + 4 * t));
+  __syncthreads();
+
+  // row -> (molecule, n); in-degree count
+  int my_cnt = 0, my_m = 0, my_n = 0;
+  bool my_real = false;
+  if (tid < kRCap) {
+    const int row = tid;
+    int info = -1;
+    if (row < R) {
+      int lo = 0, hi = M - 1;  // largest m with moloff[m] <= row
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (L.moloff[mid] <= row) lo = mid; else hi = mid - 1;
+      }
+      my_m = lo;
+      my_n = row - L.moloff[lo];
+      my_real = my_n < L.molrows[lo];
+      if (my_real) info = (my_m << 16) | my_n;
+    }
+    L.rowinfo[row] = info;
+    if (my_real) {
+      const int64_t b = m0 + my_m;
+      const int32_t* cn = conn_g + b * E * 2;
+      const int32_t* bd = bond_g + b * E;
+      for (int e = 0; e < E; ++e) {
+        const int2 st = *reinterpret_cast<const int2*>(cn + 2 * e);
+        if (st.y == my_n && edge_valid(st.x, st.y, bd[e], N, p.Vb)) ++my_cnt;
+      }
+    }
+  }
+  // exclusive scan of my_cnt over rows 0..255 (waves 0..3)
+  {
+    int incl = my_cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (tid < kRCap && lane == 63) L.scratch[wave] = incl;
+    __syncthreads();
+    if (tid < kRCap) {
+      int off = 0;
+      for (int w = 0; w < wave; ++w) off += L.scratch[w];
+      const int excl = off + incl - my_cnt;
+      L.rowptr[tid] = excl;
+      if (tid == kRCap - 1) L.rowptr[kRCap] = excl + my_cnt;
+      // fill the in-edge list in edge-slot order
+      if (my_real && my_cnt > 0) {
+        const int64_t b = m0 + my_m;
+        const int32_t* cn = conn_g + b * E * 2;
+        const int32_t* bd = bond_g + b * E;
+        const int mo = L.moloff[my_m];
+        int ptr = excl;
+        for (int e = 0; e < E; ++e) {
+          const int2 st = *reinterpret_cast<const int2*>(cn + 2 * e);
+          const int bid = bd[e];
+          if (st.y == my_n && edge_valid(st.x, st.y, bid, N, p.Vb))
+            L.ent[ptr++] = (uint32_t)(mo + st.x) | ((uint32_t)bid << 16);
+        }
+      }
+    }
+  }
+  // h0 = atom_table[atom_ids]  (train_viscosity.py:171); slack rows = 0; both buffers' tail zeroed
+  for (int t = tid; t < kRCap * 8; t += kThreads) {
+    const int row = t >> 3, part = t & 7;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int info = L.rowinfo[row];
+    if (info >= 0) {
+      const int m = info >> 16, n = info & 0xffff;
+      const int id = ids_g[(int64_t)(m0 + m) * N + n];
+      if ((unsigned)id < (unsigned)p.Va) v = ld4(p.atom_table + (int64_t)id * kD + 4 * part);
+    }
+    st4(L.hbuf0 + row * kHS + 4 * part, v);
+    st4(L.hbuf1 + row * kHS + 4 * part, v);
+  }
+  __syncthreads();
+
+  // ---- message-passing steps -----------------------------------------------------------
+  const int a = lane & 15, q = lane >> 4;
+  const float* wmsg = L.wimg;
+  const float* wupd = L.wimg + img_msg_floats(K);
+  const float* wvec = wupd + img_upd_floats();
+  for (int s = 0; s < p.S; ++s) {
+    const float* hcur = (s & 1) ? L.hbuf1 : L.hbuf0;
+    float* hnext = (s & 1) ? L.hbuf0 : L.hbuf1;
+    // prefetch next step's weight image into registers (written to LDS after the barrier)
+    constexpr int kPf = 8;
+    f32x4 pf[kPf];
+    const bool has_next = (s + 1) < p.S;
+    if (has_next) {
+      const float* nxt = img_g + (int64_t)(s + 1) * img_f;
+#pragma unroll
+      for (int i = 0; i < kPf; ++i) {
+        const int t = tid + i * kThreads;
+        if (t < img_f / 4) pf[i] = ld4(nxt + 4 * t);
+      }
+    }
+
+    for (int tile = wave; tile < ntiles; tile += kWaves) {
+      const int row = tile * 16 + a;
+      const f32x4 h0 = ld4(hcur + row * kHS + 4 * q);
+      const f32x4 h1 = ld4(hcur + row * kHS + 16 + 4 * q);
+
+      // ---- pull gather: G[k][j] = sum_{in-edges} tb[bond][k] * h[src][j]
+      float G[kKMax][8];
+#pragma unroll
+      for (int k = 0; k < kKMax; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) G[k][i] = 0.f;
+      const int p0 = L.rowptr[row];
+      const int deg = L.rowptr[row + 1] - p0;
+      const int maxdeg = wave_max_i(deg);
+      for (int d = 0; d < maxdeg; ++d) {
+        if (d < deg) {
+          const uint32_t ent = L.ent[p0 + d];
+          const int src = ent & 0xffffu, bid = ent >> 16;
+          const f32x4 x0 = ld4(hcur + src * kHS + 4 * q);
+          const f32x4 x1 = ld4(hcur + src * kHS + 16 + 4 * q);
+          const f32x4 c0 = ld4(L.tb + bid * kKMax);
+          const f32x4 c1 = ld4(L.tb + bid * kKMax + 4);
+#pragma unroll
+          for (int k = 0; k < kKMax; ++k) {
+            const float ck = k < 4 ? c0[k & 3] : c1[k & 3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              G[k][i] = fmaf(ck, x0[i], G[k][i]);
+              G[k][4 + i] = fmaf(ck, x1[i], G[k][4 + i]);
+            }
+          }
+        }
+      }
+
+      // ---- agg^T = sum_k W_k * G_k   (models/layers.py:108-112 + 78-82, reassociated)
+      f32x4 agg0 = {0.f, 0.f, 0.f, 0.f}, agg1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < kKMax; ++k) {
+        if (k < K) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const f32x4 A0 = ld4(wmsg + (k * kD + a) * kMsgRS + 16 * u + 4 * q);
+            const f32x4 A1 = ld4(wmsg + (k * kD + 16 + a) * kMsgRS + 16 * u + 4 * q);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              agg0 = mfma4(A0[r], G[k][4 * u + r], agg0);
+              agg1 = mfma4(A1[r], G[k][4 * u + r], agg1);
+            }
+          }
+        }
+      }
+
+      // ---- gates z, r  (models/layers.py:144-147)
+      f32x4 z0 = ld4(wvec + 0 * kD + 4 * q), z1 = ld4(wvec + 0 * kD + 16 + 4 * q);
+      f32x4 r0 = ld4(wvec + 1 * kD + 4 * q), r1 = ld4(wvec + 1 * kD + 16 + 4 * q);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int col = 32 * half + 16 * u + 4 * q;
+          const f32x4 Az0 = ld4(wupd + (0 * kD + a) * kUpdRS + col);
+          const f32x4 Az1 = ld4(wupd + (0 * kD + 16 + a) * kUpdRS + col);
+          const f32x4 Ar0 = ld4(wupd + (1 * kD + a) * kUpdRS + col);
+          const f32x4 Ar1 = ld4(wupd + (1 * kD + 16 + a) * kUpdRS + col);
+          const f32x4 Bv = half == 0 ? (u == 0 ? h0 : h1) : (u == 0 ? agg0 : agg1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            z0 = mfma4(Az0[r], Bv[r], z0);
+            z1 = mfma4(Az1[r], Bv[r], z1);
+            r0 = mfma4(Ar0[r], Bv[r], r0);
+            r1 = mfma4(Ar1[r], Bv[r], r1);
+          }
+        }
+      }
+      f32x4 rh0, rh1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        z0[i] = fast_sigmoid(z0[i]);
+        z1[i] = fast_sigmoid(z1[i]);
+        rh0[i] = fast_sigmoid(r0[i]) * h0[i];  // :149
+        rh1[i] = fast_sigmoid(r1[i]) * h1[i];
+      }
+      // ---- candidate  (models/layers.py:150-151)
+      f32x4 t0 = ld4(wvec + 2 * kD + 4 * q), t1 = ld4(wvec + 2 * kD + 16 + 4 * q);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int col = 32 * half + 16 * u + 4 * q;
+          const f32x4 Ah0 = ld4(wupd + (2 * kD + a) * kUpdRS + col);
+          const f32x4 Ah1 = ld4(wupd + (2 * kD + 16 + a) * kUpdRS + col);
+          const f32x4 Bv = half == 0 ? (u == 0 ? rh0 : rh1) : (u == 0 ? agg0 : agg1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            t0 = mfma4(Ah0[r], Bv[r], t0);
+            t1 = mfma4(Ah1[r], Bv[r], t1);
+          }
+        }
+      }
+      // ---- blend, LayerNorm, residual  (models/layers.py:153-155)
+      f32x4 n0, n1;
+      float sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        n0[i] = (1.0f - z0[i]) * h0[i] + z0[i] * fast_tanh(t0[i]);
+        n1[i] = (1.0f - z1[i]) * h1[i] + z1[i] * fast_tanh(t1[i]);
+        sum += n0[i] + n1[i];
+      }
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+      const float mean = sum * (1.0f / kD);
+      float var = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        n0[i] -= mean;
+        n1[i] -= mean;
+        var = fmaf(n0[i], n0[i], var);
+        var = fmaf(n1[i], n1[i], var);
+      }
+      var += __shfl_xor(var, 16);
+      var += __shfl_xor(var, 32);
+      const float inv = 1.0f / sqrtf(var * (1.0f / kD) + p.ln_eps);
+      const f32x4 g0 = ld4(wvec + 3 * kD + 4 * q), g1 = ld4(wvec + 3 * kD + 16 + 4 * q);
+      const f32x4 b0 = ld4(wvec + 4 * kD + 4 * q), b1 = ld4(wvec + 4 * kD + 16 + 4 * q);
+      f32x4 o0, o1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        o0[i] = n0[i] * inv * g0[i] + b0[i] + h0[i];
+        o1[i] = n1[i] * inv * g1[i] + b1[i] + h1[i];
+      }
+      st4(hnext + row * kHS + 4 * q, o0);
+      st4(hnext + row * kHS + 16 + 4 * q, o1);
+    }
+    __syncthreads();
+    if (has_next) {
+#pragma unroll
+      for (int i = 0; i < kPf; ++i) {
+        const int t = tid + i * kThreads;
+        if (t < img_f / 4) st4(L.wimg + 4 * t, pf[i]);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- GlobalSumPool (models/layers.py:161-164): rows with atom_ids > 0, ascending n
+  const float* hfin = (p.S & 1) ? L.hbuf1 : L.hbuf0;
+  float* out_g = p.pooled[g];
+  for (int t = tid; t < M * kD; t += kThreads) {
+    const int m = t >> 5, f = t & 31;
+    const int nr = L.molrows[m], mo = L.moloff[m];
+    const int32_t* ids = ids_g + (int64_t)(m0 + m) * N;
+    float acc = 0.f;
+    for (int n = 0; n < nr; ++n)
+      if (ids[n] > 0) acc += hfin[(mo + n) * kHS + f];
+    out_g[(int64_t)(m0 + m) * kD + f] = acc;
+  }
+}
+
+}  // namespace
+
+bool encoder_fused_supported(int N, int E, int D, int K, int S, int Vb) {
+  if (D != kD || K < 1 || K > kKMax || S < 0) return false;
+  if (N < 1 || N > 0xffff || E < 0) return false;
+  if (Vb < 1 || Vb > 0xffff || (int64_t)Vb * kKMax > kTbCapFloats) return false;
+  const int vrmax = vr_max_of(N, E);
+  if (vrmax > kRCap / 2) return false;  // keep the packing window >= half a chunk
+  return true;
+}
+
+size_t encoder_fused_workspace_bytes(int n_ions, int B, int N, int E, int D, int K, int S, int Vb) {
+  (void)D; (void)Vb;
+  return ws_layout(n_ions, B, N, E, K, S).total;
+}
+
+int launch_encoder_fused(const EncoderArgs& a, hipStream_t s) {
+  const Ws w = ws_layout(a.n_ions, a.B, a.N, a.E, a.K, a.S);
+  if (!aligned16(a.workspace)) return fail(IMPNN_E_BADARG, "encoder_fused: workspace must be 16B aligned");
+  if (!aligned16(a.atom_table)) return fail(IMPNN_E_BADARG, "encoder_fused: atom_table must be 16B aligned");
+  char* base = static_cast<char*>(a.workspace);
+  PlanParams pp{};
+  EncParams ep{};
+  for (int g = 0; g < a.n_ions; ++g) {
+    if ((reinterpret_cast<uintptr_t>(a.conn[g]) & 7u) != 0)
+      return fail(IMPNN_E_BADARG, "encoder_fused: connectivity must be 8B aligned");
+    pp.atom_ids[g] = ep.atom_ids[g] = a.atom_ids[g];
+    pp.bond_ids[g] = ep.bond_ids[g] = a.bond_ids[g];
+    pp.conn[g] = ep.conn[g] = a.conn[g];
+    pp.weights[g] = a.weights[g];
+    ep.pooled[g] = a.pooled[g];
+  }
+  pp.img = reinterpret_cast<float*>(base + w.img_off);
+  pp.rows = reinterpret_cast<int32_t*>(base + w.rows_off);
+  pp.vr = reinterpret_cast<int32_t*>(base + w.vr_off);
+  pp.start = reinterpret_cast<int32_t*>(base + w.start_off);
+  pp.first = reinterpret_cast<int32_t*>(base + w.first_off);
+  pp.nchunks = reinterpret_cast<int32_t*>(base + w.nchunks_off);
+  pp.n_ions = a.n_ions; pp.B = a.B; pp.N = a.N; pp.E = a.E; pp.K = a.K; pp.S = a.S; pp.Vb = a.Vb;
+  pp.win = kRCap - vr_max_of(a.N, a.E) + 1;
+  pp.ub = w.ub;
+  pp.step_floats = impnn_encoder_step_floats(a.D, a.K);
+  const int waves_per_block = 4;
+  pp.mol_blocks = (int)(((int64_t)a.n_ions * a.B + waves_per_block - 1) / waves_per_block);
+  const int img_blocks = a.n_ions * a.S;
+  plan_stats_kernel<<<pp.mol_blocks + img_blocks, 64 * waves_per_block, 0, s>>>(pp);
+  if (int rc = check_launch("plan_stats")) return rc;
+  plan_scan_kernel<<<a.n_ions, 1024, 0, s>>>(pp);
+  if (int rc = check_launch("plan_scan")) return rc;
+
+  ep.atom_table = a.atom_table;
+  ep.bond_table = a.bond_table;
+  ep.img = pp.img; ep.rows = pp.rows; ep.start = pp.start; ep.first = pp.first; ep.nchunks = pp.nchunks;
+  ep.n_ions = a.n_ions; ep.B = a.B; ep.N = a.N; ep.E = a.E; ep.K = a.K; ep.S = a.S;
+  ep.Va = a.Va; ep.Vb = a.Vb; ep.ub = w.ub; ep.ln_eps = a.ln_eps;
+  const size_t lds = lds_bytes(a.K);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)encoder_fused_kernel,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return fail(IMPNN_E_LAUNCH, "encoder_fused: cannot raise LDS limit: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  profile_record_start(s);
+  encoder_fused_kernel<<<w.ub * a.n_ions, kThreads, lds, s>>>(ep);
+  profile_record_stop(s);
+  return check_launch("encoder_fused");
+}
+
+}  // namespace impnn

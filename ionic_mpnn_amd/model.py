@@ -1,0 +1,255 @@
+"""build_model() of the reference's trainers, wired from ionic_mpnn_amd.layers.
+
+``build_model`` (viscosity, train_viscosity.py:139-231) and ``build_melting_point_model``
+(train_melting_point.py:137-215) keep the reference's signatures/defaults and create the layers in
+the reference's order, so Keras-style auto names (gated_update_2, dense_3, ...) line up.
+
+Two execution schedules, both on the HIP library:
+  * ``fused=True`` (default when the shape is covered): one impnn_encoder_fused launch computes
+    both ions' encode() up to GlobalSumPool;
+  * ``fused=False``: layer at a time through the drop-in layers (a1..a8), tensor boundaries
+    identical to the reference's.
+The few Dense head layers are torch addmm on the same stream.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import layers as L
+from . import ops
+
+INPUT_NAMES = ["cat_atom", "cat_bond", "cat_connectivity", "an_atom", "an_bond", "an_connectivity", "temperature"]
+
+
+class MPNNModel:
+    def __init__(self, kind, atom_vocab_size, bond_vocab_size, atom_dim, bond_dim, fp_size, mixing_size,
+                 num_steps, fp_l2, device=None, name=None):
+        self.kind = kind
+        self.name = name or ("MeltingPoint_MPNN" if kind == "melting_point" else "model")
+        self.atom_vocab_size, self.bond_vocab_size = int(atom_vocab_size), int(bond_vocab_size)
+        self.atom_dim, self.bond_dim = int(atom_dim), int(bond_dim)
+        self.fp_size, self.mixing_size, self.num_steps = int(fp_size), int(mixing_size), int(num_steps)
+        self.device = device or L.default_device()
+        dev = dict(device=self.device)
+        D, K, S = self.atom_dim, self.bond_dim, self.num_steps
+        # shared embeddings (train_viscosity.py:163-164)
+        self.atom_emb = L.Embedding(atom_vocab_size, D, mask_zero=False, **dev)
+        self.bond_emb = L.Embedding(bond_vocab_size, K, mask_zero=False, lazy=True, **dev)
+        self.branches = {}
+        for p in ("cat", "an"):  # encode(), train_viscosity.py:166-190, called at :193-194
+            br = {"bmm": [], "reduce": [], "update": []}
+            for i in range(S):
+                br["bmm"].append(L.BondMatrixMessage(D, K, name=f"{p}_bmm_{i}", **dev))
+                br["reduce"].append(L.Reduce(name=f"{p}_reduce_{i}", **dev))
+                br["update"].append(L.GatedUpdate(D, **dev))
+            br["pool"] = L.GlobalSumPool(**dev)
+            br["fp"] = L.Dense(fp_size, activation="relu", kernel_regularizer=("l2", fp_l2), **dev)
+            self.branches[p] = br
+        self.cat_proj = L.Dense(mixing_size, activation="relu", **dev)  # :197
+        self.an_proj = L.Dense(mixing_size, activation="relu", **dev)   # :198
+        if kind == "viscosity":
+            self.mix = L.AddTwoTensors(name="mix_cat_an", **dev)        # :201
+            self.visc_params = L.Dense(3, **dev)                        # :204
+            self.param_A = L.SliceParamA(name="param_A", **dev)
+            self.param_B = L.SliceParamB(name="param_B", **dev)
+            self.param_C = L.SliceParamC(name="param_C", **dev)
+            self.scale_T = L.ScaleTemperature(name="scale_T", **dev)
+            self.log_eta = L.ComputeLogEta(name="log_eta", **dev)
+        else:
+            self.mix = L.AddTwoTensors(name="add", **dev)               # keras Add(), train_melting_point.py:191
+            self.mp_hidden = L.Dense(fp_size, activation="relu", kernel_regularizer=("l2", fp_l2), **dev)  # :197
+            self.mp_out = L.Dense(1, **dev)                             # :198
+        self._build_all()
+        self._packed = None
+
+    # ------------------------------------------------------------------ construction
+    def _build_all(self):
+        D, K = self.atom_dim, self.bond_dim
+        for lyr, shape in ((self.atom_emb, (None, None)), (self.bond_emb, (None, None))):
+            lyr.build(shape); lyr.built = True
+        for p in ("cat", "an"):
+            br = self.branches[p]
+            for i in range(self.num_steps):
+                br["bmm"][i].build([(None, None, D), (None, None, K), (None, None, 2)]); br["bmm"][i].built = True
+                br["update"][i].build([(None, None, D), (None, None, D)]); br["update"][i].built = True
+                br["reduce"][i].built = True
+            br["pool"].built = True
+            br["fp"].build((None, D)); br["fp"].built = True
+        for lyr in (self.cat_proj, self.an_proj):
+            lyr.build((None, self.fp_size)); lyr.built = True
+        if self.kind == "viscosity":
+            self.visc_params.build((None, self.mixing_size)); self.visc_params.built = True
+        else:
+            self.mp_hidden.build((None, self.mixing_size)); self.mp_hidden.built = True
+            self.mp_out.build((None, self.fp_size)); self.mp_out.built = True
+
+    @property
+    def layers(self):
+        out = [self.atom_emb, self.bond_emb]
+        for p in ("cat", "an"):
+            br = self.branches[p]
+            for i in range(self.num_steps):
+                out += [br["bmm"][i], br["reduce"][i], br["update"][i]]
+            out += [br["pool"], br["fp"]]
+        out += [self.cat_proj, self.an_proj, self.mix]
+        if self.kind == "viscosity":
+            out += [self.visc_params, self.param_A, self.param_B, self.param_C, self.scale_T, self.log_eta]
+        else:
+            out += [self.mp_hidden, self.mp_out]
+        return out
+
+    def get_layer(self, name):
+        for lyr in self.layers:
+            if lyr.name == name:
+                return lyr
+        raise ValueError(f"No such layer: {name}")
+
+    # ------------------------------------------------------------------ weights
+    def _named_tensors(self):
+        t = {"atom_embedding": self.atom_emb.embeddings, "bond_embedding": self.bond_emb.embeddings}
+        for p in ("cat", "an"):
+            br = self.branches[p]
+            for i in range(self.num_steps):
+                t[f"{p}_bmm_{i}/bond_transform"] = br["bmm"][i].bond_transform
+                for wn, w in br["update"][i]._weights.items():
+                    t[f"{p}_gu_{i}/{wn}"] = w
+            t[f"{p}_fp/kernel"], t[f"{p}_fp/bias"] = br["fp"].kernel, br["fp"].bias
+        t["cat_proj/kernel"], t["cat_proj/bias"] = self.cat_proj.kernel, self.cat_proj.bias
+        t["an_proj/kernel"], t["an_proj/bias"] = self.an_proj.kernel, self.an_proj.bias
+        if self.kind == "viscosity":
+            t["visc_params/kernel"], t["visc_params/bias"] = self.visc_params.kernel, self.visc_params.bias
+        else:
+            t["mp_hidden/kernel"], t["mp_hidden/bias"] = self.mp_hidden.kernel, self.mp_hidden.bias
+            t["mp_out/kernel"], t["mp_out/bias"] = self.mp_out.kernel, self.mp_out.bias
+        return t
+
+    def state_dict(self):
+        return {k: v.detach().cpu().numpy().copy() for k, v in self._named_tensors().items()}
+
+    def load_weights(self, weights):
+        """weights: dict name -> array in the naming of ionic_mpnn_amd.weights."""
+        named = self._named_tensors()
+        missing = sorted(set(named) - set(weights))
+        if missing:
+            raise KeyError(f"missing weights: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+        for k, t in named.items():
+            a = np.ascontiguousarray(np.asarray(weights[k], dtype=np.float32))
+            if tuple(a.shape) != tuple(t.shape):
+                raise ValueError(f"{k}: shape {a.shape} != {tuple(t.shape)}")
+            t.copy_(torch.from_numpy(a))
+        self._packed = None
+
+    def invalidate_packed_weights(self):
+        """Call after mutating layer weights in place; the fused encoder caches a packed copy."""
+        self._packed = None
+
+    def _packed_weights(self):
+        if self._packed is None:
+            packed = []
+            for p in ("cat", "an"):
+                br = self.branches[p]
+                steps = []
+                for i in range(self.num_steps):
+                    w = br["update"][i]._weights
+                    steps.append({"bond_transform": br["bmm"][i].bond_transform,
+                                  "Wz": w["dense_z/kernel"], "bz": w["dense_z/bias"],
+                                  "Wr": w["dense_r/kernel"], "br": w["dense_r/bias"],
+                                  "Wh": w["dense_h/kernel"], "bh": w["dense_h/bias"],
+                                  "gamma": w["layernorm/gamma"], "beta": w["layernorm/beta"]})
+                packed.append(ops.pack_step_weights(steps))
+            self._packed = packed
+        return self._packed
+
+    # ------------------------------------------------------------------ forward
+    def fused_supported(self, N, E):
+        return ops.encoder_fused_supported(N, E, self.atom_dim, self.bond_dim, self.num_steps, self.bond_vocab_size)
+
+    def encode_layered(self, prefix, atom_ids, bond_ids, conn, trace=None, typed=True):
+        """encode() layer at a time (train_viscosity.py:171-187) -> pooled (B,D)."""
+        br = self.branches[prefix]
+        h = self.atom_emb(atom_ids)
+        bond = self.bond_emb(bond_ids)
+        if not typed:
+            bond = bond.dense()
+        for i in range(self.num_steps):
+            m = br["bmm"][i]([h, bond, conn])
+            agg = br["reduce"][i]([m, conn[:, :, 1], h])
+            h = br["update"][i]([h, agg])
+            if trace is not None:
+                trace[f"{prefix}/m{i}"], trace[f"{prefix}/agg{i}"], trace[f"{prefix}/h{i + 1}"] = m, agg, h
+        pooled = br["pool"]([h, atom_ids])
+        if trace is not None:
+            trace[f"{prefix}/pooled"] = pooled
+        return pooled
+
+    def encode_pooled(self, inputs, fused=None, trace=None):
+        """Both ions' GlobalSumPool outputs: the hot path."""
+        ca, cb, cc = inputs["cat_atom"], inputs["cat_bond"], inputs["cat_connectivity"]
+        aa, ab, ac = inputs["an_atom"], inputs["an_bond"], inputs["an_connectivity"]
+        if fused is None:
+            fused = (tuple(ca.shape) == tuple(aa.shape) and tuple(cb.shape) == tuple(ab.shape)
+                     and self.fused_supported(ca.shape[1], cb.shape[1]))
+        if fused:
+            pc, pa = ops.encoder_fused([(ca, cb, cc), (aa, ab, ac)], self.atom_emb.embeddings,
+                                       self.bond_emb.embeddings, self._packed_weights(), self.num_steps)
+            if trace is not None:
+                trace["cat/pooled"], trace["an/pooled"] = pc, pa
+            return pc, pa
+        return (self.encode_layered("cat", ca, cb, cc, trace), self.encode_layered("an", aa, ab, ac, trace))
+
+    def head(self, pooled_cat, pooled_an, temperature=None, trace=None):
+        fp_cat = self.branches["cat"]["fp"](pooled_cat)   # Dense(fp_size, relu), :189
+        fp_an = self.branches["an"]["fp"](pooled_an)
+        mixed = self.mix([self.cat_proj(fp_cat), self.an_proj(fp_an)])
+        if trace is not None:
+            trace["cat/fp"], trace["an/fp"], trace["mixed"] = fp_cat, fp_an, mixed
+        if self.kind == "viscosity":
+            vp = self.visc_params(mixed)
+            if trace is not None:
+                trace["visc_params"] = vp
+            T = self.scale_T(temperature.to(torch.float32).reshape(-1, 1))
+            return self.log_eta([self.param_A(vp), self.param_B(vp), T, self.param_C(vp)])
+        return self.mp_out(self.mp_hidden(mixed))
+
+    def __call__(self, inputs, fused=None, trace=None):
+        inputs = self._to_device(inputs)
+        pc, pa = self.encode_pooled(inputs, fused=fused, trace=trace)
+        return self.head(pc, pa, inputs.get("temperature"), trace=trace)
+
+    def predict(self, inputs, batch_size=None, fused=None):
+        """model.predict(x) (train_viscosity.py:366): returns a numpy (n,1) array.  The reference's
+        Keras default batch is 32; here the whole set is one batch unless batch_size is given."""
+        n = len(inputs["cat_atom"])
+        bs = n if not batch_size else int(batch_size)
+        outs = []
+        for lo in range(0, n, bs):
+            chunk = {k: v[lo:lo + bs] for k, v in inputs.items()}
+            outs.append(self(chunk, fused=fused).detach().cpu().numpy())
+        return np.concatenate(outs, axis=0) if outs else np.zeros((0, 1), np.float32)
+
+    def _to_device(self, inputs):
+        out = {}
+        for k, v in inputs.items():
+            if isinstance(v, np.ndarray):
+                v = torch.from_numpy(v)
+            if not isinstance(v, torch.Tensor):
+                raise TypeError(f"input {k!r} must be a numpy array or torch tensor")
+            out[k] = v.to(self.device, non_blocking=True)
+        if self.kind == "viscosity" and "temperature" not in out:
+            raise KeyError("the viscosity model needs a 'temperature' input (train_viscosity.py:160)")
+        return out
+
+
+def build_model(atom_vocab_size, bond_vocab_size, atom_dim=32, bond_dim=8, fp_size=32, mixing_size=20,
+                num_steps=4, device=None):
+    """train_viscosity.py:139-231 (same positional/keyword signature and defaults)."""
+    return MPNNModel("viscosity", atom_vocab_size, bond_vocab_size, atom_dim, bond_dim, fp_size, mixing_size,
+                     num_steps, fp_l2=1e-4, device=device)
+
+
+def build_melting_point_model(atom_vocab_size, bond_vocab_size, atom_dim=32, fp_size=32, mixing_size=20,
+                              num_steps=4, device=None):
+    """train_melting_point.py:137-215: bond embedding width = atom_dim**2 (:146)."""
+    return MPNNModel("melting_point", atom_vocab_size, bond_vocab_size, atom_dim, atom_dim * atom_dim, fp_size,
+                     mixing_size, num_steps, fp_l2=1e-5, device=device)

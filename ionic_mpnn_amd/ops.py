@@ -1,0 +1,259 @@
+"""Functional wrappers: torch CUDA tensors in, torch CUDA tensors out, every one a libimpnn call on
+the tensor's device and torch's current stream.  Shapes/dtypes follow the reference tensors
+(int32 ids and connectivity, float32 state)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, f32c, i32c, ptr, require_gpu, stream_ptr
+
+LN_EPS = 1e-3  # keras LayerNormalization default (models/layers.py:139)
+DEBUG_VALIDATE = False  # True: raise like TF-CPU on out-of-range indices (costs a device sync)
+
+
+def embed_gather(ids, table):
+    """Embedding(mask_zero=False) lookup, train_viscosity.py:171-172."""
+    require_gpu(ids, table)
+    ids = i32c(ids)
+    table = f32c(table)
+    out = torch.empty(*ids.shape, table.shape[1], dtype=torch.float32, device=table.device)
+    with torch.cuda.device(table.device):
+        check(_lib.load().impnn_embed_gather(ptr(ids), ptr(table), ptr(out), ids.numel(), table.shape[0],
+                                             table.shape[1], stream_ptr()))
+    return out
+
+
+def _check_bmm_shapes(h, conn):
+    if h.dim() != 3:
+        raise ValueError(f"atom_state must be (B,N,D), got {tuple(h.shape)}")
+    if conn.dim() != 3 or conn.shape[-1] != 2 or conn.shape[0] != h.shape[0]:
+        raise ValueError(f"connectivity must be (B,E,2) with the batch of atom_state, got {tuple(conn.shape)}")
+
+
+def validate_indices(conn=None, atom_ids=None, bond_ids=None, N=None, Va=1 << 30, Vb=1 << 30):
+    """Raises ValueError where tf-CPU's gather/scatter_nd would (models/layers.py:106,78-82)."""
+    ref = conn if conn is not None else (atom_ids if atom_ids is not None else bond_ids)
+    require_gpu(ref)
+    B = ref.shape[0]
+    E = conn.shape[1] if conn is not None else (bond_ids.shape[1] if bond_ids is not None else 0)
+    Nn = N if N is not None else (atom_ids.shape[1] if atom_ids is not None else 1)
+    counts = torch.zeros(3, dtype=torch.int32, device=ref.device)
+    with torch.cuda.device(ref.device):
+        check(_lib.load().impnn_validate_indices(
+            ptr(i32c(conn)) if conn is not None else None,
+            ptr(i32c(atom_ids)) if atom_ids is not None else None,
+            ptr(i32c(bond_ids)) if bond_ids is not None else None,
+            ptr(counts), B, Nn, E, Va, Vb, stream_ptr()))
+    c = counts.tolist()
+    if any(c):
+        raise ValueError(f"out-of-range indices: connectivity={c[0]} atom_ids={c[1]} bond_ids={c[2]}")
+
+
+def bmm_message(h, bond_state, conn, W):
+    """BondMatrixMessage.call, models/layers.py:100-117 -> messages (B,E,D)."""
+    require_gpu(h, bond_state, conn, W)
+    _check_bmm_shapes(h, conn)
+    h, bond_state, W, conn = f32c(h), f32c(bond_state), f32c(W), i32c(conn)
+    B, N, D = h.shape
+    E, K = conn.shape[1], W.shape[0]
+    if tuple(bond_state.shape) != (B, E, K) or tuple(W.shape) != (K, D, D):
+        raise ValueError(f"bond_state {tuple(bond_state.shape)} / bond_transform {tuple(W.shape)} do not match "
+                         f"(B,E,K)=({B},{E},{K}), (K,D,D)=({K},{D},{D})")
+    if DEBUG_VALIDATE:
+        validate_indices(conn=conn, N=N)
+    m = torch.empty(B, E, D, dtype=torch.float32, device=h.device)
+    with torch.cuda.device(h.device):
+        check(_lib.load().impnn_bmm_message(ptr(h), ptr(bond_state), ptr(conn), ptr(W), ptr(m), B, N, E, D, K,
+                                            stream_ptr()))
+    return m
+
+
+def bond_type_matrices(bond_table, W):
+    """A[v] = sum_k bond_table[v,k] W[k]  (models/layers.py:108 once per vocabulary entry)."""
+    require_gpu(bond_table, W)
+    bond_table, W = f32c(bond_table), f32c(W)
+    Vb, K = bond_table.shape
+    D = W.shape[-1]
+    if W.numel() != K * D * D:
+        raise ValueError("bond_transform does not match bond_table")
+    out = torch.empty(Vb, D, D, dtype=torch.float32, device=W.device)
+    with torch.cuda.device(W.device):
+        check(_lib.load().impnn_bond_type_matrices(ptr(bond_table), ptr(W), ptr(out), Vb, K, D, stream_ptr()))
+    return out
+
+
+def bmm_message_typed(h, bond_ids, conn, type_mats):
+    require_gpu(h, bond_ids, conn, type_mats)
+    _check_bmm_shapes(h, conn)
+    h, type_mats, conn, bond_ids = f32c(h), f32c(type_mats), i32c(conn), i32c(bond_ids)
+    B, N, D = h.shape
+    E, Vb = conn.shape[1], type_mats.shape[0]
+    if DEBUG_VALIDATE:
+        validate_indices(conn=conn, bond_ids=bond_ids, N=N, Vb=Vb)
+    m = torch.empty(B, E, D, dtype=torch.float32, device=h.device)
+    with torch.cuda.device(h.device):
+        check(_lib.load().impnn_bmm_message_typed(ptr(h), ptr(bond_ids), ptr(conn), ptr(type_mats), ptr(m), B, N,
+                                                  E, D, Vb, stream_ptr()))
+    return m
+
+
+def reduce_scatter_add(messages, tgt_idx, num_atoms):
+    """Reduce.call, models/layers.py:57-83.  `tgt_idx` may be the strided view conn[:, :, 1]
+    (train_viscosity.py:182); it is then read in place."""
+    require_gpu(messages, tgt_idx)
+    messages = f32c(messages)
+    B, E, D = messages.shape
+    if tgt_idx.dtype != torch.int32:
+        tgt_idx = i32c(tgt_idx)
+    if tuple(tgt_idx.shape) != (B, E):
+        raise ValueError(f"tgt_idx must be (B,E)=({B},{E}), got {tuple(tgt_idx.shape)}")
+    stride = 1
+    if not tgt_idx.is_contiguous():
+        if B * E > 0 and tgt_idx.stride(1) == 2 and (tgt_idx.stride(0) == 2 * E or B == 1):
+            stride = 2  # a conn[:, :, 1] view
+        else:
+            tgt_idx = tgt_idx.contiguous()
+    if DEBUG_VALIDATE:
+        validate_indices(conn=tgt_idx.contiguous().unsqueeze(-1).expand(B, E, 2), N=num_atoms)
+    agg = torch.empty(B, num_atoms, D, dtype=torch.float32, device=messages.device)
+    with torch.cuda.device(messages.device):
+        check(_lib.load().impnn_reduce_scatter_add(ptr(messages), ptr(tgt_idx), stride, ptr(agg), B, num_atoms,
+                                                   E, D, stream_ptr()))
+    return agg
+
+
+def bmm_fused(h, bond_state, conn, W):
+    """Orphan models/bond_matrix_message.py:37-65 signature: -> aggregated (B,N,D)."""
+    require_gpu(h, bond_state, conn, W)
+    _check_bmm_shapes(h, conn)
+    h, bond_state, W, conn = f32c(h), f32c(bond_state), f32c(W), i32c(conn)
+    B, N, D = h.shape
+    E, K = conn.shape[1], bond_state.shape[-1]
+    if W.numel() != K * D * D:
+        raise ValueError("bond_transform must hold K*D*D values")
+    agg = torch.empty(B, N, D, dtype=torch.float32, device=h.device)
+    if E == 0:
+        return agg.zero_()
+    with torch.cuda.device(h.device):
+        check(_lib.load().impnn_bmm_fused(ptr(h), ptr(bond_state), ptr(conn), ptr(W), ptr(agg), B, N, E, D, K,
+                                          stream_ptr()))
+    return agg
+
+
+def gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps=LN_EPS):
+    """GatedUpdate.call, models/layers.py:142-156."""
+    require_gpu(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta)
+    if h.shape != agg.shape:
+        raise ValueError(f"atom_state {tuple(h.shape)} and agg {tuple(agg.shape)} differ")
+    D = h.shape[-1]
+    for name, w in (("dense_z", Wz), ("dense_r", Wr), ("dense_h", Wh)):
+        if tuple(w.shape) != (2 * D, D):
+            raise ValueError(f"{name} kernel must be (2D,D)=({2 * D},{D}), got {tuple(w.shape)}")
+    ts = [f32c(t) for t in (h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta)]
+    out = torch.empty_like(ts[0])
+    rows = ts[0].numel() // D
+    with torch.cuda.device(h.device):
+        check(_lib.load().impnn_gated_update(*[ptr(t) for t in ts], float(eps), ptr(out), rows, D, stream_ptr()))
+    return out
+
+
+def global_sum_pool(h, atom_ids):
+    """GlobalSumPool.call, models/layers.py:161-164."""
+    require_gpu(h, atom_ids)
+    h, atom_ids = f32c(h), i32c(atom_ids)
+    B, N, D = h.shape
+    if tuple(atom_ids.shape) != (B, N):
+        raise ValueError(f"atom_ids must be (B,N)=({B},{N}), got {tuple(atom_ids.shape)}")
+    out = torch.empty(B, D, dtype=torch.float32, device=h.device)
+    with torch.cuda.device(h.device):
+        check(_lib.load().impnn_global_sum_pool(ptr(h), ptr(atom_ids), ptr(out), B, N, D, stream_ptr()))
+    return out
+
+
+def encoder_step_floats(D, K):
+    return int(_lib.load().impnn_encoder_step_floats(D, K))
+
+
+def pack_step_weights(steps):
+    """steps: list of dicts with bond_transform,Wz,bz,Wr,br,Wh,bh,gamma,beta (torch tensors) ->
+    one float32 tensor in the canonical layout of include/impnn.h."""
+    parts = []
+    for s in steps:
+        for k in ("bond_transform", "Wz", "bz", "Wr", "br", "Wh", "bh", "gamma", "beta"):
+            parts.append(f32c(s[k]).reshape(-1))
+    return torch.cat(parts) if parts else None
+
+
+class EncoderUnsupported(RuntimeError):
+    pass
+
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def encoder_fused_supported(N, E, D, K, S, Vb):
+    out = C.c_size_t(0)
+    rc = _lib.load().impnn_encoder_workspace_bytes(1, 1, N, E, D, K, S, Vb, C.byref(out))
+    return rc == 0
+
+
+def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=LN_EPS):
+    """encode() up to GlobalSumPool for 1 or 2 ion branches in one launch.
+
+    ions: list of (atom_ids (B,N), bond_ids (B,E), conn (B,E,2)); packed_weights: list of packed
+    step-weight tensors (pack_step_weights).  Returns a list of pooled (B,D) tensors.
+    """
+    n = len(ions)
+    if n not in (1, 2):
+        raise ValueError("1 or 2 ion branches")
+    atom_table, bond_table = f32c(atom_table), f32c(bond_table)
+    require_gpu(atom_table, bond_table)
+    dev = atom_table.device
+    prepared = []
+    for (a, b, c) in ions:
+        require_gpu(a, b, c)
+        prepared.append((i32c(a), i32c(b), i32c(c)))
+    B, N = prepared[0][0].shape
+    E = prepared[0][1].shape[1]
+    for (a, b, c) in prepared:
+        if tuple(a.shape) != (B, N) or tuple(b.shape) != (B, E) or tuple(c.shape) != (B, E, 2):
+            raise ValueError("ion branches must share (B,N,E)")
+    Va, D = atom_table.shape
+    Vb, K = bond_table.shape
+    S = int(num_steps)
+    lib = _lib.load()
+    need = C.c_size_t(0)
+    rc = lib.impnn_encoder_workspace_bytes(n, B, N, E, D, K, S, Vb, C.byref(need))
+    if rc == _lib.IMPNN_E_UNSUPPORTED:
+        raise EncoderUnsupported(lib.impnn_last_error_string().decode())
+    check(rc)
+    if DEBUG_VALIDATE:
+        for (a, b, c) in prepared:
+            validate_indices(conn=c, atom_ids=a, bond_ids=b, N=N, Va=Va, Vb=Vb)
+    ws = _workspace(dev, need.value)
+    pooled = [torch.empty(B, D, dtype=torch.float32, device=dev) for _ in range(n)]
+    ws_w = [f32c(w) if w is not None else None for w in packed_weights]
+    step_f = encoder_step_floats(D, K)
+    for w in ws_w:
+        if S > 0 and (w is None or w.numel() != S * step_f):
+            raise ValueError(f"packed step weights must hold S*{step_f} floats")
+    arr = C.c_void_p * n
+    mk = lambda ts: arr(*[t.data_ptr() if t is not None else 0 for t in ts])
+    with torch.cuda.device(dev):
+        check(lib.impnn_encoder_fused(n, mk([p[0] for p in prepared]), mk([p[1] for p in prepared]),
+                                      mk([p[2] for p in prepared]), ptr(atom_table), Va, ptr(bond_table), Vb,
+                                      mk(ws_w), mk(pooled), B, N, E, D, K, S, float(eps), ptr(ws), ws.numel(),
+                                      stream_ptr()))
+    return pooled

@@ -1,0 +1,112 @@
+"""Synthetic padded cation/anion graph batches.
+
+The reference's datasets (viscosity_id_data.pkl, mp_id_data.pkl, vocab.pkl) are git-ignored
+and absent, so every measured configuration runs on graphs drawn here:
+
+  per ion: n_atoms ~ U{min_atoms..max_atoms}; a random spanning tree (n-1 bonds) plus
+  U{0..1} ring closures, capped so that 2*n_bonds <= E; both directions of a bond are
+  emitted adjacently as (u,v),(v,u) with **0-based** atom indices, exactly like
+  src/featurize.py:54-63 - so the reference's "index 0 is padding" quirk
+  (models/layers.py:74,114) is exercised; atom_ids ~ U{1..Va-1}, bond_ids ~ U{1..Vb-1}
+  (the +1 shift of train_viscosity.py:255-262 already applied); zero padding to N, E.
+
+Va=124 / Vb=72 are stand-ins (README.md:175-176 plus the padding id).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+DEFAULT_VA = 124
+DEFAULT_VB = 72
+
+
+def _one_ion(rng, B, N, E, Va, Vb, min_atoms, max_atoms):
+    n = rng.integers(min_atoms, max_atoms + 1, size=B)
+    col = np.arange(N)
+    # spanning tree: parent[v] uniform in [0, v)
+    par = np.floor(rng.random((B, N)) * col[None, :]).astype(np.int64)
+    atom_ids = rng.integers(1, Va, size=(B, N))
+    atom_ids = np.where(col[None, :] < n[:, None], atom_ids, 0).astype(np.int32)
+
+    nb_slots = E // 2
+    bu = np.zeros((B, nb_slots), dtype=np.int64)
+    bv = np.zeros((B, nb_slots), dtype=np.int64)
+    bvalid = np.zeros((B, nb_slots), dtype=bool)
+    jt = min(N - 1, nb_slots)
+    v = np.arange(1, jt + 1)
+    bu[:, :jt] = par[:, 1:jt + 1]
+    bv[:, :jt] = v[None, :]
+    bvalid[:, :jt] = v[None, :] < n[:, None]
+
+    # 0/1 ring closure in the slot right after the tree bonds
+    flag = rng.integers(0, 2, size=B).astype(bool)
+    cu = np.floor(rng.random(B) * n).astype(np.int64)
+    cv = np.floor(rng.random(B) * n).astype(np.int64)
+    rows = np.arange(B)
+    ok = flag & (cu != cv) & (par[rows, cv] != cu) & (par[rows, cu] != cv) & (n - 1 < nb_slots)
+    slot = np.minimum(n - 1, nb_slots - 1)
+    bu[rows[ok], slot[ok]] = cu[ok]
+    bv[rows[ok], slot[ok]] = cv[ok]
+    bvalid[rows[ok], slot[ok]] = True
+
+    bid = rng.integers(1, Vb, size=(B, nb_slots))
+    bid = np.where(bvalid, bid, 0)
+    bu = np.where(bvalid, bu, 0)
+    bv = np.where(bvalid, bv, 0)
+
+    conn = np.zeros((B, E, 2), dtype=np.int32)
+    bond = np.zeros((B, E), dtype=np.int32)
+    conn[:, 0:2 * nb_slots:2, 0] = bu
+    conn[:, 0:2 * nb_slots:2, 1] = bv
+    conn[:, 1:2 * nb_slots:2, 0] = bv
+    conn[:, 1:2 * nb_slots:2, 1] = bu
+    bond[:, 0:2 * nb_slots:2] = bid
+    bond[:, 1:2 * nb_slots:2] = bid
+    return atom_ids, bond, conn
+
+
+def make_batch(batch, max_atoms=40, max_edges=80, atom_vocab_size=DEFAULT_VA,
+               bond_vocab_size=DEFAULT_VB, min_atoms=8, seed=0, with_temperature=True):
+    """Returns the reference's 7 named model inputs (train_viscosity.py:150-160,306-314) as
+    numpy arrays: int32 ids / connectivity, float32 temperature (B,1)."""
+    rng = np.random.default_rng(seed)
+    min_atoms = min(min_atoms, max_atoms)
+    out = {}
+    for p in ("cat", "an"):
+        a, b, c = _one_ion(rng, batch, max_atoms, max_edges, atom_vocab_size, bond_vocab_size,
+                           min_atoms, max_atoms)
+        out[f"{p}_atom"], out[f"{p}_bond"], out[f"{p}_connectivity"] = a, b, c
+    if with_temperature:
+        out["temperature"] = rng.uniform(253.0, 393.0, size=(batch, 1)).astype(np.float32)
+    return out
+
+
+def make_id_records(num, seed=0, min_atoms=3, max_atoms=12, atom_vocab=20, bond_vocab=6, kind="viscosity"):
+    """Synthetic ``*_id_data.pkl`` records in the schema of src/dataset.py:15-20,51-62
+    (0-based ids, featurize-style bidirectional edge list, python lists)."""
+    rng = np.random.default_rng(seed)
+    recs = []
+    for r in range(num):
+        rec = {"pair_id": f"pair_{r}"}
+        for ion in ("cation", "anion"):
+            n = int(rng.integers(min_atoms, max_atoms + 1))
+            edges, bids = [], []
+            for v in range(1, n):
+                u = int(rng.integers(0, v))
+                t = int(rng.integers(0, bond_vocab))
+                edges += [(u, v), (v, u)]
+                bids += [t, t]
+            rec[ion] = {
+                "atom_ids": [int(x) for x in rng.integers(0, atom_vocab, size=n)],
+                "bond_ids": bids,
+                "edge_indices": edges,
+                "num_atoms": n,
+            }
+        if kind == "viscosity":
+            rec["T"] = float(rng.uniform(253.0, 393.0))
+            rec["log_eta"] = float(rng.normal(4.0, 1.0))
+        else:
+            rec["mp"] = float(rng.uniform(200.0, 500.0))
+        recs.append(rec)
+    vocab = {"atom_vocab": {}, "bond_vocab": {}, "atom_vocab_size": atom_vocab, "bond_vocab_size": bond_vocab}
+    return recs, vocab

@@ -1,0 +1,189 @@
+"""GPU parity of the fused encoder (impnn_encoder_fused: the graphs/sec path) against the oracle
+on golden fixtures and random shapes, against the layer-at-a-time HIP path, and - at
+BASELINE.json's full batch 4096 - through size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, load_case
+from ionic_mpnn_amd import model as MM
+from ionic_mpnn_amd import ops, synthetic, weights
+from oracle import mpnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def to_dev(inputs):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in inputs.items()}
+
+
+def make_model(w, Va, Vb, D=32, K=8, fp=32, mix=20):
+    m = MM.build_model(Va, Vb, atom_dim=D, bond_dim=K, fp_size=fp, mixing_size=mix, num_steps=weights.num_steps_of(w),
+                       device=DEV)
+    m.load_weights(w)
+    return m
+
+
+@pytest.mark.parametrize("name", ["config2_b8", "config2_perturbed_b6"])
+def test_fused_encoder_vs_golden(name):
+    _, inp, w, outs = load_case(name)
+    m = make_model(w, *w["atom_embedding"].shape[:1], w["bond_embedding"].shape[0])
+    pc, pa = m.encode_pooled(to_dev(inp), fused=True)
+    assert_close(pc.cpu().numpy(), outs["cat/pooled"], what="cat pooled")
+    assert_close(pa.cpu().numpy(), outs["an/pooled"], what="an pooled")
+    y = m(inp, fused=True).cpu().numpy()
+    assert_close(y, outs["final"], what="log_eta")
+    # layered HIP path: same answer, and per-layer tensors match the oracle's
+    tr = {}
+    yl = m(inp, fused=False, trace=tr).cpu().numpy()
+    assert_close(yl, outs["final"], what="log_eta layered")
+    for k in ("cat/m0", "cat/agg1", "an/h2", "an/pooled", "cat/fp", "mixed"):
+        assert_close(tr[k].cpu().numpy(), outs[k], what=k)
+
+
+@pytest.mark.parametrize("N,E,K,S,B,seed", [(40, 80, 8, 3, 64, 1), (40, 80, 8, 4, 257, 2), (12, 20, 4, 2, 100, 3),
+                                            (7, 30, 1, 1, 50, 4), (64, 120, 8, 2, 40, 5), (40, 80, 5, 0, 30, 6),
+                                            (1, 0, 8, 2, 9, 7), (100, 240, 8, 1, 16, 8), (128, 512, 3, 1, 5, 9)])
+def test_fused_encoder_random_shapes(N, E, K, S, B, seed):
+    Va, Vb = 30, 11
+    inp = synthetic.make_batch(B, max_atoms=N, max_edges=E, atom_vocab_size=Va, bond_vocab_size=Vb,
+                               min_atoms=min(3, N), seed=seed)
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=32, bond_dim=K, num_steps=S, seed=seed + 100, perturb=True)
+    m = make_model(w, Va, Vb, K=K)
+    assert m.fused_supported(N, E)
+    pc, pa = m.encode_pooled(to_dev(inp), fused=True)
+    rc = O.encode(w, "cat", inp["cat_atom"], inp["cat_bond"], inp["cat_connectivity"], pooled_only=True)
+    ra = O.encode(w, "an", inp["an_atom"], inp["an_bond"], inp["an_connectivity"], pooled_only=True)
+    assert_close(pc.cpu().numpy(), rc, what="cat pooled")
+    assert_close(pa.cpu().numpy(), ra, what="an pooled")
+
+
+def test_fused_encoder_adversarial_graphs():
+    """Edges that name padding atoms, self loops, 4x duplicated bonds (trainer expansion), id-0 holes,
+    all-padding molecules, dense in-degree - the general contract, not just tree graphs."""
+    rng = np.random.default_rng(42)
+    B, N, E, Va, Vb, K, S = 48, 24, 64, 20, 7, 8, 3
+    ids = rng.integers(0, Va, size=(B, N)).astype(np.int32)          # zeros anywhere (holes)
+    ids[0] = 0                                                        # an all-padding molecule
+    conn = rng.integers(0, N, size=(B, E, 2)).astype(np.int32)        # any atom, incl. padding atoms and 0
+    conn[1] = 5                                                       # 64 self loops on atom 5
+    conn[2, :, 1] = 3                                                 # in-degree 64 on one atom
+    conn[:, 48:] = 0
+    bond = rng.integers(0, Vb, size=(B, E)).astype(np.int32)
+    # trainer-style 4x duplication for some molecules
+    e4, b4 = O.preprocess_edges_and_bonds([[(0, 1), (1, 0), (1, 2), (2, 1), (2, 3), (3, 2)]] * 4,
+                                          [[1, 1, 2, 2, 3, 3]] * 4, E // 2)
+    conn[3:7], bond[3:7] = e4, b4
+    inp = {"cat_atom": ids, "cat_bond": bond, "cat_connectivity": conn,
+           "an_atom": ids[::-1].copy(), "an_bond": bond[::-1].copy(), "an_connectivity": conn[::-1].copy()}
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=32, bond_dim=K, num_steps=S, seed=9, perturb=True)
+    m = make_model(w, Va, Vb, K=K)
+    pc, pa = m.encode_pooled(to_dev(inp), fused=True)
+    rc = O.encode(w, "cat", ids, bond, conn, pooled_only=True)
+    ra = O.encode(w, "an", inp["an_atom"], inp["an_bond"], inp["an_connectivity"], pooled_only=True)
+    assert_close(pc.cpu().numpy(), rc, what="cat pooled")
+    assert_close(pa.cpu().numpy(), ra, what="an pooled")
+    assert float(pc[0].abs().max()) == 0.0
+
+
+def test_unsupported_shapes_fall_back_to_layered_hip():
+    # melting-point model: K = D*D (train_melting_point.py:146) is outside the fused kernel
+    _, inp, w, outs = load_case("tiny_melting_point")
+    m = MM.build_melting_point_model(15, 7, atom_dim=8, fp_size=8, mixing_size=6, num_steps=2, device=DEV)
+    m.load_weights(w)
+    assert not m.fused_supported(10, 20)
+    with pytest.raises(ops.EncoderUnsupported):
+        m.encode_pooled(to_dev(inp), fused=True)
+    tr = {}
+    y = m(inp, trace=tr).cpu().numpy()                                # auto -> layered, typed schedule
+    assert_close(y, outs["final"], what="mp_out")
+    assert_close(tr["cat/pooled"].cpu().numpy(), outs["cat/pooled"], what="cat pooled")
+    # dense bond_state through the literal layer signature agrees too
+    pd = m.encode_layered("an", *[to_dev(inp)[k] for k in ("an_atom", "an_bond", "an_connectivity")], typed=False)
+    assert_close(pd.cpu().numpy(), outs["an/pooled"], what="an pooled dense")
+
+
+# ------------------------------------------------------------------ full size (B=4096): properties
+@pytest.fixture(scope="module")
+def full():
+    inp = synthetic.make_batch(4096, seed=0)
+    w = weights.init_weights("viscosity", synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, num_steps=3, seed=1)
+    m = make_model(w, synthetic.DEFAULT_VA, synthetic.DEFAULT_VB)
+    d = to_dev(inp)
+    pc, pa = m.encode_pooled(d, fused=True)
+    torch.cuda.synchronize()
+    return inp, w, m, d, pc.clone(), pa.clone()
+
+
+def test_full_batch_sampled_molecules_vs_oracle(full):
+    inp, w, m, d, pc, pa = full
+    idx = np.random.default_rng(7).choice(4096, size=96, replace=False)
+    sub = {k: v[idx] for k, v in inp.items()}
+    rc = O.encode(w, "cat", sub["cat_atom"], sub["cat_bond"], sub["cat_connectivity"], pooled_only=True)
+    ra = O.encode(w, "an", sub["an_atom"], sub["an_bond"], sub["an_connectivity"], pooled_only=True)
+    assert_close(pc.cpu().numpy()[idx], rc, what="cat pooled (sample)")
+    assert_close(pa.cpu().numpy()[idx], ra, what="an pooled (sample)")
+
+
+def test_full_batch_run_to_run_bitwise(full):
+    inp, w, m, d, pc, pa = full
+    pc2, pa2 = m.encode_pooled(d, fused=True)
+    assert torch.equal(pc, pc2) and torch.equal(pa, pa2)
+
+
+def test_full_batch_shard_concat_bitwise(full):
+    """Batch sharding (8e): any contiguous split gives identical rows - samples are independent and the
+    kernel's arithmetic per molecule does not depend on its neighbours in the batch."""
+    inp, w, m, d, pc, pa = full
+    for cuts in ([0, 1000, 4096], [0, 512, 1024, 1536, 2048, 2560, 3072, 3584, 4096]):
+        parts_c, parts_a = [], []
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            c, a = m.encode_pooled({k: v[lo:hi] for k, v in d.items()}, fused=True)
+            parts_c.append(c); parts_a.append(a)
+        assert torch.equal(torch.cat(parts_c), pc) and torch.equal(torch.cat(parts_a), pa)
+
+
+def test_full_batch_permutation_equivariance(full):
+    inp, w, m, d, pc, pa = full
+    perm = torch.from_numpy(np.random.default_rng(3).permutation(4096)).to(DEV)
+    c, a = m.encode_pooled({k: v[perm].contiguous() for k, v in d.items()}, fused=True)
+    assert torch.equal(c, pc[perm]) and torch.equal(a, pa[perm])
+
+
+def test_full_batch_padding_invariance(full):
+    inp, w, m, d, pc, pa = full
+    pad = {}
+    for k, v in d.items():
+        if k == "temperature":
+            pad[k] = v
+        elif k.endswith("connectivity"):
+            pad[k] = torch.cat([v, torch.zeros(v.shape[0], 16, 2, dtype=v.dtype, device=DEV)], 1).contiguous()
+        elif k.endswith("bond"):
+            pad[k] = torch.cat([v, torch.zeros(v.shape[0], 16, dtype=v.dtype, device=DEV)], 1).contiguous()
+        else:
+            pad[k] = torch.cat([v, torch.zeros(v.shape[0], 8, dtype=v.dtype, device=DEV)], 1).contiguous()
+    c, a = m.encode_pooled(pad, fused=True)
+    assert torch.equal(c, pc) and torch.equal(a, pa)
+
+
+def test_full_batch_fused_equals_layered_hip(full):
+    inp, w, m, d, pc, pa = full
+    lc, la = m.encode_pooled(d, fused=False)
+    assert_close(pc.cpu().numpy(), lc.cpu().numpy(), what="fused vs layered cat")
+    assert_close(pa.cpu().numpy(), la.cpu().numpy(), what="fused vs layered an")
+
+
+def test_config1_dataset_plumbing_batch32():
+    """BASELINE config 1: records in the *_id_data.pkl schema -> restated loader -> batch 32 -> HIP forward
+    vs the oracle."""
+    from ionic_mpnn_amd import data
+    recs, vocab = synthetic.make_id_records(64, seed=11, max_atoms=14)
+    ds = data.IonPairDataset(recs, vocab)
+    x = ds.build_inputs(range(32))
+    w = weights.init_weights("viscosity", ds.atom_vocab_size, ds.bond_vocab_size, num_steps=4, seed=2)
+    m = make_model(w, ds.atom_vocab_size, ds.bond_vocab_size)
+    ref = O.viscosity_forward(w, x)
+    assert_close(m(x, fused=True).cpu().numpy(), ref, what="log_eta fused")
+    assert_close(m(x, fused=False).cpu().numpy(), ref, what="log_eta layered")
+    assert_close(m.predict(x, batch_size=32), ref, what="predict")
