@@ -131,6 +131,12 @@ int impnn_profile_enable(int32_t capacity);
 int impnn_profile_collect(float* ms_out, int32_t max_n, int32_t* n_out);
 int impnn_profile_disable(void);
 
+/* ---- diagnostics: when a device buffer of >= 64 bytes per encoder workgroup is set, the encoder
+ *      kernel's lane 0 writes s_memtime stamps into it (entry, after prologue, after each of the
+ *      first 5 steps, exit) - 8 uint64 per workgroup.  NULL (the default) disables it; with NULL
+ *      no stamp instruction executes.  Never set during a timed run. */
+int impnn_debug_set_stamp_buffer(void* device_buffer, size_t bytes);
+
 /* ---- debug: counts indices the reference's CPU path would raise on.  counts[0] += #conn
  *      entries outside [0,N), counts[1] += #atom ids outside [0,Va), counts[2] += #bond ids
  *      outside [0,Vb).  Any of conn/atom_ids/bond_ids may be NULL.  counts: 3 device int32,

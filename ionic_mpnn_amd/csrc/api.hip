@@ -29,6 +29,15 @@ struct Profiler {
 thread_local Profiler g_prof;
 }  // namespace
 
+namespace {
+thread_local void* g_stamp_ptr = nullptr;
+thread_local size_t g_stamp_bytes = 0;
+}  // namespace
+void* debug_stamp_buffer(size_t* bytes) {
+  *bytes = g_stamp_bytes;
+  return g_stamp_ptr;
+}
+
 void profile_record_start(hipStream_t s) {
   Profiler& p = g_prof;
   if (!p.enabled || p.used >= (int)p.start.size()) return;
@@ -221,6 +230,12 @@ int impnn_profile_disable(void) {
   g_prof.used = 0;
   g_prof.enabled = false;
   g_prof.open = false;
+  return IMPNN_OK;
+}
+
+int impnn_debug_set_stamp_buffer(void* device_buffer, size_t bytes) {
+  g_stamp_ptr = device_buffer;
+  g_stamp_bytes = device_buffer ? bytes : 0;
   return IMPNN_OK;
 }
 

@@ -48,6 +48,11 @@ __host__ __device__ constexpr int img_vec_floats() { return 5 * kD; }
 __host__ __device__ constexpr int img_floats(int K) {
   return img_msg_floats(K) + img_upd_floats() + img_vec_floats();
 }
+// Every image is stored (HBM workspace and LDS) in a slot of kImgSlot floats so that the
+// register prefetch is kPf unconditional 16-byte loads per thread (no per-load branch / wait).
+constexpr int kPf = 8;
+constexpr int kImgSlot = kPf * kThreads * 4;  // 16384 floats = 64 KiB >= img_floats(8) = 15904
+static_assert(img_floats(kKMax) <= kImgSlot, "weight image does not fit its slot");
 
 // workspace layout (bytes, all 256-aligned sections)
 struct Ws {
@@ -70,7 +75,7 @@ __host__ inline Ws ws_layout(int n_ions, int B, int N, int E, int K, int S) {
   w.ub = (int)(((int64_t)B * vrmax) / win) + 1;
   size_t off = 0;
   w.img_off = off;
-  off = align_up(off + (size_t)n_ions * (S > 0 ? S : 1) * img_floats(K) * sizeof(float), 256);
+  off = align_up(off + (size_t)n_ions * (S > 0 ? S : 1) * kImgSlot * sizeof(float), 256);
   w.rows_off = off;
   off = align_up(off + (size_t)n_ions * B * sizeof(int32_t), 256);
   w.vr_off = off;
@@ -90,7 +95,7 @@ struct PlanParams {
   const int32_t* bond_ids[2];
   const int32_t* conn[2];
   const float* weights[2];
-  float* img;      // [n_ions][S][img_floats(K)]
+  float* img;      // [n_ions][S][kImgSlot]
   int32_t* rows;   // [n_ions][B]
   int32_t* vr;     // [n_ions][B]
   int32_t* start;  // [n_ions][B+1]
@@ -170,7 +175,7 @@ __global__ void plan_stats_kernel(PlanParams p) {
     const float* bh = Wh + 2 * kD * kD;
     const float* gamma = bh + kD;
     const float* beta = gamma + kD;
-    float* img = p.img + (int64_t)gs * img_floats(K);
+    float* img = p.img + (int64_t)gs * kImgSlot;
     const int nmsg = img_msg_floats(K), nupd = img_upd_floats();
     for (int t = threadIdx.x; t < nmsg; t += blockDim.x) {
       const int row = t / kMsgRS, j = t - row * kMsgRS;  // row = k*32 + i_out
@@ -187,6 +192,7 @@ __global__ void plan_stats_kernel(PlanParams p) {
       const float* src = v == 0 ? bz : v == 1 ? br : v == 2 ? bh : v == 3 ? gamma : beta;
       img[nmsg + nupd + t] = src[i];
     }
+    for (int t = img_floats(K) + threadIdx.x; t < kImgSlot; t += blockDim.x) img[t] = 0.f;
   }
 }
 
@@ -268,6 +274,7 @@ struct EncParams {
   const int32_t* nchunks;
   int n_ions, B, N, E, K, S, Va, Vb, ub;
   float ln_eps;
+  unsigned long long* stamps;  // diagnostics only (impnn_debug_set_stamp_buffer): 8 words per workgroup
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -297,7 +304,8 @@ struct Lds {
 };
 
 __host__ __device__ inline size_t lds_bytes(int K) {
-  return sizeof(float) * ((size_t)img_floats(K) + 2 * kRCap * kHS + kTbCapFloats) +
+  (void)K;
+  return sizeof(float) * ((size_t)kImgSlot + 2 * kRCap * kHS + kTbCapFloats) +
          sizeof(uint32_t) * kECap + sizeof(int32_t) * ((kRCap + 4) + kRCap + (kRCap + 4) + kRCap + 32);
 }
 
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
   Lds L;
   {
     float* f = smem;
-    L.wimg = f; f += img_floats(K);
+    L.wimg = f; f += kImgSlot;
     L.hbuf0 = f; f += kRCap * kHS;
     L.hbuf1 = f; f += kRCap * kHS;
     L.tb = f; f += kTbCapFloats;
@@ -319,6 +327,8 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
     L.scratch = reinterpret_cast<int32_t*>(f);
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long* stamp = p.stamps ? p.stamps + (size_t)blockIdx.x * 8 : nullptr;
+  if (stamp && tid == 0) stamp[0] = __builtin_amdgcn_s_memtime();
   const int g = p.n_ions == 2 ? (blockIdx.x & 1) : 0;
   const int c = p.n_ions == 2 ? (blockIdx.x >> 1) : blockIdx.x;
   if (c >= p.nchunks[g]) return;
@@ -335,8 +345,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
   const int32_t* ids_g = p.atom_ids[g];
   const int32_t* conn_g = p.conn[g];
   const int32_t* bond_g = p.bond_ids[g];
-  const int img_f = img_floats(K);
-  const float* img_g = p.img + (int64_t)g * (p.S > 0 ? p.S : 1) * img_f;
+  const float* img_g = p.img + (int64_t)g * (p.S > 0 ? p.S : 1) * kImgSlot;
 
   // ---- prologue ------------------------------------------------------------------------
   for (int m = tid; m <= M; m += kThreads) {
@@ -353,8 +362,10 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
       L.tb[v * kKMax + k] = 0.f;
     }
   // weights of step 0
-  if (p.S > 0)
-    for (int t = tid; t < img_f / 4; t += kThreads) st4(L.wimg + 4 * t, ld4(img_g + 4 * t));
+  if (p.S > 0) {
+#pragma unroll
+    for (int i = 0; i < kPf; ++i) st4(L.wimg + 4 * (tid + i * kThreads), ld4(img_g + 4 * (tid + i * kThreads)));
+  }
   __syncthreads();
 
   // row -> (molecule, n); in-degree count
@@ -432,6 +443,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
   }
   __syncthreads();
 
+  if (stamp && tid == 0) stamp[1] = __builtin_amdgcn_s_memtime();
   // ---- message-passing steps -----------------------------------------------------------
   const int a = lane & 15, q = lane >> 4;
   const float* wmsg = L.wimg;
@@ -441,16 +453,13 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
     const float* hcur = (s & 1) ? L.hbuf1 : L.hbuf0;
     float* hnext = (s & 1) ? L.hbuf0 : L.hbuf1;
     // prefetch next step's weight image into registers (written to LDS after the barrier)
-    constexpr int kPf = 8;
+    // (the last step re-reads its own image: unconditional loads, no branch, no extra wait)
     f32x4 pf[kPf];
-    const bool has_next = (s + 1) < p.S;
-    if (has_next) {
-      const float* nxt = img_g + (int64_t)(s + 1) * img_f;
+    {
+      const int sn = (s + 1) < p.S ? (s + 1) : s;
+      const float* nxt = img_g + (int64_t)sn * kImgSlot;
 #pragma unroll
-      for (int i = 0; i < kPf; ++i) {
-        const int t = tid + i * kThreads;
-        if (t < img_f / 4) pf[i] = ld4(nxt + 4 * t);
-      }
+      for (int i = 0; i < kPf; ++i) pf[i] = ld4(nxt + 4 * (tid + i * kThreads));
     }
 
     for (int tile = wave; tile < ntiles; tile += kWaves) {
@@ -587,14 +596,10 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
       st4(hnext + row * kHS + 16 + 4 * q, o1);
     }
     __syncthreads();
-    if (has_next) {
 #pragma unroll
-      for (int i = 0; i < kPf; ++i) {
-        const int t = tid + i * kThreads;
-        if (t < img_f / 4) st4(L.wimg + 4 * t, pf[i]);
-      }
-      __syncthreads();
-    }
+    for (int i = 0; i < kPf; ++i) st4(L.wimg + 4 * (tid + i * kThreads), pf[i]);
+    __syncthreads();
+    if (p.stamps && tid == 0 && s < 5) stamp[2 + s] = __builtin_amdgcn_s_memtime();
   }
 
   // ---- GlobalSumPool (models/layers.py:161-164): rows with atom_ids > 0, ascending n
@@ -608,6 +613,10 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
     for (int n = 0; n < nr; ++n)
       if (ids[n] > 0) acc += hfin[(mo + n) * kHS + f];
     out_g[(int64_t)(m0 + m) * kD + f] = acc;
+  }
+  if (stamp && tid == 0) {
+    stamp[7] = __builtin_amdgcn_s_memtime();
+    stamp[6] = ((unsigned long long)R << 32) | (unsigned)M;
   }
 }
 
@@ -666,6 +675,13 @@ int launch_encoder_fused(const EncoderArgs& a, hipStream_t s) {
   ep.img = pp.img; ep.rows = pp.rows; ep.start = pp.start; ep.first = pp.first; ep.nchunks = pp.nchunks;
   ep.n_ions = a.n_ions; ep.B = a.B; ep.N = a.N; ep.E = a.E; ep.K = a.K; ep.S = a.S;
   ep.Va = a.Va; ep.Vb = a.Vb; ep.ub = w.ub; ep.ln_eps = a.ln_eps;
+  ep.stamps = nullptr;
+  {
+    size_t sb = 0;
+    void* sp = debug_stamp_buffer(&sb);
+    if (sp && sb >= (size_t)w.ub * a.n_ions * 8 * sizeof(unsigned long long))
+      ep.stamps = static_cast<unsigned long long*>(sp);
+  }
   const size_t lds = lds_bytes(a.K);
   static bool attr_set = false;
   if (!attr_set) {
