@@ -297,7 +297,8 @@ struct Lds {
   float* tb;        // kTbCapFloats (row stride 8)
   uint32_t* ent;    // kECap
   int32_t* rowptr;  // kRCap+1 (+pad)
-  int32_t* rowinfo; // kRCap : (mol_local<<16 | n) or -1 for slack rows
+  int32_t* cursor;  // kRCap
+  int32_t* rowinfo; // kRCap : (mol_local<<16 | [atom id > 0]<<15 | n) or -1 for slack rows
   int32_t* moloff;  // kRCap+1
   int32_t* molrows; // kRCap
   int32_t* scratch; // 32
@@ -306,7 +307,7 @@ struct Lds {
 __host__ __device__ inline size_t lds_bytes(int K) {
   (void)K;
   return sizeof(float) * ((size_t)kImgSlot + 2 * kRCap * kHS + kTbCapFloats) +
-         sizeof(uint32_t) * kECap + sizeof(int32_t) * ((kRCap + 4) + kRCap + (kRCap + 4) + kRCap + 32);
+         sizeof(uint32_t) * kECap + sizeof(int32_t) * ((kRCap + 4) + kRCap + kRCap + (kRCap + 4) + kRCap + 32);
 }
 
 __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p) {
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
     L.tb = f; f += kTbCapFloats;
     L.ent = reinterpret_cast<uint32_t*>(f); f += kECap;
     L.rowptr = reinterpret_cast<int32_t*>(f); f += kRCap + 4;
+    L.cursor = reinterpret_cast<int32_t*>(f); f += kRCap;
     L.rowinfo = reinterpret_cast<int32_t*>(f); f += kRCap;
     L.moloff = reinterpret_cast<int32_t*>(f); f += kRCap + 4;
     L.molrows = reinterpret_cast<int32_t*>(f); f += kRCap;
@@ -348,29 +350,32 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
   const float* img_g = p.img + (int64_t)g * (p.S > 0 ? p.S : 1) * kImgSlot;
 
   // ---- prologue ------------------------------------------------------------------------
+  // P0: chunk tables; step-0 weight image starts its flight into registers
+  f32x4 pf0[kPf];
+  if (p.S > 0) {
+#pragma unroll
+    for (int i = 0; i < kPf; ++i) pf0[i] = ld4(img_g + 4 * (tid + i * kThreads));
+  }
   for (int m = tid; m <= M; m += kThreads) {
     L.moloff[m] = start[m0 + m] - base;
     if (m < M) L.molrows[m] = rows_g[m0 + m];
   }
-  for (int t = tid; t < p.Vb * K; t += kThreads) {
-    const int v = t / K, k = t - v * K;
-    L.tb[v * kKMax + k] = p.bond_table[t];
+  for (int t = tid; t < p.Vb * kKMax; t += kThreads) {
+    const int v = t >> 3, k = t & 7;
+    L.tb[t] = k < K ? p.bond_table[v * K + k] : 0.f;
   }
-  if (K < kKMax)
-    for (int t = tid; t < p.Vb * (kKMax - K); t += kThreads) {
-      const int v = t / (kKMax - K), k = K + (t - v * (kKMax - K));
-      L.tb[v * kKMax + k] = 0.f;
-    }
-  // weights of step 0
-  if (p.S > 0) {
-#pragma unroll
-    for (int i = 0; i < kPf; ++i) st4(L.wimg + 4 * (tid + i * kThreads), ld4(img_g + 4 * (tid + i * kThreads)));
-  }
+  for (int r = tid; r < kRCap + 4; r += kThreads) L.rowptr[r] = 0;  // used as in-degree counters first
   __syncthreads();
 
-  // row -> (molecule, n); in-degree count
-  int my_cnt = 0, my_m = 0, my_n = 0;
-  bool my_real = false;
+  // P1: in-degree of every row (edge-parallel, coalesced reads of conn / bond ids);
+  //     row -> (molecule, n, id>0) map
+  const int n_slots = M * E;
+  for (int slot = tid; slot < n_slots; slot += kThreads) {
+    const int m = slot / E, e = slot - m * E;
+    const int64_t b = m0 + m;
+    const int2 st = *reinterpret_cast<const int2*>(conn_g + (b * E + e) * 2);
+    if (edge_valid(st.x, st.y, bond_g[b * E + e], N, p.Vb)) atomicAdd(&L.rowptr[L.moloff[m] + st.y], 1);
+  }
   if (tid < kRCap) {
     const int row = tid;
     int info = -1;
@@ -380,24 +385,19 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
         const int mid = (lo + hi + 1) >> 1;
         if (L.moloff[mid] <= row) lo = mid; else hi = mid - 1;
       }
-      my_m = lo;
-      my_n = row - L.moloff[lo];
-      my_real = my_n < L.molrows[lo];
-      if (my_real) info = (my_m << 16) | my_n;
-    }
-    L.rowinfo[row] = info;
-    if (my_real) {
-      const int64_t b = m0 + my_m;
-      const int32_t* cn = conn_g + b * E * 2;
-      const int32_t* bd = bond_g + b * E;
-      for (int e = 0; e < E; ++e) {
-        const int2 st = *reinterpret_cast<const int2*>(cn + 2 * e);
-        if (st.y == my_n && edge_valid(st.x, st.y, bd[e], N, p.Vb)) ++my_cnt;
+      const int n = row - L.moloff[lo];
+      if (n < L.molrows[lo]) {
+        const int id = ids_g[(int64_t)(m0 + lo) * N + n];
+        info = (lo << 16) | (id > 0 ? 0x8000 : 0) | n;
       }
     }
+    L.rowinfo[row] = info;
   }
-  // exclusive scan of my_cnt over rows 0..255 (waves 0..3)
+  __syncthreads();
+
+  // P2: exclusive scan of the in-degrees -> rowptr; cursor = copy used by the fill
   {
+    const int my_cnt = tid < kRCap ? L.rowptr[tid] : 0;
     int incl = my_cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -411,35 +411,56 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
       for (int w = 0; w < wave; ++w) off += L.scratch[w];
       const int excl = off + incl - my_cnt;
       L.rowptr[tid] = excl;
+      L.cursor[tid] = excl;
       if (tid == kRCap - 1) L.rowptr[kRCap] = excl + my_cnt;
-      // fill the in-edge list in edge-slot order
-      if (my_real && my_cnt > 0) {
-        const int64_t b = m0 + my_m;
-        const int32_t* cn = conn_g + b * E * 2;
-        const int32_t* bd = bond_g + b * E;
-        const int mo = L.moloff[my_m];
-        int ptr = excl;
-        for (int e = 0; e < E; ++e) {
-          const int2 st = *reinterpret_cast<const int2*>(cn + 2 * e);
-          const int bid = bd[e];
-          if (st.y == my_n && edge_valid(st.x, st.y, bid, N, p.Vb))
-            L.ent[ptr++] = (uint32_t)(mo + st.x) | ((uint32_t)bid << 16);
-        }
-      }
     }
   }
-  // h0 = atom_table[atom_ids]  (train_viscosity.py:171); slack rows = 0; both buffers' tail zeroed
+  __syncthreads();
+
+  // P3: fill.  entry = edge slot (16b) | bond id (8b) | source row (8b); the slot in the top bits
+  //     lets P4 restore edge-slot order, so the accumulation order is fixed run to run.
+  for (int slot = tid; slot < n_slots; slot += kThreads) {
+    const int m = slot / E, e = slot - m * E;
+    const int64_t b = m0 + m;
+    const int2 st = *reinterpret_cast<const int2*>(conn_g + (b * E + e) * 2);
+    const int bid = bond_g[b * E + e];
+    if (edge_valid(st.x, st.y, bid, N, p.Vb)) {
+      const int mo = L.moloff[m];
+      const int pos = atomicAdd(&L.cursor[mo + st.y], 1);
+      L.ent[pos] = ((uint32_t)e << 16) | ((uint32_t)bid << 8) | (uint32_t)(mo + st.x);
+    }
+  }
+  // h0 = atom_table[atom_ids]  (train_viscosity.py:171); slack rows = 0 in both buffers
   for (int t = tid; t < kRCap * 8; t += kThreads) {
     const int row = t >> 3, part = t & 7;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const int info = L.rowinfo[row];
     if (info >= 0) {
-      const int m = info >> 16, n = info & 0xffff;
+      const int m = info >> 16, n = info & 0x7fff;
       const int id = ids_g[(int64_t)(m0 + m) * N + n];
       if ((unsigned)id < (unsigned)p.Va) v = ld4(p.atom_table + (int64_t)id * kD + 4 * part);
     }
     st4(L.hbuf0 + row * kHS + 4 * part, v);
     st4(L.hbuf1 + row * kHS + 4 * part, v);
+  }
+  if (p.S > 0) {
+#pragma unroll
+    for (int i = 0; i < kPf; ++i) st4(L.wimg + 4 * (tid + i * kThreads), pf0[i]);
+  }
+  __syncthreads();
+
+  // P4: sort every row's in-edge list by edge slot (lists are short: insertion sort)
+  if (tid < kRCap) {
+    const int lo = L.rowptr[tid], hi = L.rowptr[tid + 1];
+    for (int i = lo + 1; i < hi; ++i) {
+      const uint32_t v = L.ent[i];
+      int j = i - 1;
+      while (j >= lo && L.ent[j] > v) {
+        L.ent[j + 1] = L.ent[j];
+        --j;
+      }
+      L.ent[j + 1] = v;
+    }
   }
   __syncthreads();
 
@@ -479,7 +500,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
       for (int d = 0; d < maxdeg; ++d) {
         if (d < deg) {
           const uint32_t ent = L.ent[p0 + d];
-          const int src = ent & 0xffffu, bid = ent >> 16;
+          const int src = ent & 0xffu, bid = (ent >> 8) & 0xffu;
           const f32x4 x0 = ld4(hcur + src * kHS + 4 * q);
           const f32x4 x1 = ld4(hcur + src * kHS + 16 + 4 * q);
           const f32x4 c0 = ld4(L.tb + bid * kKMax);
@@ -602,17 +623,23 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
     if (p.stamps && tid == 0 && s < 5) stamp[2 + s] = __builtin_amdgcn_s_memtime();
   }
 
-  // ---- GlobalSumPool (models/layers.py:161-164): rows with atom_ids > 0, ascending n
+  // ---- GlobalSumPool (models/layers.py:161-164): rows whose atom id > 0.  Four lanes share one
+  //      (molecule, feature): each sums every 4th row in ascending order, then a fixed 2-step
+  //      butterfly - a wavefront segmented reduction with a run-to-run fixed order.
   const float* hfin = (p.S & 1) ? L.hbuf1 : L.hbuf0;
   float* out_g = p.pooled[g];
-  for (int t = tid; t < M * kD; t += kThreads) {
-    const int m = t >> 5, f = t & 31;
-    const int nr = L.molrows[m], mo = L.moloff[m];
-    const int32_t* ids = ids_g + (int64_t)(m0 + m) * N;
+  for (int t0 = 0; t0 < M * kD * 4; t0 += kThreads) {
+    const int t = t0 + tid;
+    const int part = t & 3, f = (t >> 2) & 31, m = t >> 7;
     float acc = 0.f;
-    for (int n = 0; n < nr; ++n)
-      if (ids[n] > 0) acc += hfin[(mo + n) * kHS + f];
-    out_g[(int64_t)(m0 + m) * kD + f] = acc;
+    if (m < M) {
+      const int nr = L.molrows[m], mo = L.moloff[m];
+      for (int n = part; n < nr; n += 4)
+        if (L.rowinfo[mo + n] & 0x8000) acc += hfin[(mo + n) * kHS + f];
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (m < M && part == 0) out_g[(int64_t)(m0 + m) * kD + f] = acc;
   }
   if (stamp && tid == 0) {
     stamp[7] = __builtin_amdgcn_s_memtime();
