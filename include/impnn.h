@@ -111,6 +111,13 @@ int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, i
  *  impnn_encoder_step_floats(D,K) returns that per-step count.
  *
  *  The arrays of pointers are HOST arrays of device pointers (length n_ions, n_ions <= 2). */
+/*  Arithmetic mode of the encoder's GEMMs (thread-local, default 1); returns the previous mode.
+ *    0 "f32":   v_mfma_f32_16x16x4_f32, exact f32 products;
+ *    1 "f16x2": each f32 operand split into two fp16 numbers, 3 fp16 MFMA products per f32
+ *               product, f32 accumulation (error ~ f32's own; see encoder_fused.hip).  Valid while
+ *               |h|, |agg|, |G| < 4094 and |weights| < 255 - the caller's static bound
+ *               (ionic_mpnn_amd.model checks it when weights are packed and uses mode 0 otherwise). */
+int impnn_encoder_set_mode(int32_t mode);
 int64_t impnn_encoder_step_floats(int32_t D, int32_t K);
 int impnn_encoder_workspace_bytes(int32_t n_ions, int32_t B, int32_t N, int32_t E, int32_t D,
                                   int32_t K, int32_t S, int32_t Vb, size_t* bytes);
@@ -131,9 +138,10 @@ int impnn_profile_enable(int32_t capacity);
 int impnn_profile_collect(float* ms_out, int32_t max_n, int32_t* n_out);
 int impnn_profile_disable(void);
 
-/* ---- diagnostics: when a device buffer of >= 64 bytes per encoder workgroup is set, the encoder
+/* ---- diagnostics: when a device buffer of >= 128 bytes per encoder workgroup is set, the encoder
  *      kernel's lane 0 writes s_memtime stamps into it (entry, after prologue, after each of the
- *      first 5 steps, exit) - 8 uint64 per workgroup.  NULL (the default) disables it; with NULL
+ *      first 5 steps, exit, and the phase boundaries of wave 0's first tile in one step) -
+ *      16 uint64 per workgroup.  NULL (the default) disables it; with NULL
  *      no stamp instruction executes.  Never set during a timed run. */
 int impnn_debug_set_stamp_buffer(void* device_buffer, size_t bytes);
 

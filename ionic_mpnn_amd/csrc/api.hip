@@ -33,6 +33,11 @@ namespace {
 thread_local void* g_stamp_ptr = nullptr;
 thread_local size_t g_stamp_bytes = 0;
 }  // namespace
+namespace {
+thread_local int g_encoder_mode = 1;
+}
+int encoder_mode() { return g_encoder_mode; }
+
 void* debug_stamp_buffer(size_t* bytes) {
   *bytes = g_stamp_bytes;
   return g_stamp_ptr;
@@ -231,6 +236,13 @@ int impnn_profile_disable(void) {
   g_prof.enabled = false;
   g_prof.open = false;
   return IMPNN_OK;
+}
+
+int impnn_encoder_set_mode(int32_t mode) {
+  if (mode != 0 && mode != 1) return fail(IMPNN_E_BADARG, "impnn_encoder_set_mode: mode must be 0 (f32) or 1 (f16x2)");
+  const int prev = g_encoder_mode;
+  g_encoder_mode = mode;
+  return prev;
 }
 
 int impnn_debug_set_stamp_buffer(void* device_buffer, size_t bytes) {

@@ -52,6 +52,7 @@ int launch_validate_indices(const int32_t* conn, const int32_t* atom_ids, const 
 void profile_record_start(hipStream_t s);
 void profile_record_stop(hipStream_t s);
 
+int encoder_mode();  // thread-local arithmetic mode of the fused encoder (api.hip): 0 f32, 1 f16x2 split
 void* debug_stamp_buffer(size_t* bytes);  // thread-local diagnostics buffer (api.hip), usually null
 
 // ---- fused encoder (encoder_fused.hip)

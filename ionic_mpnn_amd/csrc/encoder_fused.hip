@@ -1,10 +1,23 @@
 // Fused message-passing encoder for gfx950 (MI355X): encode() of train_viscosity.py:166-187 up to
 // and including GlobalSumPool, for both ions in one launch, D = 32, K <= 8.
 //
-// Shape of the computation (all fp32, exact-f32 MFMA v_mfma_f32_16x16x4_f32):
+// Shape of the computation:
 //   * molecules are cut into CHUNKS of <= 256 packed atom rows (padding atoms are not carried;
-//     see "rows" below); one 512-thread workgroup owns a chunk for all S steps, its node state
-//     h lives in LDS (double-buffered), weights of the current (ion, step) live in LDS;
+//     see "rows" below); one 1024-thread workgroup (16 waves, one 16-atom tile each) owns a chunk
+//     for all S steps, its node state h lives in LDS (double-buffered), the weights of the current
+//     (ion, step) live in LDS;
+//   * two arithmetic modes for the GEMMs, same data flow:
+//       mode 0 "f32":      v_mfma_f32_16x16x4_f32, exact f32 products.  On gfx950 this instruction
+//                          runs at the VALU rate and does not overlap VALU work of the same SIMD
+//                          (tools/ubench/mfma_valu_overlap.hip: 4.49 ms + 0.92 ms -> 5.32 ms);
+//       mode 1 "f16x2":    every f32 operand x is split x*2^s = hi + lo into two fp16 numbers
+//                          (hi = x*2^s rounded toward zero to 11 bits, lo = the next 11 bits), and
+//                          a*b ~= ah*bh + ah*bl + al*bh on v_mfma_f32_16x16x32_f16 with f32
+//                          accumulation: 3 matrix-pipe instructions replace 8, product error
+//                          ~2^-21, measured end-to-end error vs fp64 2-3e-7 (plain f32: 2e-7).
+//                          Weights are split once per call into the LDS image, activations on the
+//                          fly (2 VALU ops / value).  Requires |h|,|agg|,|G| < 4094 and
+//                          |W| < 255 (fp16 range after scaling); the caller checks a static bound.
 //   * atoms sit on the MFMA N dimension (lane & 15), features on M: every GEMM is computed
 //     transposed, out^T = W^T * in^T, so an accumulator tile (feature = 4*(lane>>4)+reg) is
 //     directly the B operand of the next GEMM - no LDS round trip between message, gates,
@@ -30,6 +43,12 @@ namespace impnn {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// mode 1 scaling (powers of two, exact): weights are stored as W*kSW, B operands as x*kSX
+constexpr float kSW = 256.0f;
+constexpr float kSX = 16.0f;
+constexpr float kAcc = kSW * kSX;  // scale of every accumulator in mode 1
 
 constexpr int kD = 32;
 constexpr int kKMax = 8;
@@ -38,7 +57,7 @@ constexpr int kECap = 1024;  // valid edges per chunk (= 4 * kRCap, enforced thr
 constexpr int kHS = 36;      // LDS row stride of h (floats): 16B aligned, conflict-free b128 tile writes
 constexpr int kMsgRS = 36;   // row stride of the message-weight image
 constexpr int kUpdRS = 68;   // row stride of the update-weight image (2D + 4)
-constexpr int kThreads = 512;
+constexpr int kThreads = 1024;
 constexpr int kWaves = kThreads / 64;
 constexpr int kTbCapFloats = 2048;  // bond table copy in LDS (Vb*K floats)
 
@@ -48,11 +67,19 @@ __host__ __device__ constexpr int img_vec_floats() { return 5 * kD; }
 __host__ __device__ constexpr int img_floats(int K) {
   return img_msg_floats(K) + img_upd_floats() + img_vec_floats();
 }
+// mode 1 image (halfs): per (k, T) / (gate, T, half) two 512-half blocks (hi, lo); a lane's 8 halfs of
+// a block are contiguous, so the A operand of one MFMA is one conflict-free ds_read_b128.
+__host__ __device__ constexpr int img16_msg_halfs(int K) { return K * 2 * 2 * 512; }
+__host__ __device__ constexpr int img16_upd_halfs() { return 3 * 2 * 2 * 2 * 512; }
+__host__ __device__ constexpr int img16_vec_float_off(int K) { return (img16_msg_halfs(K) + img16_upd_halfs()) / 2; }
+// feature held by element j (0..7) of lane quarter q: the accumulator layout of a 16x16 MFMA tile pair
+__host__ __device__ constexpr int feat_of(int q, int j) { return 16 * (j >> 2) + 4 * q + (j & 3); }
 // Every image is stored (HBM workspace and LDS) in a slot of kImgSlot floats so that the
 // register prefetch is kPf unconditional 16-byte loads per thread (no per-load branch / wait).
-constexpr int kPf = 8;
+constexpr int kPf = 4;
 constexpr int kImgSlot = kPf * kThreads * 4;  // 16384 floats = 64 KiB >= img_floats(8) = 15904
 static_assert(img_floats(kKMax) <= kImgSlot, "weight image does not fit its slot");
+static_assert(img16_vec_float_off(kKMax) + img_vec_floats() <= kImgSlot, "split weight image does not fit");
 
 // workspace layout (bytes, all 256-aligned sections)
 struct Ws {
@@ -103,6 +130,7 @@ struct PlanParams {
   int32_t* nchunks;  // [2]
   int n_ions, B, N, E, K, S, Vb, win, ub;
   int mol_blocks;  // blocks of plan_stats that handle molecules
+  int mode;        // 0: f32 image, 1: fp16 hi/lo image
   int64_t step_floats;
 };
 
@@ -176,6 +204,38 @@ __global__ void plan_stats_kernel(PlanParams p) {
     const float* gamma = bh + kD;
     const float* beta = gamma + kD;
     float* img = p.img + (int64_t)gs * kImgSlot;
+    if (p.mode == 1) {
+      _Float16* hi_lo = reinterpret_cast<_Float16*>(img);
+      const int nm = img16_msg_halfs(K), nu = img16_upd_halfs();
+      for (int t = threadIdx.x; t < nm + nu; t += blockDim.x) {
+        // t = ((blk * 2 + part) * 64 + lane) * 8 + j
+        const int j = t & 7, ln = (t >> 3) & 63, part = (t >> 9) & 1;
+        const int q = ln >> 4, i = ln & 15, f = feat_of(q, j);
+        float wv;
+        if (t < nm) {
+          const int blk = t >> 10;  // k*2 + T
+          const int k = blk >> 1, T = blk & 1;
+          wv = W[((int64_t)k * kD + 16 * T + i) * kD + f];
+        } else {
+          const int blk = (t - nm) >> 10;  // (gate*2 + T)*2 + half
+          const int half = blk & 1, T = (blk >> 1) & 1, gate = blk >> 2;
+          const float* Wg = gate == 0 ? Wz : (gate == 1 ? Wr : Wh);
+          wv = Wg[(int64_t)(half * kD + f) * kD + 16 * T + i];
+        }
+        wv *= kSW;
+        const _Float16 hi = __builtin_amdgcn_cvt_pkrtz(wv, 0.f)[0];
+        const _Float16 lo = __builtin_amdgcn_cvt_pkrtz(wv - (float)hi, 0.f)[0];
+        hi_lo[t] = part == 0 ? hi : lo;
+      }
+      float* vec = img + img16_vec_float_off(K);
+      for (int t = threadIdx.x; t < img_vec_floats(); t += blockDim.x) {
+        const int v = t / kD, i = t - v * kD;
+        const float* src = v == 0 ? bz : v == 1 ? br : v == 2 ? bh : v == 3 ? gamma : beta;
+        vec[t] = v < 3 ? src[i] * kAcc : src[i];  // biases seed the (scaled) accumulators
+      }
+      for (int t = img16_vec_float_off(K) + img_vec_floats() + threadIdx.x; t < kImgSlot; t += blockDim.x) img[t] = 0.f;
+      return;
+    }
     const int nmsg = img_msg_floats(K), nupd = img_upd_floats();
     for (int t = threadIdx.x; t < nmsg; t += blockDim.x) {
       const int row = t / kMsgRS, j = t - row * kMsgRS;  // row = k*32 + i_out
@@ -274,7 +334,7 @@ struct EncParams {
   const int32_t* nchunks;
   int n_ions, B, N, E, K, S, Va, Vb, ub;
   float ln_eps;
-  unsigned long long* stamps;  // diagnostics only (impnn_debug_set_stamp_buffer): 8 words per workgroup
+  unsigned long long* stamps;  // diagnostics only (impnn_debug_set_stamp_buffer): 16 words per workgroup
 };
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
@@ -289,30 +349,73 @@ __device__ __forceinline__ float fast_tanh(float x) {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+constexpr int kDegBins = 18;  // in-degree 0..15, ">= 16", and "row beyond the chunk" (placed last)
+
 // LDS carve (floats unless noted)
 struct Lds {
-  float* wimg;      // img_floats(K)
-  float* hbuf0;     // kRCap*kHS
-  float* hbuf1;     // kRCap*kHS
-  float* tb;        // kTbCapFloats (row stride 8)
-  uint32_t* ent;    // kECap
-  int32_t* rowptr;  // kRCap+1 (+pad)
-  int32_t* cursor;  // kRCap
-  int32_t* rowinfo; // kRCap : (mol_local<<16 | [atom id > 0]<<15 | n) or -1 for slack rows
-  int32_t* moloff;  // kRCap+1
-  int32_t* molrows; // kRCap
-  int32_t* scratch; // 32
+  float* wimg;       // kImgSlot
+  float* hbuf0;      // kRCap*kHS
+  float* hbuf1;      // kRCap*kHS
+  float* tb;         // kTbCapFloats (row stride 8)
+  uint32_t* ent;     // kECap
+  int32_t* rowptr;   // kRCap+4 : CSR over PLACED rows
+  int32_t* cursor;   // kRCap   : fill cursors (placed rows)
+  int32_t* cnt;      // kRCap   : in-degree per LOGICAL row
+  int32_t* place;    // kRCap   : logical row -> placed row (rows are placed by descending in-degree)
+  int32_t* rowinfo;  // kRCap   : per logical row (mol_local<<16 | [atom id > 0]<<15 | n) or -1
+  int32_t* moloff;   // kRCap+4
+  int32_t* molrows;  // kRCap
+  int32_t* tilemax;  // 16      : largest in-degree inside each 16-row tile
+  int32_t* bins;     // 2*kDegBins (+pad): histogram / bin cursors
+  int32_t* scratch;  // 32
 };
 
 __host__ __device__ inline size_t lds_bytes(int K) {
   (void)K;
-  return sizeof(float) * ((size_t)kImgSlot + 2 * kRCap * kHS + kTbCapFloats) +
-         sizeof(uint32_t) * kECap + sizeof(int32_t) * ((kRCap + 4) + kRCap + kRCap + (kRCap + 4) + kRCap + 32);
+  return sizeof(float) * ((size_t)kImgSlot + 2 * kRCap * kHS + kTbCapFloats) + sizeof(uint32_t) * kECap +
+         sizeof(int32_t) * ((kRCap + 4) + 5 * kRCap + (kRCap + 4) + 16 + 48 + 32);
 }
 
-__global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p) {
+struct H8 {
+  half8 hi, lo;
+};
+// v (already scaled into fp16 range) = hi + lo, both rounded toward zero: 2 VALU ops per value
+__device__ __forceinline__ H8 split8(const float* v) {
+  H8 r;
+#pragma unroll
+  for (int pr = 0; pr < 4; ++pr) {
+    const auto h2 = __builtin_amdgcn_cvt_pkrtz(v[2 * pr], v[2 * pr + 1]);
+    const float r0 = __builtin_fmaf((float)h2[0], -1.0f, v[2 * pr]);
+    const float r1 = __builtin_fmaf((float)h2[1], -1.0f, v[2 * pr + 1]);
+    const auto l2 = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+    r.hi[2 * pr] = h2[0];
+    r.hi[2 * pr + 1] = h2[1];
+    r.lo[2 * pr] = l2[0];
+    r.lo[2 * pr + 1] = l2[1];
+  }
+  return r;
+}
+__device__ __forceinline__ H8 split8(f32x4 a, f32x4 b) {
+  const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return split8(v);
+}
+__device__ __forceinline__ half8 ldh8(const _Float16* p) { return *reinterpret_cast<const half8*>(p); }
+__device__ __forceinline__ f32x4 mfma16(half8 a, half8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// acc += A * (b.hi + b.lo) with A = ah + al, dropping al*b.lo (2^-22 relative)
+__device__ __forceinline__ void mma3(f32x4& main, f32x4& corr, const _Float16* blk, int lane, const H8& b) {
+  const half8 ah = ldh8(blk + lane * 8), al = ldh8(blk + 512 + lane * 8);
+  main = mfma16(ah, b.hi, main);
+  corr = mfma16(ah, b.lo, corr);
+  corr = mfma16(al, b.hi, corr);
+}
+
+// KT = compile-time bond_dim (0: run-time K <= 8); SPLIT: mode 1 (fp16 hi/lo products)
+template <int KT, bool SPLIT>
+__global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel(EncParams p) {
   extern __shared__ __align__(16) float smem[];
-  const int K = p.K;
+  const int K = KT ? KT : p.K;
   Lds L;
   {
     float* f = smem;
@@ -323,13 +426,17 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
     L.ent = reinterpret_cast<uint32_t*>(f); f += kECap;
     L.rowptr = reinterpret_cast<int32_t*>(f); f += kRCap + 4;
     L.cursor = reinterpret_cast<int32_t*>(f); f += kRCap;
+    L.cnt = reinterpret_cast<int32_t*>(f); f += kRCap;
+    L.place = reinterpret_cast<int32_t*>(f); f += kRCap;
     L.rowinfo = reinterpret_cast<int32_t*>(f); f += kRCap;
     L.moloff = reinterpret_cast<int32_t*>(f); f += kRCap + 4;
     L.molrows = reinterpret_cast<int32_t*>(f); f += kRCap;
+    L.tilemax = reinterpret_cast<int32_t*>(f); f += 16;
+    L.bins = reinterpret_cast<int32_t*>(f); f += 48;
     L.scratch = reinterpret_cast<int32_t*>(f);
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned long long* stamp = p.stamps ? p.stamps + (size_t)blockIdx.x * 8 : nullptr;
+  unsigned long long* stamp = p.stamps ? p.stamps + (size_t)blockIdx.x * 16 : nullptr;
   if (stamp && tid == 0) stamp[0] = __builtin_amdgcn_s_memtime();
   const int g = p.n_ions == 2 ? (blockIdx.x & 1) : 0;
   const int c = p.n_ions == 2 ? (blockIdx.x >> 1) : blockIdx.x;
@@ -350,11 +457,11 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
   const float* img_g = p.img + (int64_t)g * (p.S > 0 ? p.S : 1) * kImgSlot;
 
   // ---- prologue ------------------------------------------------------------------------
-  // P0: chunk tables; step-0 weight image starts its flight into registers
-  f32x4 pf0[kPf];
+  // P0: chunk tables; the step-0 weight image starts its flight into registers
+  f32x4 pf[kPf];
   if (p.S > 0) {
 #pragma unroll
-    for (int i = 0; i < kPf; ++i) pf0[i] = ld4(img_g + 4 * (tid + i * kThreads));
+    for (int i = 0; i < kPf; ++i) pf[i] = ld4(img_g + 4 * (tid + i * kThreads));
   }
   for (int m = tid; m <= M; m += kThreads) {
     L.moloff[m] = start[m0 + m] - base;
@@ -362,19 +469,21 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
   }
   for (int t = tid; t < p.Vb * kKMax; t += kThreads) {
     const int v = t >> 3, k = t & 7;
-    L.tb[t] = k < K ? p.bond_table[v * K + k] : 0.f;
+    L.tb[t] = k < K ? p.bond_table[v * K + k] * (SPLIT ? kSX : 1.0f) : 0.f;  // mode 1: G comes out pre-scaled
   }
-  for (int r = tid; r < kRCap + 4; r += kThreads) L.rowptr[r] = 0;  // used as in-degree counters first
+  if (tid < kRCap) L.cnt[tid] = 0;
+  if (tid < 48) L.bins[tid] = 0;
+  if (tid < 16) L.tilemax[tid] = 0;
   __syncthreads();
 
-  // P1: in-degree of every row (edge-parallel, coalesced reads of conn / bond ids);
-  //     row -> (molecule, n, id>0) map
+  // P1: in-degree of every logical row (edge-parallel, coalesced reads of conn / bond ids);
+  //     logical row -> (molecule, n, id>0)
   const int n_slots = M * E;
   for (int slot = tid; slot < n_slots; slot += kThreads) {
     const int m = slot / E, e = slot - m * E;
     const int64_t b = m0 + m;
     const int2 st = *reinterpret_cast<const int2*>(conn_g + (b * E + e) * 2);
-    if (edge_valid(st.x, st.y, bond_g[b * E + e], N, p.Vb)) atomicAdd(&L.rowptr[L.moloff[m] + st.y], 1);
+    if (edge_valid(st.x, st.y, bond_g[b * E + e], N, p.Vb)) atomicAdd(&L.cnt[L.moloff[m] + st.y], 1);
   }
   if (tid < kRCap) {
     const int row = tid;
@@ -395,9 +504,39 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
   }
   __syncthreads();
 
-  // P2: exclusive scan of the in-degrees -> rowptr; cursor = copy used by the fill
+  // P2: place rows by descending in-degree (counting sort over 18 bins) so that a tile's lanes
+  //     walk in-edge lists of similar length.  The placement inside a bin comes from an LDS
+  //     atomic and may differ run to run - harmless: no result depends on where a row sits
+  //     (MFMA columns, the gather and LayerNorm are per row; the pool walks logical rows).
+  int my_bin = 0, my_deg = 0;
+  if (tid < kRCap) {
+    my_deg = L.cnt[tid];
+    my_bin = tid >= R ? 0 : (my_deg >= 16 ? 1 : 17 - my_deg);  // bin 0 = beyond chunk ... 17 = degree 0
+    // bins are laid out so that ascending bin index = placement order, except bin 0 which goes last
+    atomicAdd(&L.bins[my_bin], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int bI = 1; bI < kDegBins; ++bI) {
+      const int t = L.bins[bI];
+      L.bins[24 + bI] = run;
+      run += t;
+    }
+    L.bins[24] = run;  // rows beyond the chunk go last
+  }
+  __syncthreads();
+  if (tid < kRCap) {
+    const int pos = L.bins[24 + my_bin] + atomicAdd(&L.bins[my_bin], -1) - 1;
+    L.place[tid] = pos;
+    L.cursor[pos] = my_deg;  // in-degree per placed row (scanned below)
+    if (my_deg > 0) atomicMax(&L.tilemax[pos >> 4], my_deg);
+  }
+  __syncthreads();
+
+  // P3: exclusive scan of the placed in-degrees -> rowptr; cursor = fill position
   {
-    const int my_cnt = tid < kRCap ? L.rowptr[tid] : 0;
+    const int my_cnt = tid < kRCap ? L.cursor[tid] : 0;
     int incl = my_cnt;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -417,8 +556,8 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
   }
   __syncthreads();
 
-  // P3: fill.  entry = edge slot (16b) | bond id (8b) | source row (8b); the slot in the top bits
-  //     lets P4 restore edge-slot order, so the accumulation order is fixed run to run.
+  // P4: fill.  entry = edge slot (16b) | bond id (8b) | placed source row (8b); the slot in the
+  //     top bits lets P5 restore edge-slot order, so the accumulation order is fixed run to run.
   for (int slot = tid; slot < n_slots; slot += kThreads) {
     const int m = slot / E, e = slot - m * E;
     const int64_t b = m0 + m;
@@ -426,8 +565,8 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
     const int bid = bond_g[b * E + e];
     if (edge_valid(st.x, st.y, bid, N, p.Vb)) {
       const int mo = L.moloff[m];
-      const int pos = atomicAdd(&L.cursor[mo + st.y], 1);
-      L.ent[pos] = ((uint32_t)e << 16) | ((uint32_t)bid << 8) | (uint32_t)(mo + st.x);
+      const int pos = atomicAdd(&L.cursor[L.place[mo + st.y]], 1);
+      L.ent[pos] = ((uint32_t)e << 16) | ((uint32_t)bid << 8) | (uint32_t)L.place[mo + st.x];
     }
   }
   // h0 = atom_table[atom_ids]  (train_viscosity.py:171); slack rows = 0 in both buffers
@@ -440,16 +579,17 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
       const int id = ids_g[(int64_t)(m0 + m) * N + n];
       if ((unsigned)id < (unsigned)p.Va) v = ld4(p.atom_table + (int64_t)id * kD + 4 * part);
     }
-    st4(L.hbuf0 + row * kHS + 4 * part, v);
-    st4(L.hbuf1 + row * kHS + 4 * part, v);
+    const int pr = L.place[row];
+    st4(L.hbuf0 + pr * kHS + 4 * part, v);
+    st4(L.hbuf1 + pr * kHS + 4 * part, v);
   }
   if (p.S > 0) {
 #pragma unroll
-    for (int i = 0; i < kPf; ++i) st4(L.wimg + 4 * (tid + i * kThreads), pf0[i]);
+    for (int i = 0; i < kPf; ++i) st4(L.wimg + 4 * (tid + i * kThreads), pf[i]);
   }
   __syncthreads();
 
-  // P4: sort every row's in-edge list by edge slot (lists are short: insertion sort)
+  // P5: sort every row's in-edge list by edge slot (lists are short: insertion sort)
   if (tid < kRCap) {
     const int lo = L.rowptr[tid], hi = L.rowptr[tid + 1];
     for (int i = lo + 1; i < hi; ++i) {
@@ -466,38 +606,65 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
 
   if (stamp && tid == 0) stamp[1] = __builtin_amdgcn_s_memtime();
   // ---- message-passing steps -----------------------------------------------------------
+  // One 16-atom tile per wave (16 waves, 4 per SIMD): while one wave of a SIMD gathers or runs
+  // its sigmoid/LayerNorm VALU work, the other three keep the matrix pipe fed.
+  // Rows are placed by descending in-degree, so tile w (= wave w) has the longest gather of its
+  // SIMD's four tiles when w is small: give the long-gather waves issue priority so the critical
+  // path (heaviest tile) is not slowed by its lighter partners.
+  {
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
+    if (wu < 4) __builtin_amdgcn_s_setprio(3);
+    else if (wu < 8) __builtin_amdgcn_s_setprio(2);
+    else if (wu < 12) __builtin_amdgcn_s_setprio(1);
+  }
   const int a = lane & 15, q = lane >> 4;
   const float* wmsg = L.wimg;
   const float* wupd = L.wimg + img_msg_floats(K);
-  const float* wvec = wupd + img_upd_floats();
+  const float* wvec = SPLIT ? L.wimg + img16_vec_float_off(K) : wupd + img_upd_floats();
+  const _Float16* hmsg = reinterpret_cast<const _Float16*>(L.wimg);
+  const _Float16* hupd = hmsg + img16_msg_halfs(K);
   for (int s = 0; s < p.S; ++s) {
     const float* hcur = (s & 1) ? L.hbuf1 : L.hbuf0;
     float* hnext = (s & 1) ? L.hbuf0 : L.hbuf1;
-    // prefetch next step's weight image into registers (written to LDS after the barrier)
-    // (the last step re-reads its own image: unconditional loads, no branch, no extra wait)
-    f32x4 pf[kPf];
-    {
-      const int sn = (s + 1) < p.S ? (s + 1) : s;
-      const float* nxt = img_g + (int64_t)sn * kImgSlot;
-#pragma unroll
-      for (int i = 0; i < kPf; ++i) pf[i] = ld4(nxt + 4 * (tid + i * kThreads));
-    }
+    const int sn = (s + 1) < p.S ? (s + 1) : s;  // the last step re-reads its own image: no branch
+    const float* nxt = img_g + (int64_t)sn * kImgSlot;
+    bool pf_issued = false;
 
     for (int tile = wave; tile < ntiles; tile += kWaves) {
+      const bool tstamp = stamp != nullptr && tile == 0 && s == (p.S > 1 ? 1 : 0);  // wave 0 only (tile 0)
+      if (tstamp && lane == 0) stamp[8] = __builtin_amdgcn_s_memtime();
       const int row = tile * 16 + a;
       const f32x4 h0 = ld4(hcur + row * kHS + 4 * q);
       const f32x4 h1 = ld4(hcur + row * kHS + 16 + 4 * q);
 
-      // ---- pull gather: G[k][j] = sum_{in-edges} tb[bond][k] * h[src][j]
-      float G[kKMax][8];
-#pragma unroll
-      for (int k = 0; k < kKMax; ++k)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) G[k][i] = 0.f;
+      // ---- pull gather: G[k][j] = sum_{in-edges} tb[bond][k] * h[src][j]   (edge-slot order)
       const int p0 = L.rowptr[row];
       const int deg = L.rowptr[row + 1] - p0;
-      const int maxdeg = wave_max_i(deg);
-      for (int d = 0; d < maxdeg; ++d) {
+      const int maxdeg = __builtin_amdgcn_readfirstlane(L.tilemax[tile]);
+      float G[kKMax][8];
+      {
+        // first in-edge initialises G (rows without in-edges use a zero coefficient vector)
+        const uint32_t ent = L.ent[deg > 0 ? p0 : 0];
+        const int src = ent & 0xffu, bid = (ent >> 8) & 0xffu;
+        const f32x4 x0 = ld4(hcur + src * kHS + 4 * q);
+        const f32x4 x1 = ld4(hcur + src * kHS + 16 + 4 * q);
+        f32x4 c0 = ld4(L.tb + bid * kKMax);
+        f32x4 c1 = ld4(L.tb + bid * kKMax + 4);
+        if (deg <= 0) {
+          c0 = f32x4{0.f, 0.f, 0.f, 0.f};
+          c1 = c0;
+        }
+#pragma unroll
+        for (int k = 0; k < kKMax; ++k) {
+          const float ck = k < 4 ? c0[k & 3] : c1[k & 3];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            G[k][i] = ck * x0[i];
+            G[k][4 + i] = ck * x1[i];
+          }
+        }
+      }
+      for (int d = 1; d < maxdeg; ++d) {
         if (d < deg) {
           const uint32_t ent = L.ent[p0 + d];
           const int src = ent & 0xffu, bid = (ent >> 8) & 0xffu;
@@ -516,72 +683,140 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
           }
         }
       }
+      if (tstamp && lane == 0) stamp[9] = __builtin_amdgcn_s_memtime();
 
       // ---- agg^T = sum_k W_k * G_k   (models/layers.py:108-112 + 78-82, reassociated)
       f32x4 agg0 = {0.f, 0.f, 0.f, 0.f}, agg1 = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (SPLIT) {
+        f32x4 c0 = agg0, c1 = agg0;
 #pragma unroll
-      for (int k = 0; k < kKMax; ++k) {
-        if (k < K) {
+        for (int k = 0; k < kKMax; ++k) {
+          if (k < K) {
+            const H8 g = split8(G[k]);
+            mma3(agg0, c0, hmsg + (k * 2 + 0) * 1024, lane, g);
+            mma3(agg1, c1, hmsg + (k * 2 + 1) * 1024, lane, g);
+          }
+        }
+        // accumulators carry kAcc; keep agg as agg*kSX: the B-operand scale of the next GEMMs
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const f32x4 A0 = ld4(wmsg + (k * kD + a) * kMsgRS + 16 * u + 4 * q);
-            const f32x4 A1 = ld4(wmsg + (k * kD + 16 + a) * kMsgRS + 16 * u + 4 * q);
+        for (int i = 0; i < 4; ++i) {
+          agg0[i] = (agg0[i] + c0[i]) * (kSX / kAcc);
+          agg1[i] = (agg1[i] + c1[i]) * (kSX / kAcc);
+        }
+      } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              agg0 = mfma4(A0[r], G[k][4 * u + r], agg0);
-              agg1 = mfma4(A1[r], G[k][4 * u + r], agg1);
+        for (int k = 0; k < kKMax; ++k) {
+          if (k < K) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const f32x4 A0 = ld4(wmsg + (k * kD + a) * kMsgRS + 16 * u + 4 * q);
+              const f32x4 A1 = ld4(wmsg + (k * kD + 16 + a) * kMsgRS + 16 * u + 4 * q);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                agg0 = mfma4(A0[r], G[k][4 * u + r], agg0);
+                agg1 = mfma4(A1[r], G[k][4 * u + r], agg1);
+              }
             }
           }
         }
       }
+      if (tstamp && lane == 0) stamp[10] = __builtin_amdgcn_s_memtime();
+      // next step's weight image starts its flight now (G is dead: registers are free)
+      if (!pf_issued) {
+#pragma unroll
+        for (int i = 0; i < kPf; ++i) pf[i] = ld4(nxt + 4 * (tid + i * kThreads));
+        pf_issued = true;
+      }
 
-      // ---- gates z, r  (models/layers.py:144-147)
+      // ---- gates z, r (models/layers.py:144-147) and candidate (:150-151)
       f32x4 z0 = ld4(wvec + 0 * kD + 4 * q), z1 = ld4(wvec + 0 * kD + 16 + 4 * q);
       f32x4 r0 = ld4(wvec + 1 * kD + 4 * q), r1 = ld4(wvec + 1 * kD + 16 + 4 * q);
-#pragma unroll
-      for (int half = 0; half < 2; ++half) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int col = 32 * half + 16 * u + 4 * q;
-          const f32x4 Az0 = ld4(wupd + (0 * kD + a) * kUpdRS + col);
-          const f32x4 Az1 = ld4(wupd + (0 * kD + 16 + a) * kUpdRS + col);
-          const f32x4 Ar0 = ld4(wupd + (1 * kD + a) * kUpdRS + col);
-          const f32x4 Ar1 = ld4(wupd + (1 * kD + 16 + a) * kUpdRS + col);
-          const f32x4 Bv = half == 0 ? (u == 0 ? h0 : h1) : (u == 0 ? agg0 : agg1);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            z0 = mfma4(Az0[r], Bv[r], z0);
-            z1 = mfma4(Az1[r], Bv[r], z1);
-            r0 = mfma4(Ar0[r], Bv[r], r0);
-            r1 = mfma4(Ar1[r], Bv[r], r1);
-          }
-        }
-      }
-      f32x4 rh0, rh1;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        z0[i] = fast_sigmoid(z0[i]);
-        z1[i] = fast_sigmoid(z1[i]);
-        rh0[i] = fast_sigmoid(r0[i]) * h0[i];  // :149
-        rh1[i] = fast_sigmoid(r1[i]) * h1[i];
-      }
-      // ---- candidate  (models/layers.py:150-151)
       f32x4 t0 = ld4(wvec + 2 * kD + 4 * q), t1 = ld4(wvec + 2 * kD + 16 + 4 * q);
+      f32x4 rh0, rh1;
+      if constexpr (SPLIT) {
+        f32x4 hs0, hs1;  // h * kSX
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+        for (int i = 0; i < 4; ++i) {
+          hs0[i] = h0[i] * kSX;
+          hs1[i] = h1[i] * kSX;
+        }
+        const H8 sh = split8(hs0, hs1);
+        const H8 sa = split8(agg0, agg1);
+        f32x4 cz0 = {0.f, 0.f, 0.f, 0.f}, cz1 = cz0, cr0 = cz0, cr1 = cz0;
+        // block index = ((gate*2 + T)*2 + half), 1024 halfs each
+        mma3(z0, cz0, hupd + ((0 * 2 + 0) * 2 + 0) * 1024, lane, sh);
+        mma3(z1, cz1, hupd + ((0 * 2 + 1) * 2 + 0) * 1024, lane, sh);
+        mma3(r0, cr0, hupd + ((1 * 2 + 0) * 2 + 0) * 1024, lane, sh);
+        mma3(r1, cr1, hupd + ((1 * 2 + 1) * 2 + 0) * 1024, lane, sh);
+        mma3(z0, cz0, hupd + ((0 * 2 + 0) * 2 + 1) * 1024, lane, sa);
+        mma3(z1, cz1, hupd + ((0 * 2 + 1) * 2 + 1) * 1024, lane, sa);
+        mma3(r0, cr0, hupd + ((1 * 2 + 0) * 2 + 1) * 1024, lane, sa);
+        mma3(r1, cr1, hupd + ((1 * 2 + 1) * 2 + 1) * 1024, lane, sa);
+        if (tstamp && lane == 0) stamp[11] = __builtin_amdgcn_s_memtime();
+        f32x4 rs0, rs1;  // sigmoid(r) * h * kSX
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int col = 32 * half + 16 * u + 4 * q;
-          const f32x4 Ah0 = ld4(wupd + (2 * kD + a) * kUpdRS + col);
-          const f32x4 Ah1 = ld4(wupd + (2 * kD + 16 + a) * kUpdRS + col);
-          const f32x4 Bv = half == 0 ? (u == 0 ? rh0 : rh1) : (u == 0 ? agg0 : agg1);
+        for (int i = 0; i < 4; ++i) {
+          z0[i] = fast_sigmoid((z0[i] + cz0[i]) * (1.0f / kAcc));
+          z1[i] = fast_sigmoid((z1[i] + cz1[i]) * (1.0f / kAcc));
+          rs0[i] = fast_sigmoid((r0[i] + cr0[i]) * (1.0f / kAcc)) * hs0[i];  // :149
+          rs1[i] = fast_sigmoid((r1[i] + cr1[i]) * (1.0f / kAcc)) * hs1[i];
+        }
+        const H8 srh = split8(rs0, rs1);
+        f32x4 ct0 = {0.f, 0.f, 0.f, 0.f}, ct1 = ct0;
+        mma3(t0, ct0, hupd + ((2 * 2 + 0) * 2 + 0) * 1024, lane, srh);
+        mma3(t1, ct1, hupd + ((2 * 2 + 1) * 2 + 0) * 1024, lane, srh);
+        mma3(t0, ct0, hupd + ((2 * 2 + 0) * 2 + 1) * 1024, lane, sa);
+        mma3(t1, ct1, hupd + ((2 * 2 + 1) * 2 + 1) * 1024, lane, sa);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            t0 = mfma4(Ah0[r], Bv[r], t0);
-            t1 = mfma4(Ah1[r], Bv[r], t1);
+        for (int i = 0; i < 4; ++i) {
+          t0[i] = (t0[i] + ct0[i]) * (1.0f / kAcc);
+          t1[i] = (t1[i] + ct1[i]) * (1.0f / kAcc);
+        }
+      } else {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int col = 32 * half + 16 * u + 4 * q;
+            const f32x4 Az0 = ld4(wupd + (0 * kD + a) * kUpdRS + col);
+            const f32x4 Az1 = ld4(wupd + (0 * kD + 16 + a) * kUpdRS + col);
+            const f32x4 Ar0 = ld4(wupd + (1 * kD + a) * kUpdRS + col);
+            const f32x4 Ar1 = ld4(wupd + (1 * kD + 16 + a) * kUpdRS + col);
+            const f32x4 Bv = half == 0 ? (u == 0 ? h0 : h1) : (u == 0 ? agg0 : agg1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              z0 = mfma4(Az0[r], Bv[r], z0);
+              z1 = mfma4(Az1[r], Bv[r], z1);
+              r0 = mfma4(Ar0[r], Bv[r], r0);
+              r1 = mfma4(Ar1[r], Bv[r], r1);
+            }
+          }
+        }
+        if (tstamp && lane == 0) stamp[11] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          z0[i] = fast_sigmoid(z0[i]);
+          z1[i] = fast_sigmoid(z1[i]);
+          rh0[i] = fast_sigmoid(r0[i]) * h0[i];  // :149
+          rh1[i] = fast_sigmoid(r1[i]) * h1[i];
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int col = 32 * half + 16 * u + 4 * q;
+            const f32x4 Ah0 = ld4(wupd + (2 * kD + a) * kUpdRS + col);
+            const f32x4 Ah1 = ld4(wupd + (2 * kD + 16 + a) * kUpdRS + col);
+            const f32x4 Bv = half == 0 ? (u == 0 ? rh0 : rh1) : (u == 0 ? agg0 : agg1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              t0 = mfma4(Ah0[r], Bv[r], t0);
+              t1 = mfma4(Ah1[r], Bv[r], t1);
+            }
           }
         }
       }
+      if (tstamp && lane == 0) stamp[12] = __builtin_amdgcn_s_memtime();
       // ---- blend, LayerNorm, residual  (models/layers.py:153-155)
       f32x4 n0, n1;
       float sum = 0.f;
@@ -615,8 +850,15 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
       }
       st4(hnext + row * kHS + 4 * q, o0);
       st4(hnext + row * kHS + 16 + 4 * q, o1);
+      if (tstamp && lane == 0) stamp[13] = __builtin_amdgcn_s_memtime();
     }
+    if (!pf_issued) {  // waves without a tile in this chunk still carry their share of the image
+#pragma unroll
+      for (int i = 0; i < kPf; ++i) pf[i] = ld4(nxt + 4 * (tid + i * kThreads));
+    }
+    if (stamp && tid == 0 && s == (p.S > 1 ? 1 : 0)) stamp[14] = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    if (stamp && tid == 0 && s == (p.S > 1 ? 1 : 0)) stamp[15] = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int i = 0; i < kPf; ++i) st4(L.wimg + 4 * (tid + i * kThreads), pf[i]);
     __syncthreads();
@@ -635,7 +877,7 @@ __global__ __launch_bounds__(kThreads, 2) void encoder_fused_kernel(EncParams p)
     if (m < M) {
       const int nr = L.molrows[m], mo = L.moloff[m];
       for (int n = part; n < nr; n += 4)
-        if (L.rowinfo[mo + n] & 0x8000) acc += hfin[(mo + n) * kHS + f];
+        if (L.rowinfo[mo + n] & 0x8000) acc += hfin[L.place[mo + n] * kHS + f];
     }
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
@@ -689,6 +931,7 @@ int launch_encoder_fused(const EncoderArgs& a, hipStream_t s) {
   pp.win = kRCap - vr_max_of(a.N, a.E) + 1;
   pp.ub = w.ub;
   pp.step_floats = impnn_encoder_step_floats(a.D, a.K);
+  pp.mode = encoder_mode() == 1 ? 1 : 0;
   const int waves_per_block = 4;
   pp.mol_blocks = (int)(((int64_t)a.n_ions * a.B + waves_per_block - 1) / waves_per_block);
   const int img_blocks = a.n_ions * a.S;
@@ -706,19 +949,24 @@ int launch_encoder_fused(const EncoderArgs& a, hipStream_t s) {
   {
     size_t sb = 0;
     void* sp = debug_stamp_buffer(&sb);
-    if (sp && sb >= (size_t)w.ub * a.n_ions * 8 * sizeof(unsigned long long))
+    if (sp && sb >= (size_t)w.ub * a.n_ions * 16 * sizeof(unsigned long long))
       ep.stamps = static_cast<unsigned long long*>(sp);
   }
   const size_t lds = lds_bytes(a.K);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)encoder_fused_kernel,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const int mode = encoder_mode() == 1 ? 1 : 0;
+  const int variant = (a.K == 8 ? 1 : 0) + 2 * mode;
+  void (*kern)(EncParams) = variant == 0   ? encoder_fused_kernel<0, false>
+                            : variant == 1 ? encoder_fused_kernel<8, false>
+                            : variant == 2 ? encoder_fused_kernel<0, true>
+                                           : encoder_fused_kernel<8, true>;
+  static bool attr_set[4] = {false, false, false, false};
+  if (!attr_set[variant]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return fail(IMPNN_E_LAUNCH, "encoder_fused: cannot raise LDS limit: %s", hipGetErrorString(e));
-    attr_set = true;
+    attr_set[variant] = true;
   }
   profile_record_start(s);
-  encoder_fused_kernel<<<w.ub * a.n_ions, kThreads, lds, s>>>(ep);
+  kern<<<w.ub * a.n_ions, kThreads, lds, s>>>(ep);
   profile_record_stop(s);
   return check_launch("encoder_fused");
 }

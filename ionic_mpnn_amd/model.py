@@ -62,6 +62,8 @@ class MPNNModel:
             self.mp_out = L.Dense(1, **dev)                             # :198
         self._build_all()
         self._packed = None
+        self._split_deg_limit = None
+        self.encoder_mode = "auto"  # "auto" | "f32" | "f16x2"
 
     # ------------------------------------------------------------------ construction
     def _build_all(self):
@@ -138,11 +140,12 @@ class MPNNModel:
             if tuple(a.shape) != tuple(t.shape):
                 raise ValueError(f"{k}: shape {a.shape} != {tuple(t.shape)}")
             t.copy_(torch.from_numpy(a))
-        self._packed = None
+        self.invalidate_packed_weights()
 
     def invalidate_packed_weights(self):
         """Call after mutating layer weights in place; the fused encoder caches a packed copy."""
         self._packed = None
+        self._split_deg_limit = None
 
     def _packed_weights(self):
         if self._packed is None:
@@ -158,8 +161,19 @@ class MPNNModel:
                                   "Wh": w["dense_h/kernel"], "bh": w["dense_h/bias"],
                                   "gamma": w["layernorm/gamma"], "beta": w["layernorm/beta"]})
                 packed.append(ops.pack_step_weights(steps))
+                lim = ops.split_mode_degree_limit(self.atom_emb.embeddings, self.bond_emb.embeddings, steps,
+                                                  self.atom_dim)
+                self._split_deg_limit = lim if self._split_deg_limit is None else min(self._split_deg_limit, lim)
             self._packed = packed
         return self._packed
+
+    def resolve_encoder_mode(self, E):
+        """"f16x2" when the static range bound holds for every possible in-degree (<= E edge slots),
+        else the exact "f32" mode."""
+        if self.encoder_mode != "auto":
+            return self.encoder_mode
+        self._packed_weights()
+        return "f16x2" if (self._split_deg_limit is None or E <= self._split_deg_limit) else "f32"
 
     # ------------------------------------------------------------------ forward
     def fused_supported(self, N, E):
@@ -192,7 +206,8 @@ class MPNNModel:
                      and self.fused_supported(ca.shape[1], cb.shape[1]))
         if fused:
             pc, pa = ops.encoder_fused([(ca, cb, cc), (aa, ab, ac)], self.atom_emb.embeddings,
-                                       self.bond_emb.embeddings, self._packed_weights(), self.num_steps)
+                                       self.bond_emb.embeddings, self._packed_weights(), self.num_steps,
+                                       mode=self.resolve_encoder_mode(cb.shape[1]))
             if trace is not None:
                 trace["cat/pooled"], trace["an/pooled"] = pc, pa
             return pc, pa

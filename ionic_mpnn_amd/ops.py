@@ -209,11 +209,40 @@ def encoder_fused_supported(N, E, D, K, S, Vb):
     return rc == 0
 
 
-def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=LN_EPS):
+ENCODER_MODES = {"f32": 0, "f16x2": 1}
+FP16_MAX = 65504.0
+SPLIT_SX, SPLIT_SW = 16.0, 256.0  # kSX / kSW of encoder_fused.hip
+
+
+def split_mode_degree_limit(atom_table, bond_table, steps, D):
+    """Largest in-degree for which the encoder's "f16x2" mode provably stays inside fp16 range.
+
+    With LayerNorm, |h_s| <= Hmax = max|atom_table| + S*(sqrt(D-1)*max|gamma| + max|beta|)
+    (models/layers.py:154-155), |G| <= deg*max|bond_table|*Hmax and |agg_i| <= L1max(W)*|G|max, where
+    L1max = max_i sum_{k,j}|W[k,i,j]|.  Mode 1 needs 16*max(|h|,|G|,|agg|) < 65504 and
+    256*max|weights| < 65504.  Returns 0.0 when no degree is safe.  (One device sync: call when
+    weights change, not per batch.)"""
+    if not steps:
+        return float("inf")
+    gmax = max(float(s["gamma"].abs().max()) for s in steps)
+    bmax = max(float(s["beta"].abs().max()) for s in steps)
+    wmax = max(float(s[k].abs().max()) for s in steps for k in ("bond_transform", "Wz", "Wr", "Wh"))
+    l1 = max(float(s["bond_transform"].abs().sum(dim=(0, 2)).max()) for s in steps)
+    hmax = float(atom_table.abs().max()) + len(steps) * ((D - 1) ** 0.5 * gmax + bmax)
+    cmax = float(bond_table.abs().max())
+    if wmax * SPLIT_SW >= FP16_MAX or hmax * SPLIT_SX >= FP16_MAX:
+        return 0.0
+    per_deg = SPLIT_SX * cmax * hmax * max(1.0, l1)
+    return float("inf") if per_deg == 0.0 else 0.999 * FP16_MAX / per_deg
+
+
+def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=LN_EPS, mode="f16x2"):
     """encode() up to GlobalSumPool for 1 or 2 ion branches in one launch.
 
     ions: list of (atom_ids (B,N), bond_ids (B,E), conn (B,E,2)); packed_weights: list of packed
     step-weight tensors (pack_step_weights).  Returns a list of pooled (B,D) tensors.
+    mode: "f32" (exact f32 MFMA) or "f16x2" (split-fp16 MFMA, f32 accumulate; the caller vouches for
+    the range condition of include/impnn.h - ionic_mpnn_amd.model does via split_mode_degree_limit).
     """
     n = len(ions)
     if n not in (1, 2):
@@ -251,7 +280,10 @@ def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=L
             raise ValueError(f"packed step weights must hold S*{step_f} floats")
     arr = C.c_void_p * n
     mk = lambda ts: arr(*[t.data_ptr() if t is not None else 0 for t in ts])
+    if mode not in ENCODER_MODES:
+        raise ValueError(f"mode must be one of {sorted(ENCODER_MODES)}")
     with torch.cuda.device(dev):
+        lib.impnn_encoder_set_mode(ENCODER_MODES[mode])
         check(lib.impnn_encoder_fused(n, mk([p[0] for p in prepared]), mk([p[1] for p in prepared]),
                                       mk([p[2] for p in prepared]), ptr(atom_table), Va, ptr(bond_table), Vb,
                                       mk(ws_w), mk(pooled), B, N, E, D, K, S, float(eps), ptr(ws), ws.numel(),

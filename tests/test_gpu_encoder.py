@@ -18,17 +18,22 @@ def to_dev(inputs):
     return {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in inputs.items()}
 
 
-def make_model(w, Va, Vb, D=32, K=8, fp=32, mix=20):
+def make_model(w, Va, Vb, D=32, K=8, fp=32, mix=20, mode="auto"):
     m = MM.build_model(Va, Vb, atom_dim=D, bond_dim=K, fp_size=fp, mixing_size=mix, num_steps=weights.num_steps_of(w),
                        device=DEV)
     m.load_weights(w)
+    m.encoder_mode = mode
     return m
 
 
+MODES = ["f32", "f16x2"]
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", ["config2_b8", "config2_perturbed_b6"])
-def test_fused_encoder_vs_golden(name):
+def test_fused_encoder_vs_golden(name, mode):
     _, inp, w, outs = load_case(name)
-    m = make_model(w, *w["atom_embedding"].shape[:1], w["bond_embedding"].shape[0])
+    m = make_model(w, *w["atom_embedding"].shape[:1], w["bond_embedding"].shape[0], mode=mode)
     pc, pa = m.encode_pooled(to_dev(inp), fused=True)
     assert_close(pc.cpu().numpy(), outs["cat/pooled"], what="cat pooled")
     assert_close(pa.cpu().numpy(), outs["an/pooled"], what="an pooled")
@@ -45,12 +50,13 @@ def test_fused_encoder_vs_golden(name):
 @pytest.mark.parametrize("N,E,K,S,B,seed", [(40, 80, 8, 3, 64, 1), (40, 80, 8, 4, 257, 2), (12, 20, 4, 2, 100, 3),
                                             (7, 30, 1, 1, 50, 4), (64, 120, 8, 2, 40, 5), (40, 80, 5, 0, 30, 6),
                                             (1, 0, 8, 2, 9, 7), (100, 240, 8, 1, 16, 8), (128, 512, 3, 1, 5, 9)])
-def test_fused_encoder_random_shapes(N, E, K, S, B, seed):
+@pytest.mark.parametrize("mode", MODES)
+def test_fused_encoder_random_shapes(N, E, K, S, B, seed, mode):
     Va, Vb = 30, 11
     inp = synthetic.make_batch(B, max_atoms=N, max_edges=E, atom_vocab_size=Va, bond_vocab_size=Vb,
                                min_atoms=min(3, N), seed=seed)
     w = weights.init_weights("viscosity", Va, Vb, atom_dim=32, bond_dim=K, num_steps=S, seed=seed + 100, perturb=True)
-    m = make_model(w, Va, Vb, K=K)
+    m = make_model(w, Va, Vb, K=K, mode=mode)
     assert m.fused_supported(N, E)
     pc, pa = m.encode_pooled(to_dev(inp), fused=True)
     rc = O.encode(w, "cat", inp["cat_atom"], inp["cat_bond"], inp["cat_connectivity"], pooled_only=True)
@@ -59,7 +65,8 @@ def test_fused_encoder_random_shapes(N, E, K, S, B, seed):
     assert_close(pa.cpu().numpy(), ra, what="an pooled")
 
 
-def test_fused_encoder_adversarial_graphs():
+@pytest.mark.parametrize("mode", MODES)
+def test_fused_encoder_adversarial_graphs(mode):
     """Edges that name padding atoms, self loops, 4x duplicated bonds (trainer expansion), id-0 holes,
     all-padding molecules, dense in-degree - the general contract, not just tree graphs."""
     rng = np.random.default_rng(42)
@@ -78,7 +85,7 @@ def test_fused_encoder_adversarial_graphs():
     inp = {"cat_atom": ids, "cat_bond": bond, "cat_connectivity": conn,
            "an_atom": ids[::-1].copy(), "an_bond": bond[::-1].copy(), "an_connectivity": conn[::-1].copy()}
     w = weights.init_weights("viscosity", Va, Vb, atom_dim=32, bond_dim=K, num_steps=S, seed=9, perturb=True)
-    m = make_model(w, Va, Vb, K=K)
+    m = make_model(w, Va, Vb, K=K, mode=mode)
     pc, pa = m.encode_pooled(to_dev(inp), fused=True)
     rc = O.encode(w, "cat", ids, bond, conn, pooled_only=True)
     ra = O.encode(w, "an", inp["an_atom"], inp["an_bond"], inp["an_connectivity"], pooled_only=True)
@@ -105,11 +112,11 @@ def test_unsupported_shapes_fall_back_to_layered_hip():
 
 
 # ------------------------------------------------------------------ full size (B=4096): properties
-@pytest.fixture(scope="module")
-def full():
+@pytest.fixture(scope="module", params=MODES)
+def full(request):
     inp = synthetic.make_batch(4096, seed=0)
     w = weights.init_weights("viscosity", synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, num_steps=3, seed=1)
-    m = make_model(w, synthetic.DEFAULT_VA, synthetic.DEFAULT_VB)
+    m = make_model(w, synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, mode=request.param)
     d = to_dev(inp)
     pc, pa = m.encode_pooled(d, fused=True)
     torch.cuda.synchronize()
@@ -172,6 +179,25 @@ def test_full_batch_fused_equals_layered_hip(full):
     lc, la = m.encode_pooled(d, fused=False)
     assert_close(pc.cpu().numpy(), lc.cpu().numpy(), what="fused vs layered cat")
     assert_close(pa.cpu().numpy(), la.cpu().numpy(), what="fused vs layered an")
+
+
+def test_auto_mode_uses_static_range_bound():
+    """auto = f16x2 only when the LayerNorm / in-degree bound keeps every operand inside fp16 range."""
+    w = weights.init_weights("viscosity", synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, num_steps=3, seed=1)
+    m = make_model(w, synthetic.DEFAULT_VA, synthetic.DEFAULT_VB)
+    assert m.resolve_encoder_mode(80) == "f16x2" and m._split_deg_limit > 80
+    big = dict(w)
+    big["bond_embedding"] = w["bond_embedding"] * 400.0        # |G| bound explodes -> exact mode
+    m.load_weights(big)
+    assert m.resolve_encoder_mode(80) == "f32"
+    inp = synthetic.make_batch(16, seed=3)
+    ref = O.encode(big, "cat", inp["cat_atom"], inp["cat_bond"], inp["cat_connectivity"], pooled_only=True)
+    pc, _ = m.encode_pooled(to_dev(inp), fused=True)
+    assert_close(pc.cpu().numpy(), ref, what="exact-mode fallback")
+    huge = dict(w)
+    huge["cat_bmm_0/bond_transform"] = w["cat_bmm_0/bond_transform"] * 2000.0   # |W|*256 > fp16 max
+    m.load_weights(huge)
+    assert m._packed_weights() is not None and m._split_deg_limit == 0.0 and m.resolve_encoder_mode(1) == "f32"
 
 
 def test_config1_dataset_plumbing_batch32():

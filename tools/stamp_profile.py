@@ -28,13 +28,13 @@ for _ in range(3):
     m.encode_pooled(d, fused=True)
 torch.cuda.synchronize()
 nwg = 2 * (B * 40 // 217 + 1)
-buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
+buf = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
 lib = _lib.load()
 lib.impnn_debug_set_stamp_buffer(buf.data_ptr(), buf.numel() * 8)
 m.encode_pooled(d, fused=True)
 torch.cuda.synchronize()
 lib.impnn_debug_set_stamp_buffer(None, 0)
-st = buf.cpu().numpy().reshape(nwg, 8).astype(np.uint64)
+st = buf.cpu().numpy().reshape(nwg, 16).astype(np.uint64)
 live = st[:, 7] != 0
 st = st[live]
 R = (st[:, 6] >> np.uint64(32)).astype(np.int64)
@@ -55,6 +55,11 @@ print(f"kernel span {span} ticks; sum of chunk totals / 256 CUs = {tot.sum() / 2
 tiles = np.ceil(R / 16)
 ideal = tiles * 224 * 32 / 4  # MFMA-bound cycles per step for the chunk (4 SIMDs)
 print(f"ideal MFMA cycles per step per chunk {ideal.mean():.0f} vs measured step mean {np.mean([x.mean() for x in steps]):.0f}")
+ph = t[:, 8:16]
+names = ["h load+deg", "gather", "msg mfma", "gates mfma+sigmoid", "cand mfma", "tanh+LN+store"]
+print("wave0 tile0 phases (cycles): " + "  ".join(f"{n} {(ph[:, i + 1] - ph[:, i]).mean():.0f}" for i, n in enumerate(names))
+      + f"  tile total {(ph[:, 5] - ph[:, 0]).mean():.0f}")
+print(f"wave0 done -> barrier released: {(ph[:, 7] - ph[:, 6]).mean():.0f} cycles (wave 0 waits for the slowest wave)")
 ends = np.sort(t[:, 7] - t0)
 starts = np.sort(t[:, 0] - t0)
 print("start percentiles", np.percentile(starts, [0, 25, 50, 75, 100]).astype(int))
