@@ -195,7 +195,7 @@ def test_auto_mode_uses_static_range_bound():
     pc, _ = m.encode_pooled(to_dev(inp), fused=True)
     assert_close(pc.cpu().numpy(), ref, what="exact-mode fallback")
     huge = dict(w)
-    huge["cat_bmm_0/bond_transform"] = w["cat_bmm_0/bond_transform"] * 2000.0   # |W|*256 > fp16 max
+    huge["cat_bmm_0/bond_transform"] = w["cat_bmm_0/bond_transform"] * 1.0e4   # |W|*256 > fp16 max
     m.load_weights(huge)
     assert m._packed_weights() is not None and m._split_deg_limit == 0.0 and m.resolve_encoder_mode(1) == "f32"
 
