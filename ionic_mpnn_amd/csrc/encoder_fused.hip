@@ -78,6 +78,7 @@ __host__ __device__ constexpr int feat_of(int q, int j) { return 16 * (j >> 2) +
 // register prefetch is kPf unconditional 16-byte loads per thread (no per-load branch / wait).
 constexpr int kPf = 4;
 constexpr int kImgSlot = kPf * kThreads * 4;  // 16384 floats = 64 KiB >= img_floats(8) = 15904
+static_assert(kThreads == 4 * kRCap, "prologue maps 4 threads to a row");
 static_assert(img_floats(kKMax) <= kImgSlot, "weight image does not fit its slot");
 static_assert(img16_vec_float_off(kKMax) + img_vec_floats() <= kImgSlot, "split weight image does not fit");
 
@@ -346,6 +347,13 @@ __device__ __forceinline__ float fast_sigmoid(float x) {
 __device__ __forceinline__ float fast_tanh(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177793f * x));
 }
+// the same on an accumulator that carries the mode-1 scale kAcc (the division is folded into the constant)
+__device__ __forceinline__ float fast_sigmoid_scaled(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((-1.44269504088896f / kAcc) * x));
+}
+__device__ __forceinline__ float fast_tanh_scaled(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((2.88539008177793f / kAcc) * x));
+}
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
@@ -357,7 +365,8 @@ struct Lds {
   float* hbuf0;      // kRCap*kHS
   float* hbuf1;      // kRCap*kHS
   float* tb;         // kTbCapFloats (row stride 8)
-  uint32_t* ent;     // kECap
+  uint32_t* ent;     // kECap : in-edge lists, edge-slot order
+  uint32_t* ent2;    // kECap : fill order (before the per-row sort)
   int32_t* rowptr;   // kRCap+4 : CSR over PLACED rows
   int32_t* cursor;   // kRCap   : fill cursors (placed rows)
   int32_t* cnt;      // kRCap   : in-degree per LOGICAL row
@@ -372,7 +381,7 @@ struct Lds {
 
 __host__ __device__ inline size_t lds_bytes(int K) {
   (void)K;
-  return sizeof(float) * ((size_t)kImgSlot + 2 * kRCap * kHS + kTbCapFloats) + sizeof(uint32_t) * kECap +
+  return sizeof(float) * ((size_t)kImgSlot + 2 * kRCap * kHS + kTbCapFloats) + sizeof(uint32_t) * 2 * kECap +
          sizeof(int32_t) * ((kRCap + 4) + 5 * kRCap + (kRCap + 4) + 16 + 48 + 32);
 }
 
@@ -380,19 +389,33 @@ struct H8 {
   half8 hi, lo;
 };
 // v (already scaled into fp16 range) = hi + lo, both rounded toward zero: 2 VALU ops per value
+// (one v_cvt_pkrtz per pair for hi, one v_fma_mix_f32 per value for the exact residual v - hi,
+// one v_cvt_pkrtz per pair for lo).
 __device__ __forceinline__ H8 split8(const float* v) {
-  H8 r;
+  typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+  union U {
+    h2_t h;
+    unsigned u;
+  };
+  union {
+    half8 v8;
+    unsigned u[4];
+  } hi, lo;
 #pragma unroll
   for (int pr = 0; pr < 4; ++pr) {
-    const auto h2 = __builtin_amdgcn_cvt_pkrtz(v[2 * pr], v[2 * pr + 1]);
-    const float r0 = __builtin_fmaf((float)h2[0], -1.0f, v[2 * pr]);
-    const float r1 = __builtin_fmaf((float)h2[1], -1.0f, v[2 * pr + 1]);
-    const auto l2 = __builtin_amdgcn_cvt_pkrtz(r0, r1);
-    r.hi[2 * pr] = h2[0];
-    r.hi[2 * pr + 1] = h2[1];
-    r.lo[2 * pr] = l2[0];
-    r.lo[2 * pr + 1] = l2[1];
+    U h2;
+    h2.h = __builtin_amdgcn_cvt_pkrtz(v[2 * pr], v[2 * pr + 1]);
+    float r0, r1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(h2.u), "v"(v[2 * pr]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(h2.u), "v"(v[2 * pr + 1]));
+    U l2;
+    l2.h = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+    hi.u[pr] = h2.u;
+    lo.u[pr] = l2.u;
   }
+  H8 r;
+  r.hi = hi.v8;
+  r.lo = lo.v8;
   return r;
 }
 __device__ __forceinline__ H8 split8(f32x4 a, f32x4 b) {
@@ -403,12 +426,13 @@ __device__ __forceinline__ half8 ldh8(const _Float16* p) { return *reinterpret_c
 __device__ __forceinline__ f32x4 mfma16(half8 a, half8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
-// acc += A * (b.hi + b.lo) with A = ah + al, dropping al*b.lo (2^-22 relative)
-__device__ __forceinline__ void mma3(f32x4& main, f32x4& corr, const _Float16* blk, int lane, const H8& b) {
+// acc += A * (b.hi + b.lo) with A = ah + al, dropping al*b.lo (2^-22 relative).  The two correction
+// products go into the same f32 accumulator (callers interleave >= 2 independent accumulators).
+__device__ __forceinline__ void mma3(f32x4& acc, const _Float16* blk, int lane, const H8& b) {
   const half8 ah = ldh8(blk + lane * 8), al = ldh8(blk + 512 + lane * 8);
-  main = mfma16(ah, b.hi, main);
-  corr = mfma16(ah, b.lo, corr);
-  corr = mfma16(al, b.hi, corr);
+  acc = mfma16(ah, b.hi, acc);
+  acc = mfma16(ah, b.lo, acc);
+  acc = mfma16(al, b.hi, acc);
 }
 
 // KT = compile-time bond_dim (0: run-time K <= 8); SPLIT: mode 1 (fp16 hi/lo products)
@@ -424,6 +448,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
     L.hbuf1 = f; f += kRCap * kHS;
     L.tb = f; f += kTbCapFloats;
     L.ent = reinterpret_cast<uint32_t*>(f); f += kECap;
+    L.ent2 = reinterpret_cast<uint32_t*>(f); f += kECap;
     L.rowptr = reinterpret_cast<int32_t*>(f); f += kRCap + 4;
     L.cursor = reinterpret_cast<int32_t*>(f); f += kRCap;
     L.cnt = reinterpret_cast<int32_t*>(f); f += kRCap;
@@ -457,12 +482,24 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
   const float* img_g = p.img + (int64_t)g * (p.S > 0 ? p.S : 1) * kImgSlot;
 
   // ---- prologue ------------------------------------------------------------------------
-  // P0: chunk tables; the step-0 weight image starts its flight into registers
+  // P0: chunk tables; the step-0 weight image and this thread's first edge slot start their flight
   f32x4 pf[kPf];
   if (p.S > 0) {
 #pragma unroll
     for (int i = 0; i < kPf; ++i) pf[i] = ld4(img_g + 4 * (tid + i * kThreads));
   }
+  const int n_slots = M * E;
+  // edge slot owned by this thread in the first pass (slots beyond kThreads are re-read in loops)
+  int s_m = 0, s_e = 0, s_bid = -1;
+  int2 s_st = make_int2(0, 0);
+  if (tid < n_slots) {
+    s_m = tid / E;
+    s_e = tid - s_m * E;
+    const int64_t b = m0 + s_m;
+    s_st = *reinterpret_cast<const int2*>(conn_g + (b * E + s_e) * 2);
+    s_bid = bond_g[b * E + s_e];
+  }
+  const bool s_valid = tid < n_slots && edge_valid(s_st.x, s_st.y, s_bid, N, p.Vb);
   for (int m = tid; m <= M; m += kThreads) {
     L.moloff[m] = start[m0 + m] - base;
     if (m < M) L.molrows[m] = rows_g[m0 + m];
@@ -476,17 +513,18 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
   if (tid < 16) L.tilemax[tid] = 0;
   __syncthreads();
 
-  // P1: in-degree of every logical row (edge-parallel, coalesced reads of conn / bond ids);
-  //     logical row -> (molecule, n, id>0)
-  const int n_slots = M * E;
-  for (int slot = tid; slot < n_slots; slot += kThreads) {
+  // P1: in-degree of every logical row (edge-parallel); logical row -> (molecule, n, id>0);
+  //     h0 rows (train_viscosity.py:171) start their flight: 4 threads per row, 2 x 16 B each
+  if (s_valid) atomicAdd(&L.cnt[L.moloff[s_m] + s_st.y], 1);
+  for (int slot = tid + kThreads; slot < n_slots; slot += kThreads) {
     const int m = slot / E, e = slot - m * E;
     const int64_t b = m0 + m;
     const int2 st = *reinterpret_cast<const int2*>(conn_g + (b * E + e) * 2);
     if (edge_valid(st.x, st.y, bond_g[b * E + e], N, p.Vb)) atomicAdd(&L.cnt[L.moloff[m] + st.y], 1);
   }
-  if (tid < kRCap) {
-    const int row = tid;
+  f32x4 hv0 = {0.f, 0.f, 0.f, 0.f}, hv1 = hv0;
+  {
+    const int row = tid >> 2, sub = tid & 3;  // kThreads == 4 * kRCap
     int info = -1;
     if (row < R) {
       int lo = 0, hi = M - 1;  // largest m with moloff[m] <= row
@@ -498,9 +536,13 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
       if (n < L.molrows[lo]) {
         const int id = ids_g[(int64_t)(m0 + lo) * N + n];
         info = (lo << 16) | (id > 0 ? 0x8000 : 0) | n;
+        if ((unsigned)id < (unsigned)p.Va) {
+          hv0 = ld4(p.atom_table + (int64_t)id * kD + 8 * sub);
+          hv1 = ld4(p.atom_table + (int64_t)id * kD + 8 * sub + 4);
+        }
       }
     }
-    L.rowinfo[row] = info;
+    if (sub == 0) L.rowinfo[row] = info;
   }
   __syncthreads();
 
@@ -511,19 +553,20 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
   int my_bin = 0, my_deg = 0;
   if (tid < kRCap) {
     my_deg = L.cnt[tid];
-    my_bin = tid >= R ? 0 : (my_deg >= 16 ? 1 : 17 - my_deg);  // bin 0 = beyond chunk ... 17 = degree 0
-    // bins are laid out so that ascending bin index = placement order, except bin 0 which goes last
+    my_bin = tid >= R ? 0 : (my_deg >= 16 ? 1 : 17 - my_deg);  // bin 0 = beyond chunk (placed last) ... 17 = degree 0
     atomicAdd(&L.bins[my_bin], 1);
   }
   __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int bI = 1; bI < kDegBins; ++bI) {
-      const int t = L.bins[bI];
-      L.bins[24 + bI] = run;
-      run += t;
+  if (wave == 0) {  // exclusive scan of bins 1..17, then bin 0
+    const int bidx = lane < kDegBins ? (lane == kDegBins - 1 ? 0 : lane + 1) : 0;  // placement order
+    const int v = lane < kDegBins ? L.bins[bidx] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
     }
-    L.bins[24] = run;  // rows beyond the chunk go last
+    if (lane < kDegBins) L.bins[24 + bidx] = incl - v;
   }
   __syncthreads();
   if (tid < kRCap) {
@@ -558,7 +601,12 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
 
   // P4: fill.  entry = edge slot (16b) | bond id (8b) | placed source row (8b); the slot in the
   //     top bits lets P5 restore edge-slot order, so the accumulation order is fixed run to run.
-  for (int slot = tid; slot < n_slots; slot += kThreads) {
+  if (s_valid) {
+    const int mo = L.moloff[s_m];
+    const int pos = atomicAdd(&L.cursor[L.place[mo + s_st.y]], 1);
+    L.ent2[pos] = ((uint32_t)s_e << 16) | ((uint32_t)s_bid << 8) | (uint32_t)L.place[mo + s_st.x];
+  }
+  for (int slot = tid + kThreads; slot < n_slots; slot += kThreads) {
     const int m = slot / E, e = slot - m * E;
     const int64_t b = m0 + m;
     const int2 st = *reinterpret_cast<const int2*>(conn_g + (b * E + e) * 2);
@@ -566,22 +614,16 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
     if (edge_valid(st.x, st.y, bid, N, p.Vb)) {
       const int mo = L.moloff[m];
       const int pos = atomicAdd(&L.cursor[L.place[mo + st.y]], 1);
-      L.ent[pos] = ((uint32_t)e << 16) | ((uint32_t)bid << 8) | (uint32_t)L.place[mo + st.x];
+      L.ent2[pos] = ((uint32_t)e << 16) | ((uint32_t)bid << 8) | (uint32_t)L.place[mo + st.x];
     }
   }
-  // h0 = atom_table[atom_ids]  (train_viscosity.py:171); slack rows = 0 in both buffers
-  for (int t = tid; t < kRCap * 8; t += kThreads) {
-    const int row = t >> 3, part = t & 7;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    const int info = L.rowinfo[row];
-    if (info >= 0) {
-      const int m = info >> 16, n = info & 0x7fff;
-      const int id = ids_g[(int64_t)(m0 + m) * N + n];
-      if ((unsigned)id < (unsigned)p.Va) v = ld4(p.atom_table + (int64_t)id * kD + 4 * part);
-    }
+  {  // h0 -> both LDS buffers at the row's placed position (slack rows: zeros)
+    const int row = tid >> 2, sub = tid & 3;
     const int pr = L.place[row];
-    st4(L.hbuf0 + pr * kHS + 4 * part, v);
-    st4(L.hbuf1 + pr * kHS + 4 * part, v);
+    st4(L.hbuf0 + pr * kHS + 8 * sub, hv0);
+    st4(L.hbuf0 + pr * kHS + 8 * sub + 4, hv1);
+    st4(L.hbuf1 + pr * kHS + 8 * sub, hv0);
+    st4(L.hbuf1 + pr * kHS + 8 * sub + 4, hv1);
   }
   if (p.S > 0) {
 #pragma unroll
@@ -589,17 +631,14 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
   }
   __syncthreads();
 
-  // P5: sort every row's in-edge list by edge slot (lists are short: insertion sort)
+  // P5: every row's in-edge list in edge-slot order: rank sort ent2 -> ent (lists are short)
   if (tid < kRCap) {
     const int lo = L.rowptr[tid], hi = L.rowptr[tid + 1];
-    for (int i = lo + 1; i < hi; ++i) {
-      const uint32_t v = L.ent[i];
-      int j = i - 1;
-      while (j >= lo && L.ent[j] > v) {
-        L.ent[j + 1] = L.ent[j];
-        --j;
-      }
-      L.ent[j + 1] = v;
+    for (int i = lo; i < hi; ++i) {
+      const uint32_t v = L.ent2[i];
+      int rank = 0;
+      for (int j = lo; j < hi; ++j) rank += L.ent2[j] < v;
+      L.ent[lo + rank] = v;
     }
   }
   __syncthreads();
@@ -688,20 +727,19 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
       // ---- agg^T = sum_k W_k * G_k   (models/layers.py:108-112 + 78-82, reassociated)
       f32x4 agg0 = {0.f, 0.f, 0.f, 0.f}, agg1 = {0.f, 0.f, 0.f, 0.f};
       if constexpr (SPLIT) {
-        f32x4 c0 = agg0, c1 = agg0;
 #pragma unroll
         for (int k = 0; k < kKMax; ++k) {
           if (k < K) {
             const H8 g = split8(G[k]);
-            mma3(agg0, c0, hmsg + (k * 2 + 0) * 1024, lane, g);
-            mma3(agg1, c1, hmsg + (k * 2 + 1) * 1024, lane, g);
+            mma3(agg0, hmsg + (k * 2 + 0) * 1024, lane, g);
+            mma3(agg1, hmsg + (k * 2 + 1) * 1024, lane, g);
           }
         }
         // accumulators carry kAcc; keep agg as agg*kSX: the B-operand scale of the next GEMMs
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          agg0[i] = (agg0[i] + c0[i]) * (kSX / kAcc);
-          agg1[i] = (agg1[i] + c1[i]) * (kSX / kAcc);
+          agg0[i] *= (kSX / kAcc);
+          agg1[i] *= (kSX / kAcc);
         }
       } else {
 #pragma unroll
@@ -742,36 +780,29 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
         }
         const H8 sh = split8(hs0, hs1);
         const H8 sa = split8(agg0, agg1);
-        f32x4 cz0 = {0.f, 0.f, 0.f, 0.f}, cz1 = cz0, cr0 = cz0, cr1 = cz0;
         // block index = ((gate*2 + T)*2 + half), 1024 halfs each
-        mma3(z0, cz0, hupd + ((0 * 2 + 0) * 2 + 0) * 1024, lane, sh);
-        mma3(z1, cz1, hupd + ((0 * 2 + 1) * 2 + 0) * 1024, lane, sh);
-        mma3(r0, cr0, hupd + ((1 * 2 + 0) * 2 + 0) * 1024, lane, sh);
-        mma3(r1, cr1, hupd + ((1 * 2 + 1) * 2 + 0) * 1024, lane, sh);
-        mma3(z0, cz0, hupd + ((0 * 2 + 0) * 2 + 1) * 1024, lane, sa);
-        mma3(z1, cz1, hupd + ((0 * 2 + 1) * 2 + 1) * 1024, lane, sa);
-        mma3(r0, cr0, hupd + ((1 * 2 + 0) * 2 + 1) * 1024, lane, sa);
-        mma3(r1, cr1, hupd + ((1 * 2 + 1) * 2 + 1) * 1024, lane, sa);
+        mma3(z0, hupd + ((0 * 2 + 0) * 2 + 0) * 1024, lane, sh);
+        mma3(z1, hupd + ((0 * 2 + 1) * 2 + 0) * 1024, lane, sh);
+        mma3(r0, hupd + ((1 * 2 + 0) * 2 + 0) * 1024, lane, sh);
+        mma3(r1, hupd + ((1 * 2 + 1) * 2 + 0) * 1024, lane, sh);
+        mma3(z0, hupd + ((0 * 2 + 0) * 2 + 1) * 1024, lane, sa);
+        mma3(z1, hupd + ((0 * 2 + 1) * 2 + 1) * 1024, lane, sa);
+        mma3(r0, hupd + ((1 * 2 + 0) * 2 + 1) * 1024, lane, sa);
+        mma3(r1, hupd + ((1 * 2 + 1) * 2 + 1) * 1024, lane, sa);
         if (tstamp && lane == 0) stamp[11] = __builtin_amdgcn_s_memtime();
         f32x4 rs0, rs1;  // sigmoid(r) * h * kSX
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          z0[i] = fast_sigmoid((z0[i] + cz0[i]) * (1.0f / kAcc));
-          z1[i] = fast_sigmoid((z1[i] + cz1[i]) * (1.0f / kAcc));
-          rs0[i] = fast_sigmoid((r0[i] + cr0[i]) * (1.0f / kAcc)) * hs0[i];  // :149
-          rs1[i] = fast_sigmoid((r1[i] + cr1[i]) * (1.0f / kAcc)) * hs1[i];
+          z0[i] = fast_sigmoid_scaled(z0[i]);  // accumulators carry kAcc: folded into the exp2 constant
+          z1[i] = fast_sigmoid_scaled(z1[i]);
+          rs0[i] = fast_sigmoid_scaled(r0[i]) * hs0[i];  // :149
+          rs1[i] = fast_sigmoid_scaled(r1[i]) * hs1[i];
         }
         const H8 srh = split8(rs0, rs1);
-        f32x4 ct0 = {0.f, 0.f, 0.f, 0.f}, ct1 = ct0;
-        mma3(t0, ct0, hupd + ((2 * 2 + 0) * 2 + 0) * 1024, lane, srh);
-        mma3(t1, ct1, hupd + ((2 * 2 + 1) * 2 + 0) * 1024, lane, srh);
-        mma3(t0, ct0, hupd + ((2 * 2 + 0) * 2 + 1) * 1024, lane, sa);
-        mma3(t1, ct1, hupd + ((2 * 2 + 1) * 2 + 1) * 1024, lane, sa);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          t0[i] = (t0[i] + ct0[i]) * (1.0f / kAcc);
-          t1[i] = (t1[i] + ct1[i]) * (1.0f / kAcc);
-        }
+        mma3(t0, hupd + ((2 * 2 + 0) * 2 + 0) * 1024, lane, srh);
+        mma3(t1, hupd + ((2 * 2 + 1) * 2 + 0) * 1024, lane, srh);
+        mma3(t0, hupd + ((2 * 2 + 0) * 2 + 1) * 1024, lane, sa);
+        mma3(t1, hupd + ((2 * 2 + 1) * 2 + 1) * 1024, lane, sa);
       } else {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -822,8 +853,9 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
       float sum = 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        n0[i] = (1.0f - z0[i]) * h0[i] + z0[i] * fast_tanh(t0[i]);
-        n1[i] = (1.0f - z1[i]) * h1[i] + z1[i] * fast_tanh(t1[i]);
+        // (1-z) h + z t == h + z (t - h)
+        n0[i] = fmaf(z0[i], (SPLIT ? fast_tanh_scaled(t0[i]) : fast_tanh(t0[i])) - h0[i], h0[i]);
+        n1[i] = fmaf(z1[i], (SPLIT ? fast_tanh_scaled(t1[i]) : fast_tanh(t1[i])) - h1[i], h1[i]);
         sum += n0[i] + n1[i];
       }
       sum += __shfl_xor(sum, 16);
@@ -866,22 +898,25 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
   }
 
   // ---- GlobalSumPool (models/layers.py:161-164): rows whose atom id > 0.  Four lanes share one
-  //      (molecule, feature): each sums every 4th row in ascending order, then a fixed 2-step
+  //      (molecule, 4 features): each sums every 4th row in ascending order, then a fixed 2-step
   //      butterfly - a wavefront segmented reduction with a run-to-run fixed order.
   const float* hfin = (p.S & 1) ? L.hbuf1 : L.hbuf0;
   float* out_g = p.pooled[g];
-  for (int t0 = 0; t0 < M * kD * 4; t0 += kThreads) {
+  for (int t0 = 0; t0 < M * 32; t0 += kThreads) {
     const int t = t0 + tid;
-    const int part = t & 3, f = (t >> 2) & 31, m = t >> 7;
-    float acc = 0.f;
+    const int part = t & 3, f4 = (t >> 2) & 7, m = t >> 5;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (m < M) {
       const int nr = L.molrows[m], mo = L.moloff[m];
       for (int n = part; n < nr; n += 4)
-        if (L.rowinfo[mo + n] & 0x8000) acc += hfin[L.place[mo + n] * kHS + f];
+        if (L.rowinfo[mo + n] & 0x8000) acc += ld4(hfin + L.place[mo + n] * kHS + 4 * f4);
     }
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
-    if (m < M && part == 0) out_g[(int64_t)(m0 + m) * kD + f] = acc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[i] += __shfl_xor(acc[i], 1);
+      acc[i] += __shfl_xor(acc[i], 2);
+    }
+    if (m < M && part == 0) st4(out_g + (int64_t)(m0 + m) * kD + 4 * f4, acc);
   }
   if (stamp && tid == 0) {
     stamp[7] = __builtin_amdgcn_s_memtime();
