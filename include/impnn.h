@@ -128,6 +128,24 @@ int impnn_encoder_fused(int32_t n_ions, const int32_t* const* atom_ids,
                         int32_t E, int32_t D, int32_t K, int32_t S, float ln_eps, void* workspace,
                         size_t workspace_bytes, impnn_stream_t stream);
 
+/* ---- a9 with weights prepared once.  The kernel-side weight image (transposed / padded f32 for
+ *      mode 0, pre-split fp16 hi/lo blocks for mode 1) depends on the weights only, so a caller
+ *      whose weights are fixed between calls (inference; every step of an epoch's evaluation) builds
+ *      it once per ion and per mode and passes it to impnn_encoder_fused_prepared, which then
+ *      launches only the two plan kernels and the encoder.  impnn_encoder_fused (above) takes the
+ *      canonical weights and rebuilds the image in the workspace on every call (training).
+ *      `prepared`: device buffer of impnn_encoder_prepared_bytes(S) bytes, 16B aligned. */
+size_t impnn_encoder_prepared_bytes(int32_t S);
+int impnn_encoder_prepare_weights(const float* weights, int32_t D, int32_t K, int32_t S, int32_t mode,
+                                  void* prepared, size_t prepared_bytes, impnn_stream_t stream);
+int impnn_encoder_fused_prepared(int32_t n_ions, const int32_t* const* atom_ids,
+                                 const int32_t* const* bond_ids, const int32_t* const* conn,
+                                 const float* atom_table, int32_t Va, const float* bond_table,
+                                 int32_t Vb, const void* const* prepared, int32_t mode,
+                                 float* const* pooled, int32_t B, int32_t N, int32_t E, int32_t D,
+                                 int32_t K, int32_t S, float ln_eps, void* workspace,
+                                 size_t workspace_bytes, impnn_stream_t stream);
+
 /* ---- measurement: HIP-event timing of the dominant kernel (encoder_fused_kernel), recorded on the
  *      stream the kernel is launched on.  After impnn_profile_enable(capacity) every
  *      impnn_encoder_fused call of this thread records one (start, stop) event pair around that
@@ -138,10 +156,10 @@ int impnn_profile_enable(int32_t capacity);
 int impnn_profile_collect(float* ms_out, int32_t max_n, int32_t* n_out);
 int impnn_profile_disable(void);
 
-/* ---- diagnostics: when a device buffer of >= 128 bytes per encoder workgroup is set, the encoder
+/* ---- diagnostics: when a device buffer of >= 256 bytes per encoder workgroup is set, the encoder
  *      kernel's lane 0 writes s_memtime stamps into it (entry, after prologue, after each of the
  *      first 5 steps, exit, and the phase boundaries of wave 0's first tile in one step) -
- *      16 uint64 per workgroup.  NULL (the default) disables it; with NULL
+ *      32 uint64 per workgroup.  NULL (the default) disables it; with NULL
  *      no stamp instruction executes.  Never set during a timed run. */
 int impnn_debug_set_stamp_buffer(void* device_buffer, size_t bytes);
 

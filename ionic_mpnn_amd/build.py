@@ -51,6 +51,19 @@ def build_library(force=False, verbose=True, extra_flags=()):
     return LIB
 
 
+
+
+def build_variant(out_path, src_dir=None, extra_flags=()):
+    """One-shot build of a library variant (for tools/ab_bench.py) from src_dir (default: csrc)."""
+    src_dir = Path(src_dir) if src_dir else CSRC
+    out_path = Path(out_path)
+    out_path.parent.mkdir(parents=True, exist_ok=True)
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", str(out_path),
+           *[str(src_dir / s) for s in SOURCES], *extra_flags]
+    subprocess.run(cmd, check=True)
+    return out_path
+
+
 if __name__ == "__main__":
     build_library(force="--force" in sys.argv)
     print(LIB)

@@ -159,29 +159,38 @@ int impnn_encoder_workspace_bytes(int32_t n_ions, int32_t B, int32_t N, int32_t 
   return IMPNN_OK;
 }
 
-int impnn_encoder_fused(int32_t n_ions, const int32_t* const* atom_ids, const int32_t* const* bond_ids,
-                        const int32_t* const* conn, const float* atom_table, int32_t Va,
-                        const float* bond_table, int32_t Vb, const float* const* weights,
-                        float* const* pooled, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K, int32_t S,
-                        float ln_eps, void* workspace, size_t workspace_bytes, impnn_stream_t stream) {
-  REQUIRE(n_ions >= 1 && n_ions <= 2, "n_ions must be 1 or 2");
-  REQUIRE(B >= 0 && N > 0 && E >= 0 && D > 0 && K > 0 && S >= 0 && Va > 0 && Vb > 0, "bad shape");
-  REQUIRE(atom_ids && bond_ids && conn && weights && pooled && atom_table && bond_table, "null pointer");
+static int encoder_common(const char* fn, int32_t n_ions, const int32_t* const* atom_ids,
+                          const int32_t* const* bond_ids, const int32_t* const* conn, const float* atom_table,
+                          int32_t Va, const float* bond_table, int32_t Vb, const float* const* weights,
+                          const void* const* prepared, int32_t mode, float* const* pooled, int32_t B, int32_t N,
+                          int32_t E, int32_t D, int32_t K, int32_t S, float ln_eps, void* workspace,
+                          size_t workspace_bytes, impnn_stream_t stream) {
+#define REQ(cond, what)                                           \
+  do {                                                            \
+    if (!(cond)) return fail(IMPNN_E_BADARG, "%s: %s", fn, what); \
+  } while (0)
+  REQ(n_ions >= 1 && n_ions <= 2, "n_ions must be 1 or 2");
+  REQ(mode == 0 || mode == 1, "mode must be 0 (f32) or 1 (f16x2)");
+  REQ(B >= 0 && N > 0 && E >= 0 && D > 0 && K > 0 && S >= 0 && Va > 0 && Vb > 0, "bad shape");
+  REQ(atom_ids && bond_ids && conn && (weights || prepared) && pooled && atom_table && bond_table, "null pointer");
   if (!encoder_fused_supported(N, E, D, K, S, Vb))
     return fail(IMPNN_E_UNSUPPORTED, "encoder_fused: shape N=%d E=%d D=%d K=%d S=%d Vb=%d not covered", N, E, D,
                 K, S, Vb);
   if (B == 0) return IMPNN_OK;
   EncoderArgs a{};
   a.n_ions = n_ions;
+  a.mode = mode;
   for (int g = 0; g < n_ions; ++g) {
-    REQUIRE(atom_ids[g] && pooled[g] && (E == 0 || (bond_ids[g] && conn[g])) && (S == 0 || weights[g]),
-            "null per-ion pointer");
+    const bool have_w = S == 0 || (prepared && prepared[g]) || (weights && weights[g]);
+    REQ(atom_ids[g] && pooled[g] && (E == 0 || (bond_ids[g] && conn[g])) && have_w, "null per-ion pointer");
     a.atom_ids[g] = atom_ids[g];
     a.bond_ids[g] = bond_ids[g];
     a.conn[g] = conn[g];
-    a.weights[g] = weights[g];
+    a.weights[g] = weights ? weights[g] : nullptr;
+    a.prepared[g] = prepared ? prepared[g] : nullptr;
     a.pooled[g] = pooled[g];
   }
+#undef REQ
   a.atom_table = atom_table;
   a.bond_table = bond_table;
   a.Va = Va; a.Vb = Vb; a.B = B; a.N = N; a.E = E; a.D = D; a.K = K; a.S = S;
@@ -190,8 +199,44 @@ int impnn_encoder_fused(int32_t n_ions, const int32_t* const* atom_ids, const in
   a.workspace_bytes = workspace_bytes;
   const size_t need = encoder_fused_workspace_bytes(n_ions, B, N, E, D, K, S, Vb);
   if (need > 0 && (!workspace || workspace_bytes < need))
-    return fail(IMPNN_E_WORKSPACE, "encoder_fused: workspace %zu < %zu bytes", workspace_bytes, need);
+    return fail(IMPNN_E_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, workspace_bytes, need);
   return launch_encoder_fused(a, as_stream(stream));
+}
+
+int impnn_encoder_fused(int32_t n_ions, const int32_t* const* atom_ids, const int32_t* const* bond_ids,
+                        const int32_t* const* conn, const float* atom_table, int32_t Va,
+                        const float* bond_table, int32_t Vb, const float* const* weights,
+                        float* const* pooled, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K, int32_t S,
+                        float ln_eps, void* workspace, size_t workspace_bytes, impnn_stream_t stream) {
+  return encoder_common(__func__, n_ions, atom_ids, bond_ids, conn, atom_table, Va, bond_table, Vb, weights, nullptr,
+                        encoder_mode(), pooled, B, N, E, D, K, S, ln_eps, workspace, workspace_bytes, stream);
+}
+
+size_t impnn_encoder_prepared_bytes(int32_t S) { return encoder_prepared_bytes(S); }
+
+int impnn_encoder_prepare_weights(const float* weights, int32_t D, int32_t K, int32_t S, int32_t mode,
+                                  void* prepared, size_t prepared_bytes, impnn_stream_t stream) {
+  REQUIRE(D > 0 && K > 0 && S >= 0, "bad shape");
+  REQUIRE(mode == 0 || mode == 1, "mode must be 0 (f32) or 1 (f16x2)");
+  if (!encoder_fused_supported(1, 0, D, K, S, 1))
+    return fail(IMPNN_E_UNSUPPORTED, "encoder_prepare_weights: D=%d K=%d not covered", D, K);
+  if (S == 0) return IMPNN_OK;
+  REQUIRE(weights && prepared, "null pointer");
+  REQUIRE(aligned16(prepared), "prepared buffer must be 16B aligned");
+  if (prepared_bytes < encoder_prepared_bytes(S))
+    return fail(IMPNN_E_WORKSPACE, "encoder_prepare_weights: buffer %zu < %zu bytes", prepared_bytes,
+                encoder_prepared_bytes(S));
+  return launch_encoder_prepare(weights, D, K, S, mode, prepared, as_stream(stream));
+}
+
+int impnn_encoder_fused_prepared(int32_t n_ions, const int32_t* const* atom_ids, const int32_t* const* bond_ids,
+                                 const int32_t* const* conn, const float* atom_table, int32_t Va,
+                                 const float* bond_table, int32_t Vb, const void* const* prepared, int32_t mode,
+                                 float* const* pooled, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K,
+                                 int32_t S, float ln_eps, void* workspace, size_t workspace_bytes,
+                                 impnn_stream_t stream) {
+  return encoder_common(__func__, n_ions, atom_ids, bond_ids, conn, atom_table, Va, bond_table, Vb, nullptr, prepared,
+                        mode, pooled, B, N, E, D, K, S, ln_eps, workspace, workspace_bytes, stream);
 }
 
 int impnn_profile_enable(int32_t capacity) {

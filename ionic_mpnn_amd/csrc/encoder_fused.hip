@@ -38,6 +38,13 @@
 // Three launches per call: plan_stats (+ weight image prep), plan_scan, encoder_fused.
 #include "common.h"
 
+#ifndef IMPNN_OPT_PF_LATE
+#define IMPNN_OPT_PF_LATE 1
+#endif
+#ifndef IMPNN_OPT_PSORT
+#define IMPNN_OPT_PSORT 1
+#endif
+
 namespace impnn {
 
 namespace {
@@ -84,7 +91,7 @@ static_assert(img16_vec_float_off(kKMax) + img_vec_floats() <= kImgSlot, "split 
 
 // workspace layout (bytes, all 256-aligned sections)
 struct Ws {
-  size_t img_off, rows_off, vr_off, start_off, first_off, nchunks_off, total;
+  size_t img_off, rows_off, vr_off, start_off, first_off, nchunks_off, desc_off, total;
   int ub;  // upper bound of chunks per ion
 };
 
@@ -114,6 +121,8 @@ __host__ inline Ws ws_layout(int n_ions, int B, int N, int E, int K, int S) {
   off = align_up(off + (size_t)n_ions * (w.ub + 2) * sizeof(int32_t), 256);
   w.nchunks_off = off;
   off = align_up(off + 2 * sizeof(int32_t), 256);
+  w.desc_off = off;
+  off = align_up(off + (size_t)n_ions * w.ub * 4 * sizeof(int32_t), 256);
   w.total = off;
   return w;
 }
@@ -122,17 +131,13 @@ struct PlanParams {
   const int32_t* atom_ids[2];
   const int32_t* bond_ids[2];
   const int32_t* conn[2];
-  const float* weights[2];
-  float* img;      // [n_ions][S][kImgSlot]
   int32_t* rows;   // [n_ions][B]
   int32_t* vr;     // [n_ions][B]
   int32_t* start;  // [n_ions][B+1]
   int32_t* first;  // [n_ions][ub+2]
   int32_t* nchunks;  // [2]
+  int32_t* desc;     // [n_ions][ub][4] = {first molecule, molecules, first virtual row, rows}; zeros if empty
   int n_ions, B, N, E, K, S, Vb, win, ub;
-  int mol_blocks;  // blocks of plan_stats that handle molecules
-  int mode;        // 0: f32 image, 1: fp16 hi/lo image
-  int64_t step_floats;
 };
 
 __device__ __forceinline__ int wave_max_i(int v) {
@@ -161,39 +166,74 @@ __device__ __forceinline__ bool edge_valid(int s, int t, int bid, int N, int Vb)
 // -----------------------------------------------------------------------------------------
 __global__ void plan_stats_kernel(PlanParams p) {
   const int lane = threadIdx.x & 63;
-  if ((int)blockIdx.x < p.mol_blocks) {
-    const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (item >= (int64_t)p.n_ions * p.B) return;
-    const int g = (int)(item / p.B);
-    const int b = (int)(item - (int64_t)g * p.B);
-    const int32_t* ids = p.atom_ids[g] + (int64_t)b * p.N;
-    const int32_t* cn = p.conn[g] + (int64_t)b * p.E * 2;
-    const int32_t* bd = p.bond_ids[g] + (int64_t)b * p.E;
-    int rmax = 0, cnt = 0;
-    for (int n = lane; n < p.N; n += 64)
-      if (ids[n] > 0) rmax = n + 1;  // ascending n per lane: last hit is the largest
-    for (int e = lane; e < p.E; e += 64) {
+  const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (item >= (int64_t)p.n_ions * p.B) return;
+  const int g = (int)(item / p.B);
+  const int b = (int)(item - (int64_t)g * p.B);
+  const int32_t* ids = p.atom_ids[g] + (int64_t)b * p.N;
+  const int32_t* cn = p.conn[g] + (int64_t)b * p.E * 2;
+  const int32_t* bd = p.bond_ids[g] + (int64_t)b * p.E;
+  // wave-level reductions through ballots (scalar unit), no cross-lane data movement
+  int rmax = 0, cnt = 0;
+  for (int n0 = 0; n0 < p.N; n0 += 64) {
+    const int n = n0 + lane;
+    const unsigned long long hit = __ballot(n < p.N && ids[n] > 0);
+    if (hit) rmax = n0 + 64 - __builtin_clzll(hit);  // 1 + highest n with ids[n] > 0
+  }
+  int emax = 0;  // largest atom index on a valid edge (lane-local)
+  for (int e0 = 0; e0 < p.E; e0 += 64) {
+    const int e = e0 + lane;
+    bool ok = false;
+    if (e < p.E) {
       const int2 st = *reinterpret_cast<const int2*>(cn + 2 * e);
-      if (edge_valid(st.x, st.y, bd[e], p.N, p.Vb)) {
-        ++cnt;
-        const int m = (st.x > st.y ? st.x : st.y) + 1;
-        rmax = rmax > m ? rmax : m;
+      ok = edge_valid(st.x, st.y, bd[e], p.N, p.Vb);
+      if (ok) {
+        const int m = st.x > st.y ? st.x : st.y;
+        emax = emax > m ? emax : m;
       }
     }
-    rmax = wave_max_i(rmax);
-    cnt = wave_sum_i(cnt);
-    if (lane == 0) {
-      int vr = (cnt + 3) >> 2;
-      vr = vr > rmax ? vr : rmax;
-      vr = vr < 1 ? 1 : vr;
-      p.rows[item] = rmax;
-      p.vr[item] = vr;
+    cnt += __builtin_popcountll(__ballot(ok));
+  }
+  if (cnt > 0) {  // wave max of emax, bit by bit from the top (indices < 65536)
+    bool alive = true;
+    int res = 0;
+#pragma unroll
+    for (int bit = 15; bit >= 0; --bit) {
+      const bool one = alive && ((emax >> bit) & 1);
+      if (__ballot(one)) {
+        res |= 1 << bit;
+        alive = one;
+      }
     }
-  } else {
-    // weight image for (ion g, step s)
-    const int gs = blockIdx.x - p.mol_blocks;
-    const int g = gs / p.S, s = gs - g * p.S;
-    const float* w = p.weights[g] + (int64_t)s * p.step_floats;
+    rmax = rmax > res + 1 ? rmax : res + 1;
+  }
+  if (lane == 0) {
+    int vr = (cnt + 3) >> 2;
+    vr = vr > rmax ? vr : rmax;
+    vr = vr < 1 ? 1 : vr;
+    p.rows[item] = rmax;
+    p.vr[item] = vr;
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// weight_image: canonical packed step weights -> the image the encoder copies verbatim into LDS
+// (mode 0: f32, message rows padded to 36, gate kernels transposed; mode 1: fp16 hi/lo blocks in
+// MFMA A-operand order).  grid = (slices, steps); depends on the weights only, so callers that
+// keep weights fixed run it once (impnn_encoder_prepare_weights).
+// -----------------------------------------------------------------------------------------
+struct ImageParams {
+  const float* weights;  // S steps, canonical layout
+  float* img;            // S slots of kImgSlot floats
+  int K, mode;
+  int64_t step_floats;
+};
+
+__global__ void weight_image_kernel(ImageParams p) {
+  {
+    const int s = blockIdx.y;
+    const int t_begin = blockIdx.x * blockDim.x + threadIdx.x, t_stride = gridDim.x * blockDim.x;
+    const float* w = p.weights + (int64_t)s * p.step_floats;
     const int K = p.K;
     const float* W = w;                                 // (K,32,32)
     const float* Wz = W + (int64_t)K * kD * kD;          // (64,32)
@@ -204,11 +244,11 @@ __global__ void plan_stats_kernel(PlanParams p) {
     const float* bh = Wh + 2 * kD * kD;
     const float* gamma = bh + kD;
     const float* beta = gamma + kD;
-    float* img = p.img + (int64_t)gs * kImgSlot;
+    float* img = p.img + (int64_t)s * kImgSlot;
     if (p.mode == 1) {
       _Float16* hi_lo = reinterpret_cast<_Float16*>(img);
       const int nm = img16_msg_halfs(K), nu = img16_upd_halfs();
-      for (int t = threadIdx.x; t < nm + nu; t += blockDim.x) {
+      for (int t = t_begin; t < nm + nu; t += t_stride) {
         // t = ((blk * 2 + part) * 64 + lane) * 8 + j
         const int j = t & 7, ln = (t >> 3) & 63, part = (t >> 9) & 1;
         const int q = ln >> 4, i = ln & 15, f = feat_of(q, j);
@@ -229,31 +269,31 @@ __global__ void plan_stats_kernel(PlanParams p) {
         hi_lo[t] = part == 0 ? hi : lo;
       }
       float* vec = img + img16_vec_float_off(K);
-      for (int t = threadIdx.x; t < img_vec_floats(); t += blockDim.x) {
+      for (int t = t_begin; t < img_vec_floats(); t += t_stride) {
         const int v = t / kD, i = t - v * kD;
         const float* src = v == 0 ? bz : v == 1 ? br : v == 2 ? bh : v == 3 ? gamma : beta;
         vec[t] = v < 3 ? src[i] * kAcc : src[i];  // biases seed the (scaled) accumulators
       }
-      for (int t = img16_vec_float_off(K) + img_vec_floats() + threadIdx.x; t < kImgSlot; t += blockDim.x) img[t] = 0.f;
+      for (int t = img16_vec_float_off(K) + img_vec_floats() + t_begin; t < kImgSlot; t += t_stride) img[t] = 0.f;
       return;
     }
     const int nmsg = img_msg_floats(K), nupd = img_upd_floats();
-    for (int t = threadIdx.x; t < nmsg; t += blockDim.x) {
+    for (int t = t_begin; t < nmsg; t += t_stride) {
       const int row = t / kMsgRS, j = t - row * kMsgRS;  // row = k*32 + i_out
       img[t] = j < kD ? W[(int64_t)row * kD + j] : 0.f;
     }
-    for (int t = threadIdx.x; t < nupd; t += blockDim.x) {
+    for (int t = t_begin; t < nupd; t += t_stride) {
       const int row = t / kUpdRS, jj = t - row * kUpdRS;  // row = gate*32 + i_out
       const int gate = row / kD, io = row - gate * kD;
       const float* Wg = gate == 0 ? Wz : (gate == 1 ? Wr : Wh);
       img[nmsg + t] = jj < 2 * kD ? Wg[(int64_t)jj * kD + io] : 0.f;
     }
-    for (int t = threadIdx.x; t < img_vec_floats(); t += blockDim.x) {
+    for (int t = t_begin; t < img_vec_floats(); t += t_stride) {
       const int v = t / kD, i = t - v * kD;
       const float* src = v == 0 ? bz : v == 1 ? br : v == 2 ? bh : v == 3 ? gamma : beta;
       img[nmsg + nupd + t] = src[i];
     }
-    for (int t = img_floats(K) + threadIdx.x; t < kImgSlot; t += blockDim.x) img[t] = 0.f;
+    for (int t = img_floats(K) + t_begin; t < kImgSlot; t += t_stride) img[t] = 0.f;
   }
 }
 
@@ -309,12 +349,27 @@ __global__ void plan_scan_kernel(PlanParams p) {
     }
     run += vr[b];
   }
+  const int total = carry_s;
+  const int last_chunk = B > 0 ? (total - vr[B - 1]) / p.win : -1;
   if (threadIdx.x == 0) {
-    const int total = carry_s;
     start[B] = total;
-    const int last_chunk = B > 0 ? (total - vr[B - 1]) / p.win : -1;
     p.nchunks[g] = last_chunk + 1;
     first[last_chunk + 1] = B;
+  }
+  // chunk descriptors: one 16-byte record per launched workgroup (the encoder's first load)
+  __threadfence_block();
+  __syncthreads();
+  int4* desc = reinterpret_cast<int4*>(p.desc) + (int64_t)g * p.ub;
+  for (int c = threadIdx.x; c < p.ub; c += T) {
+    int4 d = make_int4(0, 0, 0, 0);
+    if (c <= last_chunk) {
+      const int f0 = first[c], f1 = first[c + 1];
+      if (f1 > f0) {
+        const int s0 = start[f0];
+        d = make_int4(f0, f1 - f0, s0, start[f1] - s0);
+      }
+    }
+    desc[c] = d;
   }
 }
 
@@ -328,11 +383,12 @@ struct EncParams {
   float* pooled[2];
   const float* atom_table;
   const float* bond_table;
-  const float* img;
+  const float* img[2];  // per ion: S weight images (kImgSlot floats each)
   const int32_t* rows;
   const int32_t* start;
   const int32_t* first;
   const int32_t* nchunks;
+  const int32_t* desc;
   int n_ions, B, N, E, K, S, Va, Vb, ub;
   float ln_eps;
   unsigned long long* stamps;  // diagnostics only (impnn_debug_set_stamp_buffer): 16 words per workgroup
@@ -461,33 +517,34 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
     L.scratch = reinterpret_cast<int32_t*>(f);
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  unsigned long long* stamp = p.stamps ? p.stamps + (size_t)blockIdx.x * 16 : nullptr;
+  unsigned long long* stamp = p.stamps ? p.stamps + (size_t)blockIdx.x * 32 : nullptr;
   if (stamp && tid == 0) stamp[0] = __builtin_amdgcn_s_memtime();
   const int g = p.n_ions == 2 ? (blockIdx.x & 1) : 0;
   const int c = p.n_ions == 2 ? (blockIdx.x >> 1) : blockIdx.x;
-  if (c >= p.nchunks[g]) return;
-  const int32_t* first = p.first + (int64_t)g * (p.ub + 2);
-  const int m0 = first[c], m1 = first[c + 1];
-  const int M = m1 - m0;
+  const int4 dsc = reinterpret_cast<const int4*>(p.desc)[(int64_t)g * p.ub + c];
+  // workgroup-uniform: keep them in SGPRs so every loop bound / branch below stays scalar
+  const int m0 = __builtin_amdgcn_readfirstlane(dsc.x), M = __builtin_amdgcn_readfirstlane(dsc.y);
+  const int base = __builtin_amdgcn_readfirstlane(dsc.z);
+  const int R = __builtin_amdgcn_readfirstlane(dsc.w);  // <= kRCap by construction of the plan
   if (M <= 0) return;
   const int32_t* start = p.start + (int64_t)g * (p.B + 1);
   const int32_t* rows_g = p.rows + (int64_t)g * p.B;
-  const int base = start[m0];
-  const int R = start[m1] - base;  // <= kRCap by construction of the plan
   const int ntiles = (R + 15) >> 4;
   const int N = p.N, E = p.E;
   const int32_t* ids_g = p.atom_ids[g];
   const int32_t* conn_g = p.conn[g];
   const int32_t* bond_g = p.bond_ids[g];
-  const float* img_g = p.img + (int64_t)g * (p.S > 0 ? p.S : 1) * kImgSlot;
+  const float* img_g = p.img[g];
 
   // ---- prologue ------------------------------------------------------------------------
-  // P0: chunk tables; the step-0 weight image and this thread's first edge slot start their flight
+  // P0: chunk tables; this thread's first edge slot starts its flight
   f32x4 pf[kPf];
+#if IMPNN_OPT_PF_LATE == 0
   if (p.S > 0) {
 #pragma unroll
     for (int i = 0; i < kPf; ++i) pf[i] = ld4(img_g + 4 * (tid + i * kThreads));
   }
+#endif
   const int n_slots = M * E;
   // edge slot owned by this thread in the first pass (slots beyond kThreads are re-read in loops)
   int s_m = 0, s_e = 0, s_bid = -1;
@@ -512,6 +569,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
   if (tid < 48) L.bins[tid] = 0;
   if (tid < 16) L.tilemax[tid] = 0;
   __syncthreads();
+  if (stamp && tid == 0) stamp[16] = __builtin_amdgcn_s_memtime();
 
   // P1: in-degree of every logical row (edge-parallel); logical row -> (molecule, n, id>0);
   //     h0 rows (train_viscosity.py:171) start their flight: 4 threads per row, 2 x 16 B each
@@ -544,7 +602,16 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
     }
     if (sub == 0) L.rowinfo[row] = info;
   }
+  // the step-0 weight image starts its flight behind the latency-critical loads (loads retire in
+  // order: issued first, it would hold up every small dependent load above)
+#if IMPNN_OPT_PF_LATE == 1
+  if (p.S > 0) {
+#pragma unroll
+    for (int i = 0; i < kPf; ++i) pf[i] = ld4(img_g + 4 * (tid + i * kThreads));
+  }
+#endif
   __syncthreads();
+  if (stamp && tid == 0) stamp[17] = __builtin_amdgcn_s_memtime();
 
   // P2: place rows by descending in-degree (counting sort over 18 bins) so that a tile's lanes
   //     walk in-edge lists of similar length.  The placement inside a bin comes from an LDS
@@ -576,6 +643,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
     if (my_deg > 0) atomicMax(&L.tilemax[pos >> 4], my_deg);
   }
   __syncthreads();
+  if (stamp && tid == 0) stamp[18] = __builtin_amdgcn_s_memtime();
 
   // P3: exclusive scan of the placed in-degrees -> rowptr; cursor = fill position
   {
@@ -598,6 +666,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
     }
   }
   __syncthreads();
+  if (stamp && tid == 0) stamp[19] = __builtin_amdgcn_s_memtime();
 
   // P4: fill.  entry = edge slot (16b) | bond id (8b) | placed source row (8b); the slot in the
   //     top bits lets P5 restore edge-slot order, so the accumulation order is fixed run to run.
@@ -630,8 +699,10 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
     for (int i = 0; i < kPf; ++i) st4(L.wimg + 4 * (tid + i * kThreads), pf[i]);
   }
   __syncthreads();
+  if (stamp && tid == 0) stamp[20] = __builtin_amdgcn_s_memtime();
 
-  // P5: every row's in-edge list in edge-slot order: rank sort ent2 -> ent (lists are short)
+  // P5: every row's in-edge list in edge-slot order: entry-parallel rank sort ent2 -> ent
+#if IMPNN_OPT_PSORT == 0
   if (tid < kRCap) {
     const int lo = L.rowptr[tid], hi = L.rowptr[tid + 1];
     for (int i = lo; i < hi; ++i) {
@@ -641,6 +712,23 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
       L.ent[lo + rank] = v;
     }
   }
+#else
+  {
+    const int total = L.rowptr[kRCap];
+    for (int i = tid; i < total; i += kThreads) {
+      int lo = 0, hi = kRCap - 1;  // largest row with rowptr[row] <= i
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (L.rowptr[mid] <= i) lo = mid; else hi = mid - 1;
+      }
+      const int b0 = L.rowptr[lo], b1 = L.rowptr[lo + 1];
+      const uint32_t v = L.ent2[i];
+      int rank = 0;
+      for (int j = b0; j < b1; ++j) rank += L.ent2[j] < v;
+      L.ent[b0 + rank] = v;
+    }
+  }
+#endif
   __syncthreads();
 
   if (stamp && tid == 0) stamp[1] = __builtin_amdgcn_s_memtime();
@@ -940,11 +1028,26 @@ size_t encoder_fused_workspace_bytes(int n_ions, int B, int N, int E, int D, int
   return ws_layout(n_ions, B, N, E, K, S).total;
 }
 
+size_t encoder_prepared_bytes(int S) { return (size_t)(S > 0 ? S : 1) * kImgSlot * sizeof(float); }
+
+int launch_encoder_prepare(const float* weights, int D, int K, int S, int mode, void* prepared, hipStream_t s) {
+  if (S <= 0) return IMPNN_OK;
+  ImageParams ip{};
+  ip.weights = weights;
+  ip.img = static_cast<float*>(prepared);
+  ip.K = K;
+  ip.mode = mode == 1 ? 1 : 0;
+  ip.step_floats = impnn_encoder_step_floats(D, K);
+  weight_image_kernel<<<dim3(16, S), 256, 0, s>>>(ip);
+  return check_launch("weight_image");
+}
+
 int launch_encoder_fused(const EncoderArgs& a, hipStream_t s) {
   const Ws w = ws_layout(a.n_ions, a.B, a.N, a.E, a.K, a.S);
   if (!aligned16(a.workspace)) return fail(IMPNN_E_BADARG, "encoder_fused: workspace must be 16B aligned");
   if (!aligned16(a.atom_table)) return fail(IMPNN_E_BADARG, "encoder_fused: atom_table must be 16B aligned");
   char* base = static_cast<char*>(a.workspace);
+  const int mode = a.mode == 1 ? 1 : 0;
   PlanParams pp{};
   EncParams ep{};
   for (int g = 0; g < a.n_ions; ++g) {
@@ -953,42 +1056,45 @@ int launch_encoder_fused(const EncoderArgs& a, hipStream_t s) {
     pp.atom_ids[g] = ep.atom_ids[g] = a.atom_ids[g];
     pp.bond_ids[g] = ep.bond_ids[g] = a.bond_ids[g];
     pp.conn[g] = ep.conn[g] = a.conn[g];
-    pp.weights[g] = a.weights[g];
     ep.pooled[g] = a.pooled[g];
+    if (a.prepared[g]) {
+      if (!aligned16(a.prepared[g])) return fail(IMPNN_E_BADARG, "encoder_fused: prepared weights must be 16B aligned");
+      ep.img[g] = static_cast<const float*>(a.prepared[g]);
+    } else {  // canonical weights: build the image into the workspace first
+      float* img = reinterpret_cast<float*>(base + w.img_off) + (size_t)g * (a.S > 0 ? a.S : 1) * kImgSlot;
+      if (int rc = launch_encoder_prepare(a.weights[g], a.D, a.K, a.S, mode, img, s)) return rc;
+      ep.img[g] = img;
+    }
   }
-  pp.img = reinterpret_cast<float*>(base + w.img_off);
   pp.rows = reinterpret_cast<int32_t*>(base + w.rows_off);
   pp.vr = reinterpret_cast<int32_t*>(base + w.vr_off);
   pp.start = reinterpret_cast<int32_t*>(base + w.start_off);
   pp.first = reinterpret_cast<int32_t*>(base + w.first_off);
   pp.nchunks = reinterpret_cast<int32_t*>(base + w.nchunks_off);
+  pp.desc = reinterpret_cast<int32_t*>(base + w.desc_off);
   pp.n_ions = a.n_ions; pp.B = a.B; pp.N = a.N; pp.E = a.E; pp.K = a.K; pp.S = a.S; pp.Vb = a.Vb;
   pp.win = kRCap - vr_max_of(a.N, a.E) + 1;
   pp.ub = w.ub;
-  pp.step_floats = impnn_encoder_step_floats(a.D, a.K);
-  pp.mode = encoder_mode() == 1 ? 1 : 0;
   const int waves_per_block = 4;
-  pp.mol_blocks = (int)(((int64_t)a.n_ions * a.B + waves_per_block - 1) / waves_per_block);
-  const int img_blocks = a.n_ions * a.S;
-  plan_stats_kernel<<<pp.mol_blocks + img_blocks, 64 * waves_per_block, 0, s>>>(pp);
+  const int mol_blocks = (int)(((int64_t)a.n_ions * a.B + waves_per_block - 1) / waves_per_block);
+  plan_stats_kernel<<<mol_blocks, 64 * waves_per_block, 0, s>>>(pp);
   if (int rc = check_launch("plan_stats")) return rc;
   plan_scan_kernel<<<a.n_ions, 1024, 0, s>>>(pp);
   if (int rc = check_launch("plan_scan")) return rc;
 
   ep.atom_table = a.atom_table;
   ep.bond_table = a.bond_table;
-  ep.img = pp.img; ep.rows = pp.rows; ep.start = pp.start; ep.first = pp.first; ep.nchunks = pp.nchunks;
+  ep.rows = pp.rows; ep.start = pp.start; ep.first = pp.first; ep.nchunks = pp.nchunks; ep.desc = pp.desc;
   ep.n_ions = a.n_ions; ep.B = a.B; ep.N = a.N; ep.E = a.E; ep.K = a.K; ep.S = a.S;
   ep.Va = a.Va; ep.Vb = a.Vb; ep.ub = w.ub; ep.ln_eps = a.ln_eps;
   ep.stamps = nullptr;
   {
     size_t sb = 0;
     void* sp = debug_stamp_buffer(&sb);
-    if (sp && sb >= (size_t)w.ub * a.n_ions * 16 * sizeof(unsigned long long))
+    if (sp && sb >= (size_t)w.ub * a.n_ions * 32 * sizeof(unsigned long long))
       ep.stamps = static_cast<unsigned long long*>(sp);
   }
   const size_t lds = lds_bytes(a.K);
-  const int mode = encoder_mode() == 1 ? 1 : 0;
   const int variant = (a.K == 8 ? 1 : 0) + 2 * mode;
   void (*kern)(EncParams) = variant == 0   ? encoder_fused_kernel<0, false>
                             : variant == 1 ? encoder_fused_kernel<8, false>

@@ -62,6 +62,7 @@ class MPNNModel:
             self.mp_out = L.Dense(1, **dev)                             # :198
         self._build_all()
         self._packed = None
+        self._prepared = {}
         self._split_deg_limit = None
         self.encoder_mode = "auto"  # "auto" | "f32" | "f16x2"
 
@@ -145,7 +146,15 @@ class MPNNModel:
     def invalidate_packed_weights(self):
         """Call after mutating layer weights in place; the fused encoder caches a packed copy."""
         self._packed = None
+        self._prepared = {}
         self._split_deg_limit = None
+
+    def _prepared_weights(self, mode):
+        """Kernel-side weight images (one per ion), built once per weight version and mode."""
+        if mode not in self._prepared:
+            self._prepared[mode] = [ops.prepare_encoder_weights(pk, self.atom_dim, self.bond_dim, self.num_steps, mode)
+                                    if pk is not None else None for pk in self._packed_weights()]
+        return self._prepared[mode]
 
     def _packed_weights(self):
         if self._packed is None:
@@ -205,9 +214,11 @@ class MPNNModel:
             fused = (tuple(ca.shape) == tuple(aa.shape) and tuple(cb.shape) == tuple(ab.shape)
                      and self.fused_supported(ca.shape[1], cb.shape[1]))
         if fused:
+            mode = self.resolve_encoder_mode(cb.shape[1])
+            prepared = self._prepared_weights(mode) if self.num_steps > 0 else None
             pc, pa = ops.encoder_fused([(ca, cb, cc), (aa, ab, ac)], self.atom_emb.embeddings,
-                                       self.bond_emb.embeddings, self._packed_weights(), self.num_steps,
-                                       mode=self.resolve_encoder_mode(cb.shape[1]))
+                                       self.bond_emb.embeddings, None if prepared else self._packed_weights(),
+                                       self.num_steps, mode=mode, prepared=prepared)
             if trace is not None:
                 trace["cat/pooled"], trace["an/pooled"] = pc, pa
             return pc, pa

@@ -236,27 +236,46 @@ def split_mode_degree_limit(atom_table, bond_table, steps, D):
     return float("inf") if per_deg == 0.0 else 0.999 * FP16_MAX / per_deg
 
 
-def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=LN_EPS, mode="f16x2"):
+def prepare_encoder_weights(packed, D, K, num_steps, mode="f16x2"):
+    """Builds the encoder's kernel-side weight image once (impnn_encoder_prepare_weights); pass the
+    result as `prepared` to encoder_fused while the weights stay unchanged."""
+    require_gpu(packed)
+    packed = f32c(packed)
+    S = int(num_steps)
+    lib = _lib.load()
+    nbytes = int(lib.impnn_encoder_prepared_bytes(S))
+    out = torch.empty(nbytes, dtype=torch.uint8, device=packed.device)
+    with torch.cuda.device(packed.device):
+        check(lib.impnn_encoder_prepare_weights(ptr(packed), D, K, S, ENCODER_MODES[mode], ptr(out), nbytes,
+                                                stream_ptr()))
+    return out
+
+
+def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=LN_EPS, mode="f16x2", prepared=None):
     """encode() up to GlobalSumPool for 1 or 2 ion branches in one launch.
 
     ions: list of (atom_ids (B,N), bond_ids (B,E), conn (B,E,2)); packed_weights: list of packed
-    step-weight tensors (pack_step_weights).  Returns a list of pooled (B,D) tensors.
+    step-weight tensors (pack_step_weights), or None when `prepared` (list of
+    prepare_encoder_weights outputs built for the same `mode`) is given.  Returns a list of pooled
+    (B,D) tensors.
     mode: "f32" (exact f32 MFMA) or "f16x2" (split-fp16 MFMA, f32 accumulate; the caller vouches for
     the range condition of include/impnn.h - ionic_mpnn_amd.model does via split_mode_degree_limit).
     """
     n = len(ions)
     if n not in (1, 2):
         raise ValueError("1 or 2 ion branches")
+    if mode not in ENCODER_MODES:
+        raise ValueError(f"mode must be one of {sorted(ENCODER_MODES)}")
     atom_table, bond_table = f32c(atom_table), f32c(bond_table)
     require_gpu(atom_table, bond_table)
     dev = atom_table.device
-    prepared = []
+    prepared_in = []
     for (a, b, c) in ions:
         require_gpu(a, b, c)
-        prepared.append((i32c(a), i32c(b), i32c(c)))
-    B, N = prepared[0][0].shape
-    E = prepared[0][1].shape[1]
-    for (a, b, c) in prepared:
+        prepared_in.append((i32c(a), i32c(b), i32c(c)))
+    B, N = prepared_in[0][0].shape
+    E = prepared_in[0][1].shape[1]
+    for (a, b, c) in prepared_in:
         if tuple(a.shape) != (B, N) or tuple(b.shape) != (B, E) or tuple(c.shape) != (B, E, 2):
             raise ValueError("ion branches must share (B,N,E)")
     Va, D = atom_table.shape
@@ -269,23 +288,27 @@ def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=L
         raise EncoderUnsupported(lib.impnn_last_error_string().decode())
     check(rc)
     if DEBUG_VALIDATE:
-        for (a, b, c) in prepared:
+        for (a, b, c) in prepared_in:
             validate_indices(conn=c, atom_ids=a, bond_ids=b, N=N, Va=Va, Vb=Vb)
     ws = _workspace(dev, need.value)
     pooled = [torch.empty(B, D, dtype=torch.float32, device=dev) for _ in range(n)]
-    ws_w = [f32c(w) if w is not None else None for w in packed_weights]
-    step_f = encoder_step_floats(D, K)
-    for w in ws_w:
-        if S > 0 and (w is None or w.numel() != S * step_f):
-            raise ValueError(f"packed step weights must hold S*{step_f} floats")
     arr = C.c_void_p * n
     mk = lambda ts: arr(*[t.data_ptr() if t is not None else 0 for t in ts])
-    if mode not in ENCODER_MODES:
-        raise ValueError(f"mode must be one of {sorted(ENCODER_MODES)}")
+    common = (mk([p[0] for p in prepared_in]), mk([p[1] for p in prepared_in]), mk([p[2] for p in prepared_in]),
+              ptr(atom_table), Va, ptr(bond_table), Vb)
     with torch.cuda.device(dev):
-        lib.impnn_encoder_set_mode(ENCODER_MODES[mode])
-        check(lib.impnn_encoder_fused(n, mk([p[0] for p in prepared]), mk([p[1] for p in prepared]),
-                                      mk([p[2] for p in prepared]), ptr(atom_table), Va, ptr(bond_table), Vb,
-                                      mk(ws_w), mk(pooled), B, N, E, D, K, S, float(eps), ptr(ws), ws.numel(),
-                                      stream_ptr()))
+        if prepared is not None:
+            if len(prepared) != n or any(int(t.numel()) < int(lib.impnn_encoder_prepared_bytes(S)) for t in prepared):
+                raise ValueError("prepared weight images do not match (n_ions, num_steps)")
+            check(lib.impnn_encoder_fused_prepared(n, *common, mk(prepared), ENCODER_MODES[mode], mk(pooled), B, N, E,
+                                                   D, K, S, float(eps), ptr(ws), ws.numel(), stream_ptr()))
+        else:
+            ws_w = [f32c(w) if w is not None else None for w in packed_weights]
+            step_f = encoder_step_floats(D, K)
+            for w in ws_w:
+                if S > 0 and (w is None or w.numel() != S * step_f):
+                    raise ValueError(f"packed step weights must hold S*{step_f} floats")
+            lib.impnn_encoder_set_mode(ENCODER_MODES[mode])
+            check(lib.impnn_encoder_fused(n, *common, mk(ws_w), mk(pooled), B, N, E, D, K, S, float(eps), ptr(ws),
+                                          ws.numel(), stream_ptr()))
     return pooled

@@ -181,6 +181,21 @@ def test_full_batch_fused_equals_layered_hip(full):
     assert_close(pa.cpu().numpy(), la.cpu().numpy(), what="fused vs layered an")
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_prepared_and_per_call_weight_images_agree_bitwise(mode):
+    _, inp, w, outs = load_case("config2_perturbed_b6")
+    m = make_model(w, 124, 72, mode=mode)
+    d = to_dev(inp)
+    ions = [(d["cat_atom"], d["cat_bond"], d["cat_connectivity"]), (d["an_atom"], d["an_bond"], d["an_connectivity"])]
+    a = ops.encoder_fused(ions, m.atom_emb.embeddings, m.bond_emb.embeddings, m._packed_weights(), m.num_steps, mode=mode)
+    b = ops.encoder_fused(ions, m.atom_emb.embeddings, m.bond_emb.embeddings, None, m.num_steps, mode=mode,
+                          prepared=m._prepared_weights(mode))
+    one = ops.encoder_fused(ions[:1], m.atom_emb.embeddings, m.bond_emb.embeddings, m._packed_weights()[:1], m.num_steps,
+                            mode=mode)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(one[0], a[0])
+    assert_close(a[0].cpu().numpy(), outs["cat/pooled"], what="cat pooled")
+
+
 def test_auto_mode_uses_static_range_bound():
     """auto = f16x2 only when the LayerNorm / in-degree bound keeps every operand inside fp16 range."""
     w = weights.init_weights("viscosity", synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, num_steps=3, seed=1)

@@ -28,13 +28,13 @@ for _ in range(3):
     m.encode_pooled(d, fused=True)
 torch.cuda.synchronize()
 nwg = 2 * (B * 40 // 217 + 1)
-buf = torch.zeros(nwg * 16, dtype=torch.int64, device=dev)
+buf = torch.zeros(nwg * 32, dtype=torch.int64, device=dev)
 lib = _lib.load()
 lib.impnn_debug_set_stamp_buffer(buf.data_ptr(), buf.numel() * 8)
 m.encode_pooled(d, fused=True)
 torch.cuda.synchronize()
 lib.impnn_debug_set_stamp_buffer(None, 0)
-st = buf.cpu().numpy().reshape(nwg, 16).astype(np.uint64)
+st = buf.cpu().numpy().reshape(nwg, 32).astype(np.uint64)
 live = st[:, 7] != 0
 st = st[live]
 R = (st[:, 6] >> np.uint64(32)).astype(np.int64)
@@ -55,6 +55,9 @@ print(f"kernel span {span} ticks; sum of chunk totals / 256 CUs = {tot.sum() / 2
 tiles = np.ceil(R / 16)
 ideal = tiles * 224 * 32 / 4  # MFMA-bound cycles per step for the chunk (4 SIMDs)
 print(f"ideal MFMA cycles per step per chunk {ideal.mean():.0f} vs measured step mean {np.mean([x.mean() for x in steps]):.0f}")
+pp = [t[:, 0], t[:, 16], t[:, 17], t[:, 18], t[:, 19], t[:, 20], t[:, 1]]
+pn = ["P0 tables+first loads", "P1 degrees+ids+table issue", "P2 placement", "P3 scan", "P4 fill+h0+image", "P5 sort"]
+print("prologue phases (cycles): " + "  ".join(f"{n} {(pp[i + 1] - pp[i]).mean():.0f}" for i, n in enumerate(pn)))
 ph = t[:, 8:16]
 names = ["h load+deg", "gather", "msg mfma", "gates mfma+sigmoid", "cand mfma", "tanh+LN+store"]
 print("wave0 tile0 phases (cycles): " + "  ".join(f"{n} {(ph[:, i + 1] - ph[:, i]).mean():.0f}" for i, n in enumerate(names))
