@@ -187,10 +187,6 @@ def pack_step_weights(steps):
     return torch.cat(parts) if parts else None
 
 
-class EncoderUnsupported(RuntimeError):
-    pass
-
-
 _workspaces = {}
 
 
@@ -207,6 +203,10 @@ def encoder_fused_supported(N, E, D, K, S, Vb):
     out = C.c_size_t(0)
     rc = _lib.load().impnn_encoder_workspace_bytes(1, 1, N, E, D, K, S, Vb, C.byref(out))
     return rc == 0
+
+
+class EncoderUnsupported(RuntimeError):
+    pass
 
 
 ENCODER_MODES = {"f32": 0, "f16x2": 1}
@@ -246,8 +246,11 @@ def prepare_encoder_weights(packed, D, K, num_steps, mode="f16x2"):
     nbytes = int(lib.impnn_encoder_prepared_bytes(S))
     out = torch.empty(nbytes, dtype=torch.uint8, device=packed.device)
     with torch.cuda.device(packed.device):
-        check(lib.impnn_encoder_prepare_weights(ptr(packed), D, K, S, ENCODER_MODES[mode], ptr(out), nbytes,
-                                                stream_ptr()))
+        rc = lib.impnn_encoder_prepare_weights(ptr(packed), D, K, S, ENCODER_MODES[mode], ptr(out), nbytes,
+                                               stream_ptr())
+    if rc == _lib.IMPNN_E_UNSUPPORTED:
+        raise EncoderUnsupported(lib.impnn_last_error_string().decode())
+    check(rc)
     return out
 
 
