@@ -42,13 +42,37 @@ def algorithmic_bytes_per_pair(N, E, D):
     return 2 * (4 * N + 12 * E + 4 * D) + 8
 
 
+def usable_cores():
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("IMPNN_BENCH_CORES", "16"))))  # GPU-box share: 16 cores per GPU
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per encoder launch from the committed rocprofv3 --pmc passes (profiles/pmc_*.json,
+    FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section + WRITE_SIZE), or None if absent."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("pmc_*.json")):
+        try:
+            best = json.loads(f.read_text()).get("encoder_fused", {}).get("hbm_bytes_per_launch", best)
+        except (OSError, ValueError):
+            pass
+    return best
+
+
 def cpu_baseline(inputs, w, budget_s=20.0):
     """Reference-schedule torch-CPU forward (oracle/torch_ref.py) on a bounded sample of the same
-    workload, all host cores.  Reported beside the GPU number; never the thing measured as `value`."""
+    workload on the usable host cores.  Reported beside the GPU number; never `value`."""
     from oracle import torch_ref as TR
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
-    sample = 128
+    sample = 256
     sub = {k: v[:sample] for k, v in inputs.items()}
     t0 = time.perf_counter()
     TR.pooled_pair(w, sub)  # warm-up / page-in
@@ -74,6 +98,9 @@ def main():
     ap.add_argument("--mp-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--schedule", choices=["fused", "layered"], default="fused")
+    ap.add_argument("--mode", choices=["auto", "f32", "f16x2"], default="auto",
+                    help="GEMM arithmetic of the fused encoder (include/impnn.h); auto = f16x2 when the static "
+                         "range bound holds, else exact f32")
     args = ap.parse_args()
 
     from ionic_mpnn_amd import _lib, dist as idist, model, synthetic, weights
@@ -100,6 +127,8 @@ def main():
                              num_steps=S, seed=1)
     m = model.build_model(synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, atom_dim=D, bond_dim=K, num_steps=S, device=dev)
     m.load_weights(w)
+    m.encoder_mode = args.mode
+    mode_used = m.resolve_encoder_mode(E) if args.schedule == "fused" else "layered"
     d_in = {k: torch.from_numpy(v).to(dev) for k, v in inputs.items()}  # resident in HBM before timing
     fused = args.schedule == "fused"
 
@@ -107,8 +136,6 @@ def main():
         return m.encode_pooled(d_in, fused=fused)
 
     lib = _lib.load()
-    check_sum = torch.zeros(2, dtype=torch.float64, device="cpu" if rehearsal else dev)
-    works = []
     for _ in range(args.warmup):
         pc, pa = step()
     torch.cuda.synchronize()
@@ -164,6 +191,12 @@ def main():
         "config": {"workload": f"BASELINE.json configs[1]: message-passing forward (embedding gather -> {S}x"
                                f"(BondMatrixMessage, Reduce, GatedUpdate) -> GlobalSumPool), cation+anion, synthetic "
                                f"padded graphs N<={N} E<={E}, D={D}, K={K}, batch {B} pairs/GPU, schedule={args.schedule}",
+                   "arithmetic": {"f16x2": "f32 in/out/accumulate; every f32 GEMM product formed from fp16 hi/lo splits "
+                                           "(3 v_mfma_f32_16x16x32_f16 per f32 product, error ~2^-21; parity <=1e-5 vs "
+                                           "fp64 oracle in tests/test_gpu_encoder.py)",
+                                  "f32": "exact f32 products on v_mfma_f32_16x16x4_f32",
+                                  "layered": "f32 VALU, one launch per reference layer"}[mode_used],
+                   "mode": mode_used,
                    "global_batch": int(total_pairs), "parallelism": f"batch-sharded x{world}, weights replicated, "
                    "no data-path collective; one all-reduce of the fingerprint checksum after the timed region",
                    "checksum": float(local_sum[0].item())},
@@ -174,7 +207,9 @@ def main():
         ach = flops_launch / (kernel_ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": "encoder_fused_kernel", "achieved": ach,
                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                           "traffic": None, "kernel_ms": kernel_ms,
+                           "traffic": pmc_traffic_bytes(), "kernel_ms": kernel_ms,
+                           "note": "achieved = SURVEY 8(d) algorithmic f32 flops / measured kernel time; peak = dense "
+                                   "f32 MFMA (= f32 VALU) peak, the rate an exact-f32 implementation is bound by",
                            "algorithmic_flops_per_launch": flops_launch,
                            "hbm": {"algorithmic_bytes_per_launch": bytes_launch,
                                    "achieved_GBs": bytes_launch / (kernel_ms * 1e-3) / 1e9,

@@ -19,3 +19,17 @@ for kern, cs in acc.items():
     for name in sorted(cs):
         v = cs[name]
         print(f"  {name:32s} mean/dispatch {sum(v) / len(v):16.1f}  (n={len(v)})")
+
+import json
+res = {}
+for kern, cs in acc.items():
+    mean = {k: sum(v) / len(v) for k, v in cs.items()}
+    entry = {"counters_mean_per_dispatch": mean}
+    if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
+        # rocprofv3 reports KiB; gfx950 FETCH_SIZE counts 128-B requests at 64 B: double it
+        entry["hbm_bytes_per_launch"] = (2.0 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024.0
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "GRBM_GUI_ACTIVE" in mean:
+        entry["mfma_pipe_busy_frac"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (mean["GRBM_GUI_ACTIVE"] / 8.0)
+    res[kern] = entry
+with open(f"{out}/pmc.json", "w") as fh:
+    json.dump(res, fh, indent=1)
