@@ -1,0 +1,83 @@
+"""CPU, world_size 2, gloo: the batch-shard path - contiguous shard bounds, rank-major
+all-gather of per-sample rows (uneven shards included) and the 2-scalar loss all-reduce.  The compute
+itself is GPU-only; here each rank's "forward" is a deterministic per-row function so that the test
+checks exactly what the distributed layer adds: partitioning and reassembly."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_rows, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    from ionic_mpnn_amd import dist as idist
+    from ionic_mpnn_amd import synthetic
+    r, lr, w = idist.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world) and idist.is_distributed()
+    glob = synthetic.make_batch(n_rows, max_atoms=6, max_edges=10, atom_vocab_size=9, bond_vocab_size=4, min_atoms=2,
+                                seed=3)
+
+    def fake_forward(local):  # per-sample, independent of the rest of the batch - like the real forward
+        a = torch.from_numpy(local["cat_atom"]).float()
+        c = torch.from_numpy(local["an_connectivity"]).float()
+        return torch.stack([a.sum(1), (a * a).sum(1), c.sum((1, 2)), torch.from_numpy(local["temperature"])[:, 0]], 1)
+
+    sf = idist.ShardedForward(fake_forward)
+    lo, hi = idist.shard_bounds(n_rows, world, rank)
+    local = sf.local_inputs(glob)
+    assert len(local["cat_atom"]) == hi - lo and (local["cat_bond"] == glob["cat_bond"][lo:hi]).all()
+    full = sf(glob)                                   # all-gather, rank-major
+    ref = fake_forward(glob)
+    assert full.shape == ref.shape and torch.equal(full, ref)
+    # loss statistics: one all-reduce of (sum sq err, count)
+    target = torch.arange(n_rows, dtype=torch.float32)
+    stats = idist.all_reduce_loss_stats(sf(glob, gather=False)[:, 0], target[lo:hi])
+    sse = float(((ref[:, 0].double() - target.double()) ** 2).sum())
+    assert abs(float(stats[0]) - sse) <= 1e-9 * max(1.0, sse) and int(stats[1]) == n_rows
+    t = idist.all_reduce_sum_(torch.tensor([float(rank + 1)]))
+    assert float(t) == world * (world + 1) / 2
+    Path(out_dir, f"ok_{rank}").write_text("ok")
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows", [8, 7])            # even and uneven shards
+def test_world2_gloo_shard_gather_reduce(tmp_path, n_rows):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_rows, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    for r, p in enumerate(procs):
+        if p.is_alive():
+            p.kill()
+            pytest.fail(f"rank {r} hung")
+        assert p.exitcode == 0, f"rank {r} exit code {p.exitcode}"
+        assert (tmp_path / f"ok_{r}").exists()
+
+
+def test_single_process_is_a_noop():
+    sys.path.insert(0, str(ROOT))
+    from ionic_mpnn_amd import dist as idist
+    assert idist.env_world()[2] >= 1
+    x = torch.arange(6.0).reshape(3, 2)
+    if not idist.is_distributed():
+        assert idist.all_gather_fingerprints(x) is x
+        s = idist.all_reduce_loss_stats(x[:, 0], torch.zeros(3))
+        assert float(s[0]) == float((x[:, 0] ** 2).sum()) and int(s[1]) == 3
