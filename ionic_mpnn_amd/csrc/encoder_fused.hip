@@ -757,7 +757,21 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
     const float* nxt = img_g + (int64_t)sn * kImgSlot;
     bool pf_issued = false;
 
-    for (int tile = wave; tile < ntiles; tile += kWaves) {
+    // Tile -> wave map.  Waves w, w+4, w+8, w+12 share a SIMD.  With ntiles = 4q + r the first r
+    // SIMD groups carry q+1 tiles and the rest q; tiles are ordered heavy -> light (rows are placed by
+    // descending in-degree), so the q-tile groups take the heaviest tiles and the (q+1)-tile groups
+    // the light ones: the busiest SIMD is not also the one with the longest gathers.
+    int my_tile = -1;
+    {
+      const int grp = wave & 3, slot = wave >> 2, q4 = ntiles >> 2, r4 = ntiles & 3;
+      const int heavy = (4 - r4) * q4;  // tiles given to the q-tile groups
+      if (grp >= r4) {
+        if (slot < q4) my_tile = slot * (4 - r4) + (grp - r4);
+      } else if (slot <= q4) {
+        my_tile = heavy + slot * r4 + grp;
+      }
+    }
+    for (int tile = my_tile; tile >= 0 && tile < ntiles; tile = -1) {
       const bool tstamp = stamp != nullptr && tile == 0 && s == (p.S > 1 ? 1 : 0);  // wave 0 only (tile 0)
       if (tstamp && lane == 0) stamp[8] = __builtin_amdgcn_s_memtime();
       const int row = tile * 16 + a;
