@@ -1,0 +1,180 @@
+// Shared constants, LDS/HBM layouts and kernel parameter blocks of the fused encoder (gfx950).
+// Included by encoder_plan.hip (plan + weight-image kernels) and encoder_fused.hip (the encoder).
+#pragma once
+
+#include "common.h"
+
+namespace impnn {
+namespace enc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// mode 1 scaling (powers of two, exact): weights are stored as W*kSW, B operands as x*kSX
+constexpr float kSW = 256.0f;
+constexpr float kSX = 16.0f;
+constexpr float kAcc = kSW * kSX;  // scale of every accumulator in mode 1
+
+constexpr int kD = 32;
+constexpr int kKMax = 8;
+constexpr int kRCap = 256;   // packed rows per chunk
+constexpr int kECap = 1024;  // valid edges per chunk (= 4 * kRCap, enforced through "virtual rows")
+constexpr int kHS = 36;      // LDS row stride of h (floats): 16B aligned, conflict-free b128 tile writes
+constexpr int kMsgRS = 36;   // row stride of the message-weight image
+constexpr int kUpdRS = 68;   // row stride of the update-weight image (2D + 4)
+constexpr int kThreads = 1024;
+constexpr int kWaves = kThreads / 64;
+constexpr int kTbCapFloats = 2048;  // bond table copy in LDS (Vb*K floats)
+
+__host__ __device__ constexpr int img_msg_floats(int K) { return K * kD * kMsgRS; }
+__host__ __device__ constexpr int img_upd_floats() { return 3 * kD * kUpdRS; }
+__host__ __device__ constexpr int img_vec_floats() { return 5 * kD; }
+__host__ __device__ constexpr int img_floats(int K) {
+  return img_msg_floats(K) + img_upd_floats() + img_vec_floats();
+}
+// mode 1 image (halfs): per (k, T) / (gate, T, half) two 512-half blocks (hi, lo); a lane's 8 halfs of
+// a block are contiguous, so the A operand of one MFMA is one conflict-free ds_read_b128.
+__host__ __device__ constexpr int img16_msg_halfs(int K) { return K * 2 * 2 * 512; }
+__host__ __device__ constexpr int img16_upd_halfs() { return 3 * 2 * 2 * 2 * 512; }
+__host__ __device__ constexpr int img16_vec_float_off(int K) { return (img16_msg_halfs(K) + img16_upd_halfs()) / 2; }
+// feature held by element j (0..7) of lane quarter q: the accumulator layout of a 16x16 MFMA tile pair
+__host__ __device__ constexpr int feat_of(int q, int j) { return 16 * (j >> 2) + 4 * q + (j & 3); }
+// Every image is stored (HBM workspace and LDS) in a slot of kImgSlot floats so that the
+// register prefetch is kPf unconditional 16-byte loads per thread (no per-load branch / wait).
+constexpr int kPf = 4;
+constexpr int kImgSlot = kPf * kThreads * 4;  // 16384 floats = 64 KiB >= img_floats(8) = 15904
+static_assert(kThreads == 4 * kRCap, "prologue maps 4 threads to a row");
+static_assert(img_floats(kKMax) <= kImgSlot, "weight image does not fit its slot");
+static_assert(img16_vec_float_off(kKMax) + img_vec_floats() <= kImgSlot, "split weight image does not fit");
+
+// ---- chunk record: everything the encoder needs to know about one chunk's graph structure, built by
+// plan_chunks (one small workgroup per chunk, many per CU) and copied verbatim into LDS by the
+// encoder.  Offsets in bytes.
+constexpr int kRecRowptr = 0;      // u16[kRCap + 2]: CSR over PLACED rows (rows placed by descending in-degree)
+constexpr int kRecTilemax = 528;   // u8[16]        : largest in-degree inside each 16-row tile
+constexpr int kRecMoloff = 544;    // u16[kRCap + 2]: first logical row of every molecule (+ end marker)
+constexpr int kRecMolrows = 1072;  // u16[kRCap]    : kept rows r_b of every molecule
+constexpr int kRecPoolrow = 1584;  // u16[kRCap]    : logical row -> placed row, | 0x8000 if atom id > 0 (pooled)
+constexpr int kRecRowatom = 2096;  // i32[kRCap]    : atom id of the PLACED row, -1 for a slack row
+constexpr int kRecEnt = 3136;      // u32[kECap]    : in-edge lists in edge-slot order: slot<<16 | bond id<<8 | placed src row
+constexpr int kRecBytes = 8192;
+static_assert(kRecEnt + 4 * kECap <= kRecBytes && kRecEnt % 16 == 0, "record layout");
+
+// chunk descriptor (int4): {first molecule, molecules, 0, rows | ion << 16}
+// share (int4), one per persistent encoder workgroup: {ion | first 16-molecule block << 1,
+//   virtual-row prefix at that block, first virtual row of the share, one past its last virtual row}
+constexpr int kPB = 16;  // molecules per plan_stats workgroup (= partial-sum granularity)
+
+// ---- workspace layout (bytes, all 256-aligned sections)
+struct Ws {
+  size_t img_off, rows_off, vr_off, partial_off, share_off, nsub_off, desc_off, rec_off, total;
+  int nwg;      // persistent encoder workgroups (= compute units)
+  int max_sub;  // chunk slots per workgroup (upper bound of chunks in one share)
+  int nblk;     // 16-molecule blocks per ion
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+inline int vr_max_of(int N, int E) {
+  int v = (E + 3) / 4;
+  int m = N > v ? N : v;
+  return m < 1 ? 1 : m;
+}
+
+inline Ws ws_layout(int n_ions, int B, int N, int E, int K, int S, int nwg) {
+  (void)K;
+  Ws w{};
+  const int vrmax = vr_max_of(N, E);
+  const int win = kRCap - vrmax + 1;  // a chunk closed by next-fit holds at least this many rows
+  w.nwg = nwg;
+  w.nblk = (B + kPB - 1) / kPB;
+  // rows of one share <= 2 * (all rows) / nwg + vrmax (ion split rounds to whole workgroups)
+  const int64_t share_rows = (2 * (int64_t)n_ions * B * vrmax) / nwg + vrmax;
+  w.max_sub = (int)(share_rows / win) + 2;
+  size_t off = 0;
+  w.img_off = off;
+  off = align_up(off + (size_t)n_ions * (S > 0 ? S : 1) * kImgSlot * sizeof(float), 256);
+  w.rows_off = off;
+  off = align_up(off + (size_t)n_ions * B * sizeof(int32_t), 256);
+  w.vr_off = off;
+  off = align_up(off + (size_t)n_ions * B * sizeof(int32_t), 256);
+  w.partial_off = off;
+  off = align_up(off + (size_t)n_ions * w.nblk * sizeof(int32_t), 256);
+  w.share_off = off;
+  off = align_up(off + (size_t)nwg * 4 * sizeof(int32_t), 256);
+  w.nsub_off = off;
+  off = align_up(off + (size_t)nwg * sizeof(int32_t), 256);
+  w.desc_off = off;
+  off = align_up(off + (size_t)nwg * w.max_sub * 4 * sizeof(int32_t), 256);
+  w.rec_off = off;
+  off = align_up(off + (size_t)nwg * w.max_sub * kRecBytes, 256);
+  w.total = off;
+  return w;
+}
+
+struct PlanParams {
+  const int32_t* atom_ids[2];
+  const int32_t* bond_ids[2];
+  const int32_t* conn[2];
+  int32_t* rows;      // [n_ions][B]     kept rows r_b
+  int32_t* vr;        // [n_ions][B]     virtual rows max(1, r_b, ceil(v_b/4))
+  int32_t* partial;   // [n_ions][nblk]  sum of vr over 16 molecules
+  int32_t* share;     // [nwg][4]
+  int32_t* nsub;      // [nwg]           chunks of every encoder workgroup
+  int32_t* desc;      // [nwg][max_sub][4]
+  unsigned char* rec; // [nwg][max_sub][kRecBytes]
+  int n_ions, B, N, E, Vb, nwg, max_sub, nblk;
+};
+
+struct ImageParams {
+  const float* weights;  // S steps, canonical layout
+  float* img;            // S slots of kImgSlot floats
+  int K, mode;
+  int64_t step_floats;
+};
+
+struct EncParams {
+  const int32_t* atom_ids[2];
+  float* pooled[2];
+  const float* atom_table;
+  const float* bond_table;
+  const float* img[2];  // per ion: S weight images (kImgSlot floats each)
+  const int32_t* nsub;
+  const int32_t* desc;
+  const unsigned char* rec;
+  int n_ions, B, N, K, S, Va, Vb, max_sub;
+  float ln_eps;
+  unsigned long long* stamps;  // diagnostics only (impnn_debug_set_stamp_buffer): 32 words per workgroup
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
+// global store of the wave (s_waitcnt vmcnt(0)); in kernels that stream results to HBM between LDS
+// phases that wait is pure latency (1-2 us per barrier).  Use only where no thread reads another
+// thread's GLOBAL writes after the barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Inclusive wave64 prefix sum on the DPP network (no LDS round trips: a __shfl_up chain is six
+// dependent ds_bpermute, ~150 cycles each).
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);  // row_bcast:15 -> rows 1,3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);  // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+__device__ __forceinline__ bool edge_valid(int s, int t, int bid, int N, int Vb) {
+  // models/layers.py:114-115 (src>0 & tgt>0); out-of-range indices behave as padding (impnn.h)
+  return s > 0 && t > 0 && s < N && t < N && (unsigned)bid < (unsigned)Vb;
+}
+
+// plan side (encoder_plan.hip)
+int launch_weight_image(const ImageParams& ip, int S, hipStream_t s);
+int launch_plan(const PlanParams& pp, hipStream_t s);
+
+}  // namespace enc
+}  // namespace impnn

@@ -1,0 +1,511 @@
+// Plan kernels of the fused encoder (gfx950): everything that depends on the graph batch only
+// (not on the weights) and is cheap, latency-bound, index arithmetic:
+//
+//   plan_stats   one wave per molecule: kept rows r_b, valid edges v_b -> virtual rows; one partial
+//                sum per 16 molecules
+//   plan_shares  one small workgroup: prefix over the partial sums (a few hundred values); the rows
+//                are dealt to `nwg` persistent encoder workgroups in equal contiguous shares (per
+//                ion, proportional to its rows): share = [first virtual row, last virtual row)
+//   plan_chunks  one 256-thread workgroup per (share, chunk slot) (8+ resident per CU, so its
+//                dependent loads overlap): resolves the share's molecules and its next-fit chain of
+//                chunks (<= 256 rows / <= 1024 edges) locally, then builds its chunk: in-degrees,
+//                placement of rows by descending in-degree, CSR of in-edges in edge-slot order,
+//                pool map -> one 8 KB chunk record in HBM
+//   weight_image canonical weights -> the encoder's LDS image (weights only; run when they change)
+#include "encoder_layout.h"
+
+namespace impnn {
+namespace enc {
+
+namespace {
+
+// -----------------------------------------------------------------------------------------
+// plan_stats: one wave per (ion, molecule): kept rows r_b, valid edges v_b, virtual rows
+// vr_b = max(1, r_b, ceil(v_b/4)).  Extra blocks convert the canonical packed step weights into
+// the LDS image the encoder copies verbatim (message rows padded to 36, gate kernels transposed).
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * kPB) void plan_stats_kernel(PlanParams p) {
+  __shared__ int vsum[kPB];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int g = blockIdx.x / p.nblk, blk = blockIdx.x - g * p.nblk;
+  const int b = blk * kPB + wv;
+  const bool have = b < p.B;
+  const int64_t item = (int64_t)g * p.B + (have ? b : 0);
+  int my_vr = 0;
+  if (have) {
+  const int32_t* ids = p.atom_ids[g] + (int64_t)b * p.N;
+  const int32_t* cn = p.conn[g] + (int64_t)b * p.E * 2;
+  const int32_t* bd = p.bond_ids[g] + (int64_t)b * p.E;
+  // wave-level reductions through ballots (scalar unit), no cross-lane data movement
+  int rmax = 0, cnt = 0;
+  for (int n0 = 0; n0 < p.N; n0 += 64) {
+    const int n = n0 + lane;
+    const unsigned long long hit = __ballot(n < p.N && ids[n] > 0);
+    if (hit) rmax = n0 + 64 - __builtin_clzll(hit);  // 1 + highest n with ids[n] > 0
+  }
+  int emax = 0;  // largest atom index on a valid edge (lane-local)
+  for (int e0 = 0; e0 < p.E; e0 += 64) {
+    const int e = e0 + lane;
+    bool ok = false;
+    if (e < p.E) {
+      const int2 st = *reinterpret_cast<const int2*>(cn + 2 * e);
+      ok = edge_valid(st.x, st.y, bd[e], p.N, p.Vb);
+      if (ok) {
+        const int m = st.x > st.y ? st.x : st.y;
+        emax = emax > m ? emax : m;
+      }
+    }
+    cnt += __builtin_popcountll(__ballot(ok));
+  }
+  if (cnt > 0) {  // wave max of emax, bit by bit from the top (indices < 65536)
+    bool alive = true;
+    int res = 0;
+#pragma unroll
+    for (int bit = 15; bit >= 0; --bit) {
+      const bool one = alive && ((emax >> bit) & 1);
+      if (__ballot(one)) {
+        res |= 1 << bit;
+        alive = one;
+      }
+    }
+    rmax = rmax > res + 1 ? rmax : res + 1;
+  }
+  {
+    int vr = (cnt + 3) >> 2;
+    vr = vr > rmax ? vr : rmax;
+    my_vr = vr < 1 ? 1 : vr;
+    if (lane == 0) {
+      p.rows[item] = rmax;
+      p.vr[item] = my_vr;
+    }
+  }
+  }
+  if (lane == 0) vsum[wv] = my_vr;
+  lds_barrier();
+  if (threadIdx.x == 0) {
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < kPB; ++i) t += vsum[i];
+    p.partial[(int64_t)g * p.nblk + blk] = t;
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// weight_image: canonical packed step weights -> the image the encoder copies verbatim into LDS
+// (mode 0: f32, message rows padded to 36, gate kernels transposed; mode 1: fp16 hi/lo blocks in
+// MFMA A-operand order).  grid = (slices, steps); depends on the weights only, so callers that
+// keep weights fixed run it once (impnn_encoder_prepare_weights).
+// -----------------------------------------------------------------------------------------
+
+__global__ void weight_image_kernel(ImageParams p) {
+  {
+    const int s = blockIdx.y;
+    const int t_begin = blockIdx.x * blockDim.x + threadIdx.x, t_stride = gridDim.x * blockDim.x;
+    const float* w = p.weights + (int64_t)s * p.step_floats;
+    const int K = p.K;
+    const float* W = w;                                 // (K,32,32)
+    const float* Wz = W + (int64_t)K * kD * kD;          // (64,32)
+    const float* bz = Wz + 2 * kD * kD;
+    const float* Wr = bz + kD;
+    const float* br = Wr + 2 * kD * kD;
+    const float* Wh = br + kD;
+    const float* bh = Wh + 2 * kD * kD;
+    const float* gamma = bh + kD;
+    const float* beta = gamma + kD;
+    float* img = p.img + (int64_t)s * kImgSlot;
+    if (p.mode == 1) {
+      _Float16* hi_lo = reinterpret_cast<_Float16*>(img);
+      const int nm = img16_msg_halfs(K), nu = img16_upd_halfs();
+      for (int t = t_begin; t < nm + nu; t += t_stride) {
+        // t = ((blk * 2 + part) * 64 + lane) * 8 + j
+        const int j = t & 7, ln = (t >> 3) & 63, part = (t >> 9) & 1;
+        const int q = ln >> 4, i = ln & 15, f = feat_of(q, j);
+        float wv;
+        if (t < nm) {
+          const int blk = t >> 10;  // k*2 + T
+          const int k = blk >> 1, T = blk & 1;
+          wv = W[((int64_t)k * kD + 16 * T + i) * kD + f];
+        } else {
+          const int blk = (t - nm) >> 10;  // (gate*2 + T)*2 + half
+          const int half = blk & 1, T = (blk >> 1) & 1, gate = blk >> 2;
+          const float* Wg = gate == 0 ? Wz : (gate == 1 ? Wr : Wh);
+          wv = Wg[(int64_t)(half * kD + f) * kD + 16 * T + i];
+        }
+        wv *= kSW;
+        const _Float16 hi = __builtin_amdgcn_cvt_pkrtz(wv, 0.f)[0];
+        const _Float16 lo = __builtin_amdgcn_cvt_pkrtz(wv - (float)hi, 0.f)[0];
+        hi_lo[t] = part == 0 ? hi : lo;
+      }
+      float* vec = img + img16_vec_float_off(K);
+      for (int t = t_begin; t < img_vec_floats(); t += t_stride) {
+        const int v = t / kD, i = t - v * kD;
+        const float* src = v == 0 ? bz : v == 1 ? br : v == 2 ? bh : v == 3 ? gamma : beta;
+        vec[t] = v < 3 ? src[i] * kAcc : src[i];  // biases seed the (scaled) accumulators
+      }
+      for (int t = img16_vec_float_off(K) + img_vec_floats() + t_begin; t < kImgSlot; t += t_stride) img[t] = 0.f;
+      return;
+    }
+    const int nmsg = img_msg_floats(K), nupd = img_upd_floats();
+    for (int t = t_begin; t < nmsg; t += t_stride) {
+      const int row = t / kMsgRS, j = t - row * kMsgRS;  // row = k*32 + i_out
+      img[t] = j < kD ? W[(int64_t)row * kD + j] : 0.f;
+    }
+    for (int t = t_begin; t < nupd; t += t_stride) {
+      const int row = t / kUpdRS, jj = t - row * kUpdRS;  // row = gate*32 + i_out
+      const int gate = row / kD, io = row - gate * kD;
+      const float* Wg = gate == 0 ? Wz : (gate == 1 ? Wr : Wh);
+      img[nmsg + t] = jj < 2 * kD ? Wg[(int64_t)jj * kD + io] : 0.f;
+    }
+    for (int t = t_begin; t < img_vec_floats(); t += t_stride) {
+      const int v = t / kD, i = t - v * kD;
+      const float* src = v == 0 ? bz : v == 1 ? br : v == 2 ? bh : v == 3 ? gamma : beta;
+      img[nmsg + nupd + t] = src[i];
+    }
+    for (int t = img_floats(K) + t_begin; t < kImgSlot; t += t_stride) img[t] = 0.f;
+  }
+}
+
+
+// -----------------------------------------------------------------------------------------
+// plan_shares: one 256-thread workgroup; wave g scans the partial sums of ion g.
+// -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void plan_shares_kernel(PlanParams p) {
+  extern __shared__ int32_t bp[];  // [n_ions][nblk + 1] exclusive prefix of the partial sums
+  __shared__ int tot_s[2], nwg_s[2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int nblk = p.nblk;
+  if (wv < p.n_ions) {
+    const int g = wv;
+    const int32_t* part = p.partial + (int64_t)g * nblk;
+    int32_t* out = bp + g * (nblk + 1);
+    int carry = 0;
+    for (int k0 = 0; k0 < nblk; k0 += 64 * 8) {  // 8 consecutive blocks per lane and round
+      int v[8];
+      const int kb = k0 + lane * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = part[(kb + i) < nblk ? (kb + i) : (nblk - 1)];  // clamped, masked below
+      int local = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (kb + i >= nblk) v[i] = 0;
+        local += v[i];
+      }
+      const int incl = wave_incl_scan(local);
+      int run = carry + incl - local;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (kb + i < nblk) out[kb + i] = run;
+        run += v[i];
+      }
+      carry += __shfl(incl, 63);
+    }
+    if (lane == 0) {
+      out[nblk] = carry;
+      tot_s[g] = carry;
+    }
+  }
+  lds_barrier();
+  if (threadIdx.x == 0) {  // workgroups per ion, proportional to its rows
+    if (p.n_ions == 1) {
+      nwg_s[0] = p.nwg;
+      nwg_s[1] = 0;
+    } else {
+      const long long t0 = tot_s[0], t1 = tot_s[1];
+      int n0 = (t0 + t1) > 0 ? (int)((p.nwg * t0 + (t0 + t1) / 2) / (t0 + t1)) : p.nwg / 2;
+      if (p.nwg >= 2) n0 = n0 < 1 ? 1 : (n0 > p.nwg - 1 ? p.nwg - 1 : n0);
+      nwg_s[0] = n0;
+      nwg_s[1] = p.nwg - n0;
+    }
+  }
+  lds_barrier();
+  for (int j = threadIdx.x; j < p.nwg; j += blockDim.x) {
+    const int g = j < nwg_s[0] ? 0 : 1;
+    const int jj = j - (g ? nwg_s[0] : 0);
+    const long long tg = tot_s[g];
+    const int t_lo = (int)(tg * jj / nwg_s[g]);
+    const int t_hi = (jj + 1 == nwg_s[g]) ? (int)tg : (int)(tg * (jj + 1) / nwg_s[g]);
+    // block that holds virtual row t_lo: largest k with bp[k] <= t_lo (branch-free)
+    const int32_t* bg = bp + g * (nblk + 1);
+    int lo = 0, hi = nblk - 1;
+    for (int it = 0; it < 32 && lo < hi; ++it) {
+      const int mid = (lo + hi + 1) >> 1;
+      const bool le = bg[mid] <= t_lo;
+      lo = le ? mid : lo;
+      hi = le ? hi : mid - 1;
+    }
+    reinterpret_cast<int4*>(p.share)[j] = make_int4(g | (lo << 1), bg[lo], t_lo, t_hi);
+  }
+}
+
+// -----------------------------------------------------------------------------------------
+// plan_chunks: 256 threads (= kRCap: one per row) per chunk.
+// -----------------------------------------------------------------------------------------
+constexpr int kDegBins = 18;    // in-degree 0..15, ">= 16", and "row beyond the chunk" (placed last)
+constexpr int kShareCap = 2048;  // molecules of one share resolved in LDS
+
+__global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
+  __shared__ int32_t moloff[kRCap + 2], molrows[kRCap], cnt[kRCap], place[kRCap], cursor[kRCap], rowptr[kRCap + 2];
+  __shared__ int32_t bins[48], tilemax[16], scratch[8];
+  __shared__ uint32_t ent2[kECap];
+  __shared__ int32_t shst[kShareCap + 1];  // virtual-row prefix of the share's molecules (+ end)
+  __shared__ int chunk_s[4];              // first molecule (share-local), molecules, rows, chunks in the share
+  const int j = blockIdx.x / p.max_sub, slot_i = blockIdx.x - j * p.max_sub;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int4 shr = reinterpret_cast<const int4*>(p.share)[j];
+  const int g = __builtin_amdgcn_readfirstlane(shr.x & 1), k0 = __builtin_amdgcn_readfirstlane(shr.x >> 1);
+  const int t_lo = __builtin_amdgcn_readfirstlane(shr.z), t_hi = __builtin_amdgcn_readfirstlane(shr.w);
+  if (t_hi <= t_lo) {
+    if (slot_i == 0 && tid == 0) p.nsub[j] = 0;
+    return;
+  }
+  // ---- resolve the share: molecules whose first virtual row lies in [t_lo, t_hi), their prefix, and
+  //      the next-fit chain of chunks; wave 0 does it, everybody else waits at the barrier.
+  if (wave == 0) {
+    const int32_t* vrg = p.vr + (int64_t)g * p.B;
+    int run = __builtin_amdgcn_readfirstlane(shr.y);  // prefix at molecule k0 * 16
+    int first = -1, nsh = 0;                          // first share molecule (global index), count
+    int end_row = -1;                                 // first virtual row after the share's last molecule
+    for (int mbase = k0 * kPB; mbase < p.B && end_row < 0; mbase += 64) {
+      const int m = mbase + lane;
+      const int v = vrg[m < p.B ? m : p.B - 1];  // clamped address, masked value
+      const int vv = m < p.B ? v : 0;
+      const int incl = wave_incl_scan(vv);
+      const int st = run + incl - vv;  // first virtual row of molecule m
+      const bool in = m < p.B && st >= t_lo && st < t_hi;
+      const unsigned long long inb = __ballot(in);
+      if (inb) {
+        if (first < 0) first = mbase + __builtin_ctzll(inb);
+        const int pos = nsh + __builtin_popcountll(inb & ((1ull << lane) - 1));
+        if (in && pos < kShareCap) shst[pos] = st;
+        nsh += __builtin_popcountll(inb);
+      }
+      const unsigned long long ge = __ballot(m < p.B && st >= t_hi);
+      if (ge) end_row = __shfl(st, __builtin_ctzll(ge));  // the next share's first molecule starts here
+      run += __shfl(incl, 63);
+    }
+    if (end_row < 0) end_row = run;           // ran off the end of the ion
+    nsh = nsh < kShareCap ? nsh : kShareCap;  // a share holds ~B/nwg molecules; launch_plan checks the cap
+    if (lane == 0) shst[nsh] = end_row;
+    __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): sst is read back by this wave below
+    int mb = 0, hop = 0, my_mb = -1, my_e = -1;
+    while (mb < nsh) {  // next-fit: chunk [mb, e), e = largest index with shst[e] - shst[mb] <= 256
+      const int lim = shst[mb] + kRCap;
+      int e = mb + 1;
+      for (int c0 = mb + 1; c0 <= nsh; c0 += 64) {
+        const int cidx = c0 + lane;
+        const bool ok = cidx <= nsh && shst[cidx <= nsh ? cidx : nsh] <= lim;
+        const unsigned long long okb = __ballot(ok);
+        if (okb == 0) break;
+        e = c0 + 63 - __builtin_clzll(okb);
+        if (okb != ~0ull) break;
+      }
+      if (hop == slot_i) {
+        my_mb = mb;
+        my_e = e;
+      }
+      ++hop;
+      mb = e;
+      if (slot_i != 0 && my_mb >= 0) break;  // only slot 0 needs the total count
+    }
+    if (lane == 0) {
+      chunk_s[0] = my_mb >= 0 ? first + my_mb : -1;
+      chunk_s[1] = my_mb >= 0 ? my_e - my_mb : 0;
+      chunk_s[2] = my_mb >= 0 ? shst[my_e] - shst[my_mb] : 0;
+      chunk_s[3] = my_mb;
+      if (slot_i == 0) p.nsub[j] = hop;
+    }
+  }
+  lds_barrier();
+  const int m0 = chunk_s[0], M = chunk_s[1], R = chunk_s[2], mb_local = chunk_s[3];
+  if (M <= 0) return;
+  const int idx = blockIdx.x;
+  if (tid == 0) reinterpret_cast<int4*>(p.desc)[idx] = make_int4(m0, M, 0, R | (g << 16));
+  const int N = p.N, E = p.E;
+  const int32_t* ids_g = p.atom_ids[g];
+  const int32_t* conn_g = p.conn[g];
+  const int32_t* bond_g = p.bond_ids[g];
+  const int32_t* rows_g = p.rows + (int64_t)g * p.B;
+  unsigned char* rec = p.rec + (size_t)idx * kRecBytes;
+  uint16_t* r_rowptr = reinterpret_cast<uint16_t*>(rec + kRecRowptr);
+  unsigned char* r_tilemax = rec + kRecTilemax;
+  uint16_t* r_moloff = reinterpret_cast<uint16_t*>(rec + kRecMoloff);
+  uint16_t* r_molrows = reinterpret_cast<uint16_t*>(rec + kRecMolrows);
+  uint16_t* r_poolrow = reinterpret_cast<uint16_t*>(rec + kRecPoolrow);
+  int32_t* r_rowatom = reinterpret_cast<int32_t*>(rec + kRecRowatom);
+  uint32_t* r_ent = reinterpret_cast<uint32_t*>(rec + kRecEnt);
+
+  // P0: molecule tables; the first edge slots of this thread start their flight now (their addresses
+  //     need only the descriptor), so the dependent-load chain is descriptor -> {tables, edges} -> ids
+  const int n_slots = M * E;
+  constexpr int kSC = 4;  // edge slots per thread kept in registers (covers M*E <= 1024)
+  int sm[kSC], se[kSC], sbid[kSC];
+  int2 sst[kSC];
+#pragma unroll
+  for (int k = 0; k < kSC; ++k) {
+    const int slot = tid + k * kRCap;
+    sm[k] = 0; se[k] = 0; sbid[k] = -1; sst[k] = make_int2(0, 0);
+    if (slot < n_slots) {
+      sm[k] = slot / E;
+      se[k] = slot - sm[k] * E;
+      const int64_t b = m0 + sm[k];
+      sst[k] = *reinterpret_cast<const int2*>(conn_g + (b * E + se[k]) * 2);
+      sbid[k] = bond_g[b * E + se[k]];
+    }
+  }
+  for (int m = tid; m <= M; m += kRCap) {
+    const int off = shst[mb_local + m] - shst[mb_local];
+    moloff[m] = off;
+    r_moloff[m] = (uint16_t)off;
+    if (m < M) {
+      const int rr = rows_g[m0 + m];
+      molrows[m] = rr;
+      r_molrows[m] = (uint16_t)rr;
+    }
+  }
+  cnt[tid] = 0;
+  if (tid < 48) bins[tid] = 0;
+  if (tid < 16) tilemax[tid] = 0;
+  lds_barrier();
+
+  // P1: in-degree of every logical row (edge-parallel, coalesced reads of conn / bond ids);
+  //     logical row -> (molecule, n), atom id
+#pragma unroll
+  for (int k = 0; k < kSC; ++k)
+    if (edge_valid(sst[k].x, sst[k].y, sbid[k], N, p.Vb)) atomicAdd(&cnt[moloff[sm[k]] + sst[k].y], 1);
+  for (int slot = tid + kSC * kRCap; slot < n_slots; slot += kRCap) {
+    const int m = slot / E, e = slot - m * E;
+    const int64_t b = m0 + m;
+    const int2 st = *reinterpret_cast<const int2*>(conn_g + (b * E + e) * 2);
+    if (edge_valid(st.x, st.y, bond_g[b * E + e], N, p.Vb)) atomicAdd(&cnt[moloff[m] + st.y], 1);
+  }
+  int my_id = -1;       // atom id of logical row tid (-1: slack row)
+  bool my_real = false;
+  if (tid < R) {
+    int lo = 0, hi = M - 1;  // largest m with moloff[m] <= row
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (moloff[mid] <= tid) lo = mid; else hi = mid - 1;
+    }
+    const int n = tid - moloff[lo];
+    if (n < molrows[lo]) {
+      my_real = true;
+      my_id = ids_g[(int64_t)(m0 + lo) * N + n];
+    }
+  }
+  lds_barrier();
+
+  // P2: place rows by descending in-degree (counting sort over 18 bins) so that a tile's lanes walk
+  //     in-edge lists of similar length.  The placement inside a bin comes from an LDS atomic and
+  //     may differ run to run - harmless: no result depends on where a row sits (MFMA columns,
+  //     the gather and LayerNorm are per row; the pool walks logical rows in order).
+  const int my_deg = cnt[tid];
+  const int my_bin = tid >= R ? 0 : (my_deg >= 16 ? 1 : 17 - my_deg);  // bin 0 = beyond chunk (placed last)
+  atomicAdd(&bins[my_bin], 1);
+  lds_barrier();
+  if (wave == 0) {  // exclusive scan in placement order: bins 1..17, then bin 0
+    const int bidx = lane < kDegBins ? (lane == kDegBins - 1 ? 0 : lane + 1) : 0;
+    const int v = lane < kDegBins ? bins[bidx] : 0;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+      int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane < kDegBins) bins[24 + bidx] = incl - v;
+  }
+  lds_barrier();
+  const int pos = bins[24 + my_bin] + atomicAdd(&bins[my_bin], -1) - 1;
+  place[tid] = pos;
+  cursor[pos] = my_deg;  // in-degree per placed row (scanned below)
+  if (my_deg > 0) atomicMax(&tilemax[pos >> 4], my_deg > 255 ? 255 : my_deg);
+  r_rowatom[pos] = my_real ? my_id : -1;  // out-of-range ids (incl. negative) read as a zero row in the encoder
+  r_poolrow[tid] = (uint16_t)(pos | ((my_real && my_id > 0) ? 0x8000 : 0));
+  lds_barrier();
+
+  // P3: exclusive scan of the placed in-degrees -> rowptr; cursor = fill position
+  {
+    const int my_cnt = cursor[tid];
+    int incl = my_cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) scratch[wave] = incl;
+    lds_barrier();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += scratch[w];
+    const int excl = off + incl - my_cnt;
+    rowptr[tid] = excl;
+    cursor[tid] = excl;
+    r_rowptr[tid] = (uint16_t)excl;
+    if (tid == kRCap - 1) {
+      rowptr[kRCap] = excl + my_cnt;
+      r_rowptr[kRCap] = (uint16_t)(excl + my_cnt);
+    }
+    if (tid < 16) r_tilemax[tid] = (unsigned char)tilemax[tid];
+  }
+  lds_barrier();
+
+  // P4: fill.  entry = edge slot (16b) | bond id (8b) | placed source row (8b); the slot in the top
+  //     bits lets P5 restore edge-slot order, so the accumulation order is fixed run to run.
+#pragma unroll
+  for (int k = 0; k < kSC; ++k)
+    if (edge_valid(sst[k].x, sst[k].y, sbid[k], N, p.Vb)) {
+      const int mo = moloff[sm[k]];
+      const int at = atomicAdd(&cursor[place[mo + sst[k].y]], 1);
+      ent2[at] = ((uint32_t)se[k] << 16) | ((uint32_t)sbid[k] << 8) | (uint32_t)place[mo + sst[k].x];
+    }
+  for (int slot = tid + kSC * kRCap; slot < n_slots; slot += kRCap) {
+    const int m = slot / E, e = slot - m * E;
+    const int64_t b = m0 + m;
+    const int2 st = *reinterpret_cast<const int2*>(conn_g + (b * E + e) * 2);
+    const int bid = bond_g[b * E + e];
+    if (edge_valid(st.x, st.y, bid, N, p.Vb)) {
+      const int mo = moloff[m];
+      const int at = atomicAdd(&cursor[place[mo + st.y]], 1);
+      ent2[at] = ((uint32_t)e << 16) | ((uint32_t)bid << 8) | (uint32_t)place[mo + st.x];
+    }
+  }
+  lds_barrier();
+
+  // P5: every row's in-edge list in edge-slot order: entry-parallel rank sort, straight into the record
+  {
+    const int total = rowptr[kRCap];
+    for (int i = tid; i < total; i += kRCap) {
+      int lo = 0, hi = kRCap - 1;  // largest row with rowptr[row] <= i
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rowptr[mid] <= i) lo = mid; else hi = mid - 1;
+      }
+      const int b0 = rowptr[lo], b1 = rowptr[lo + 1];
+      const uint32_t v = ent2[i];
+      int rank = 0;
+      for (int jx = b0; jx < b1; ++jx) rank += ent2[jx] < v;
+      r_ent[b0 + rank] = v;
+    }
+  }
+}
+
+}  // namespace
+
+int launch_weight_image(const ImageParams& ip, int S, hipStream_t s) {
+  if (S <= 0) return IMPNN_OK;
+  weight_image_kernel<<<dim3(16, S), 256, 0, s>>>(ip);
+  return check_launch("weight_image");
+}
+
+int launch_plan(const PlanParams& pp, hipStream_t s) {
+  plan_stats_kernel<<<pp.n_ions * pp.nblk, 64 * kPB, 0, s>>>(pp);
+  if (int rc = check_launch("plan_stats")) return rc;
+  const size_t lds = (size_t)pp.n_ions * (pp.nblk + 1) * sizeof(int32_t);
+  if (lds > 60 * 1024 || (int64_t)2 * pp.n_ions * pp.B / pp.nwg + 64 > kShareCap)
+    return fail(IMPNN_E_UNSUPPORTED, "encoder plan: batch of %d molecules per ion is too large", pp.B);
+  plan_shares_kernel<<<1, 256, lds, s>>>(pp);
+  if (int rc = check_launch("plan_shares")) return rc;
+  plan_chunks_kernel<<<pp.nwg * pp.max_sub, kRCap, 0, s>>>(pp);
+  return check_launch("plan_chunks");
+}
+
+}  // namespace enc
+}  // namespace impnn
