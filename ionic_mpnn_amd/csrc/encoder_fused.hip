@@ -157,9 +157,15 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
   unsigned long long t_pro = 0, t_steps = 0, t_pool = 0, t_mark = 0;
   if (stamp && tid == 0) t_mark = __builtin_amdgcn_s_memtime();
 
+  // The record of the NEXT chunk travels in two registers per thread while the current chunk runs;
+  // the step-0 weight image of the next chunk (same ion: a share never mixes ions) is what the last
+  // step's image prefetch brings in.  A chunk prologue is then one dependent load stage (atom rows).
+  uint2 rec_next = reinterpret_cast<const uint2*>(p.rec + (size_t)c_begin * kRecBytes)[tid];
+  int4 dsc_next = reinterpret_cast<const int4*>(p.desc)[c_begin];
+  bool image_ready = false;
   for (int c = c_begin; c < c_end; ++c) {
     // ---- chunk prologue: descriptor, record -> LDS, h0 = atom_table[atom ids], step-0 weights
-    const int4 dsc = reinterpret_cast<const int4*>(p.desc)[c];
+    const int4 dsc = dsc_next;
     // workgroup-uniform: keep them in SGPRs so every loop bound / branch below stays scalar
     const int m0 = __builtin_amdgcn_readfirstlane(dsc.x), M = __builtin_amdgcn_readfirstlane(dsc.y);
     const int rg = __builtin_amdgcn_readfirstlane(dsc.w);
@@ -168,16 +174,19 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
     const int N = p.N;
     const int32_t* ids_g = p.atom_ids[g];
     const float* img_g = p.img[g];
+    reinterpret_cast<uint2*>(recl)[tid] = rec_next;  // kRecBytes == 8 * kThreads
     {
-      const uint2* src = reinterpret_cast<const uint2*>(p.rec + (size_t)c * kRecBytes);
-      reinterpret_cast<uint2*>(recl)[tid] = src[tid];  // kRecBytes == 8 * kThreads
+      const int cn = (c + 1) < c_end ? (c + 1) : c;  // clamped: unconditional loads
+      rec_next = reinterpret_cast<const uint2*>(p.rec + (size_t)cn * kRecBytes)[tid];
+      dsc_next = reinterpret_cast<const int4*>(p.desc)[cn];
     }
     f32x4 pf[kPf];
-    if (p.S > 0) {
+    const bool need_image = p.S > 0 && !image_ready;  // workgroup-uniform
+    if (need_image) {
 #pragma unroll
       for (int i = 0; i < kPf; ++i) pf[i] = ld4(img_g + 4 * (tid + i * kThreads));
     }
-    __syncthreads();
+    lds_barrier();
     {  // h0 (train_viscosity.py:171) for the placed row: 4 threads per row, 2 x 16 B each; slack rows: zeros
       const int row = tid >> 2, sub = tid & 3;
       const int id = r_rowatom[row];
@@ -191,11 +200,12 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
       st4(hbuf1 + row * kHS + 8 * sub, v0);
       st4(hbuf1 + row * kHS + 8 * sub + 4, v1);
     }
-    if (p.S > 0) {
+    if (need_image) {
 #pragma unroll
       for (int i = 0; i < kPf; ++i) st4(wimg + 4 * (tid + i * kThreads), pf[i]);
     }
-    __syncthreads();
+    image_ready = p.S > 0;  // from now on the last step leaves the step-0 image behind
+    lds_barrier();
     if (stamp && tid == 0) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
       t_pro += t - t_mark;
@@ -206,7 +216,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
     for (int s = 0; s < p.S; ++s) {
       const float* hcur = (s & 1) ? hbuf1 : hbuf0;
       float* hnext = (s & 1) ? hbuf0 : hbuf1;
-      const int sn = (s + 1) < p.S ? (s + 1) : s;  // the last step re-reads its own image: no branch
+      const int sn = (s + 1) < p.S ? (s + 1) : 0;  // the last step fetches the step-0 image for the next chunk
       const float* nxt = img_g + (int64_t)sn * kImgSlot;
       bool pf_issued = false;
 
@@ -453,26 +463,29 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
       t_mark = t;
     }
 
-    // ---- GlobalSumPool (models/layers.py:161-164): rows whose atom id > 0.  Four lanes share one
-    //      (molecule, 4 features): each sums every 4th row in ascending order, then a fixed 2-step
-    //      butterfly - a wavefront segmented reduction with a run-to-run fixed order.
+    // ---- GlobalSumPool (models/layers.py:161-164): rows whose atom id > 0.  Eight lanes share one
+    //      (molecule, 4 features): each sums every 8th row in ascending order, then a fixed 3-step
+    //      butterfly on the DPP network - a wavefront segmented reduction with a run-to-run fixed order.
     const float* hfin = (p.S & 1) ? hbuf1 : hbuf0;
     float* out_g = p.pooled[g];
-    for (int t0 = 0; t0 < M * 32; t0 += kThreads) {
+    for (int t0 = 0; t0 < M * 64; t0 += kThreads) {
       const int t = t0 + tid;
-      const int part = t & 3, f4 = (t >> 2) & 7, m = t >> 5;
+      const int part = t & 7, f4 = (t >> 3) & 7, m = t >> 6;
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       if (m < M) {
         const int nr = r_molrows[m], mo = r_moloff[m];
-        for (int n = part; n < nr; n += 4) {
+        for (int n = part; n < nr; n += 8) {
           const int pr = r_poolrow[mo + n];
           if (pr & 0x8000) acc += ld4(hfin + (pr & 0xff) * kHS + 4 * f4);
         }
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        acc[i] += __shfl_xor(acc[i], 1);
-        acc[i] += __shfl_xor(acc[i], 2);
+        float v = acc[i];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror: lane ^ 7 within 8
+        acc[i] = v;
       }
       if (m < M && part == 0) st4(out_g + (int64_t)(m0 + m) * kD + 4 * f4, acc);
     }
