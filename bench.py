@@ -98,6 +98,10 @@ def main():
     ap.add_argument("--mp-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--schedule", choices=["fused", "layered"], default="fused")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="enqueue the plan kernels of step i+1 on a side stream before the encoder of step i "
+                         "(default: plan and encode every batch back to back on one stream, which is faster on "
+                         "MI355X: the encoder fills every CU's register file, see include/impnn.h)")
     ap.add_argument("--mode", choices=["auto", "f32", "f16x2"], default="auto",
                     help="GEMM arithmetic of the fused encoder (include/impnn.h); auto = f16x2 when the static "
                          "range bound holds, else exact f32")
@@ -132,8 +136,16 @@ def main():
     d_in = {k: torch.from_numpy(v).to(dev) for k, v in inputs.items()}  # resident in HBM before timing
     fused = args.schedule == "fused"
 
+    pipelined = fused and args.pipeline and S > 0
+    state = {"plan": m.plan_batch(d_in) if pipelined else None}
+
     def step():
-        return m.encode_pooled(d_in, fused=fused)
+        if not pipelined:
+            return m.encode_pooled(d_in, fused=fused)
+        nxt = m.plan_batch(d_in)  # the next step's batch (same synthetic graphs, planned again from scratch)
+        out = m.encode_pooled(d_in, plan=state["plan"])
+        state["plan"] = nxt
+        return out
 
     lib = _lib.load()
     for _ in range(args.warmup):
@@ -197,6 +209,8 @@ def main():
                                   "f32": "exact f32 products on v_mfma_f32_16x16x4_f32",
                                   "layered": "f32 VALU, one launch per reference layer"}[mode_used],
                    "mode": mode_used,
+                   "pipeline": ("plan kernels of step i+1 run on a side stream under the encoder of step i; every "
+                                "step still plans and encodes one full batch") if pipelined else "none",
                    "global_batch": int(total_pairs), "parallelism": f"batch-sharded x{world}, weights replicated, "
                    "no data-path collective; one all-reduce of the fingerprint checksum after the timed region",
                    "checksum": float(local_sum[0].item())},

@@ -146,6 +146,25 @@ int impnn_encoder_fused_prepared(int32_t n_ions, const int32_t* const* atom_ids,
                                  int32_t K, int32_t S, float ln_eps, void* workspace,
                                  size_t workspace_bytes, impnn_stream_t stream);
 
+/* ---- a9 in two halves, for callers that pipeline batches.  impnn_encoder_plan runs only the
+ *      graph-dependent plan kernels (row counts, shares, chunk records) of a batch into `workspace`;
+ *      impnn_encoder_run runs only the encoder kernel from a planned workspace.  The plan needs no
+ *      weights, so a caller may plan batch i+1 (any stream) before or while batch i is encoded and
+ *      order the two with events; every batch in flight needs its own workspace.  Measured on
+ *      MI355X: the encoder's 16 waves x 128 VGPRs fill the register file of every CU, so plan kernels
+ *      enqueued beside it mostly wait for a CU to drain - the split buys ordering freedom (e.g. planning
+ *      on an idle queue during host work), not overlap with the encoder itself.
+ *      impnn_encoder_fused_prepared(...) == impnn_encoder_plan(...) then impnn_encoder_run(...). */
+int impnn_encoder_plan(int32_t n_ions, const int32_t* const* atom_ids, const int32_t* const* bond_ids,
+                       const int32_t* const* conn, int32_t B, int32_t N, int32_t E, int32_t D,
+                       int32_t K, int32_t S, int32_t Vb, void* workspace, size_t workspace_bytes,
+                       impnn_stream_t stream);
+int impnn_encoder_run(int32_t n_ions, const int32_t* const* atom_ids, const float* atom_table,
+                      int32_t Va, const float* bond_table, int32_t Vb, const void* const* prepared,
+                      int32_t mode, float* const* pooled, int32_t B, int32_t N, int32_t E, int32_t D,
+                      int32_t K, int32_t S, float ln_eps, void* workspace, size_t workspace_bytes,
+                      impnn_stream_t stream);
+
 /* ---- measurement: HIP-event timing of the dominant kernel (encoder_fused_kernel), recorded on the
  *      stream the kernel is launched on.  After impnn_profile_enable(capacity) every
  *      impnn_encoder_fused call of this thread records one (start, stop) event pair around that

@@ -36,6 +36,10 @@ SIGNATURES = {
     "impnn_encoder_fused_prepared": (C.c_int, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, i32, vp, i32,
                                                C.POINTER(vp), i32, C.POINTER(vp), i32, i32, i32, i32, i32, i32, f32,
                                                vp, sz, vp]),
+    "impnn_encoder_plan": (C.c_int, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i32, i32,
+                                     i32, vp, sz, vp]),
+    "impnn_encoder_run": (C.c_int, [i32, C.POINTER(vp), vp, i32, vp, i32, C.POINTER(vp), i32, C.POINTER(vp), i32, i32,
+                                    i32, i32, i32, i32, f32, vp, sz, vp]),
     "impnn_validate_indices": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "impnn_profile_enable": (C.c_int, [i32]),
     "impnn_profile_collect": (C.c_int, [C.POINTER(C.c_float), i32, C.POINTER(i32)]),

@@ -164,7 +164,7 @@ static int encoder_common(const char* fn, int32_t n_ions, const int32_t* const* 
                           int32_t Va, const float* bond_table, int32_t Vb, const float* const* weights,
                           const void* const* prepared, int32_t mode, float* const* pooled, int32_t B, int32_t N,
                           int32_t E, int32_t D, int32_t K, int32_t S, float ln_eps, void* workspace,
-                          size_t workspace_bytes, impnn_stream_t stream) {
+                          size_t workspace_bytes, impnn_stream_t stream, int phases = 3) {
 #define REQ(cond, what)                                           \
   do {                                                            \
     if (!(cond)) return fail(IMPNN_E_BADARG, "%s: %s", fn, what); \
@@ -172,7 +172,9 @@ static int encoder_common(const char* fn, int32_t n_ions, const int32_t* const* 
   REQ(n_ions >= 1 && n_ions <= 2, "n_ions must be 1 or 2");
   REQ(mode == 0 || mode == 1, "mode must be 0 (f32) or 1 (f16x2)");
   REQ(B >= 0 && N > 0 && E >= 0 && D > 0 && K > 0 && S >= 0 && Va > 0 && Vb > 0, "bad shape");
-  REQ(atom_ids && bond_ids && conn && (weights || prepared) && pooled && atom_table && bond_table, "null pointer");
+  const bool planning = (phases & 1) != 0, running = (phases & 2) != 0;
+  REQ(atom_ids && (!planning || (bond_ids && conn)), "null pointer");
+  REQ(!running || ((weights || prepared) && pooled && atom_table && bond_table), "null pointer");
   if (!encoder_fused_supported(N, E, D, K, S, Vb))
     return fail(IMPNN_E_UNSUPPORTED, "encoder_fused: shape N=%d E=%d D=%d K=%d S=%d Vb=%d not covered", N, E, D,
                 K, S, Vb);
@@ -180,15 +182,18 @@ static int encoder_common(const char* fn, int32_t n_ions, const int32_t* const* 
   EncoderArgs a{};
   a.n_ions = n_ions;
   a.mode = mode;
+  a.phases = phases;
   for (int g = 0; g < n_ions; ++g) {
-    const bool have_w = S == 0 || (prepared && prepared[g]) || (weights && weights[g]);
-    REQ(atom_ids[g] && pooled[g] && (E == 0 || (bond_ids[g] && conn[g])) && have_w, "null per-ion pointer");
+    const bool have_w = !running || S == 0 || (prepared && prepared[g]) || (weights && weights[g]);
+    REQ(atom_ids[g] && have_w, "null per-ion pointer");
+    REQ(!planning || E == 0 || (bond_ids[g] && conn[g]), "null per-ion pointer");
+    REQ(!running || pooled[g], "null per-ion pointer");
     a.atom_ids[g] = atom_ids[g];
-    a.bond_ids[g] = bond_ids[g];
-    a.conn[g] = conn[g];
+    a.bond_ids[g] = bond_ids ? bond_ids[g] : nullptr;
+    a.conn[g] = conn ? conn[g] : nullptr;
     a.weights[g] = weights ? weights[g] : nullptr;
     a.prepared[g] = prepared ? prepared[g] : nullptr;
-    a.pooled[g] = pooled[g];
+    a.pooled[g] = pooled ? pooled[g] : nullptr;
   }
 #undef REQ
   a.atom_table = atom_table;
@@ -210,6 +215,21 @@ int impnn_encoder_fused(int32_t n_ions, const int32_t* const* atom_ids, const in
                         float ln_eps, void* workspace, size_t workspace_bytes, impnn_stream_t stream) {
   return encoder_common(__func__, n_ions, atom_ids, bond_ids, conn, atom_table, Va, bond_table, Vb, weights, nullptr,
                         encoder_mode(), pooled, B, N, E, D, K, S, ln_eps, workspace, workspace_bytes, stream);
+}
+
+int impnn_encoder_plan(int32_t n_ions, const int32_t* const* atom_ids, const int32_t* const* bond_ids,
+                       const int32_t* const* conn, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K, int32_t S,
+                       int32_t Vb, void* workspace, size_t workspace_bytes, impnn_stream_t stream) {
+  return encoder_common(__func__, n_ions, atom_ids, bond_ids, conn, nullptr, 1, nullptr, Vb, nullptr, nullptr, 0,
+                        nullptr, B, N, E, D, K, S, 0.f, workspace, workspace_bytes, stream, 1);
+}
+
+int impnn_encoder_run(int32_t n_ions, const int32_t* const* atom_ids, const float* atom_table, int32_t Va,
+                      const float* bond_table, int32_t Vb, const void* const* prepared, int32_t mode,
+                      float* const* pooled, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K, int32_t S,
+                      float ln_eps, void* workspace, size_t workspace_bytes, impnn_stream_t stream) {
+  return encoder_common(__func__, n_ions, atom_ids, nullptr, nullptr, atom_table, Va, bond_table, Vb, nullptr,
+                        prepared, mode, pooled, B, N, E, D, K, S, ln_eps, workspace, workspace_bytes, stream, 2);
 }
 
 size_t impnn_encoder_prepared_bytes(int32_t S) { return encoder_prepared_bytes(S); }

@@ -64,6 +64,7 @@ struct EncoderArgs {
   const float* weights[2];   // canonical packed step weights (used when prepared[g] is null)
   const void* prepared[2];   // impnn_encoder_prepare_weights output for `mode`, or null
   int mode;                  // 0 f32, 1 f16x2
+  int phases;                // bit 0: plan kernels, bit 1: encoder kernel
   float* pooled[2];
   const float* atom_table;
   const float* bond_table;
@@ -75,6 +76,7 @@ struct EncoderArgs {
 bool encoder_fused_supported(int N, int E, int D, int K, int S, int Vb);
 size_t encoder_fused_workspace_bytes(int n_ions, int B, int N, int E, int D, int K, int S, int Vb);
 int launch_encoder_fused(const EncoderArgs& a, hipStream_t s);
+int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase);
 size_t encoder_prepared_bytes(int S);
 int launch_encoder_prepare(const float* weights, int D, int K, int S, int mode, void* prepared, hipStream_t s);
 

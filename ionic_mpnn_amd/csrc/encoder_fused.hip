@@ -115,8 +115,10 @@ __device__ __forceinline__ void mma3(f32x4& acc, const _Float16* blk, int lane, 
   acc = mfma16(al, b.hi, acc);
 }
 
-constexpr size_t kLdsBytes = sizeof(float) * ((size_t)kImgSlot + 2 * kRCap * kHS + kTbCapFloats) + kRecBytes;
-static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+// image | h (2 buffers) | chunk record | bond table (Vb*8 floats, sized at launch so that the plan
+// kernels of the next batch still find LDS on the same CU)
+constexpr size_t kLdsFixedBytes = sizeof(float) * ((size_t)kImgSlot + 2 * kRCap * kHS) + kRecBytes;
+static_assert(kLdsFixedBytes + sizeof(float) * kTbCapFloats <= 160 * 1024, "LDS budget");
 
 // KT = compile-time bond_dim (0: run-time K <= 8); SPLIT: mode 1 (fp16 hi/lo products)
 template <int KT, bool SPLIT>
@@ -126,8 +128,8 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
   float* const wimg = smem;
   float* const hbuf0 = wimg + kImgSlot;
   float* const hbuf1 = hbuf0 + kRCap * kHS;
-  float* const tbl = hbuf1 + kRCap * kHS;
-  unsigned char* const recl = reinterpret_cast<unsigned char*>(tbl + kTbCapFloats);
+  unsigned char* const recl = reinterpret_cast<unsigned char*>(hbuf1 + kRCap * kHS);
+  float* const tbl = reinterpret_cast<float*>(recl + kRecBytes);
   const uint16_t* const r_rowptr = reinterpret_cast<const uint16_t*>(recl + kRecRowptr);
   const unsigned char* const r_tilemax = recl + kRecTilemax;
   const uint16_t* const r_moloff = reinterpret_cast<const uint16_t*>(recl + kRecMoloff);
@@ -551,6 +553,14 @@ int launch_encoder_prepare(const float* weights, int D, int K, int S, int mode, 
 }
 
 int launch_encoder_fused(const EncoderArgs& a, hipStream_t s) {
+  if (a.phases & 1)
+    if (int rc = launch_encoder_phase(a, s, true)) return rc;
+  if (a.phases & 2)
+    if (int rc = launch_encoder_phase(a, s, false)) return rc;
+  return IMPNN_OK;
+}
+
+int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
   using namespace enc;
   const Ws w = ws_layout(a.n_ions, a.B, a.N, a.E, a.K, a.S, encoder_workgroups());
   if (!aligned16(a.workspace)) return fail(IMPNN_E_BADARG, "encoder_fused: workspace must be 16B aligned");
@@ -560,12 +570,13 @@ int launch_encoder_fused(const EncoderArgs& a, hipStream_t s) {
   PlanParams pp{};
   EncParams ep{};
   for (int g = 0; g < a.n_ions; ++g) {
-    if ((reinterpret_cast<uintptr_t>(a.conn[g]) & 7u) != 0)
+    if (plan_phase && (reinterpret_cast<uintptr_t>(a.conn[g]) & 7u) != 0)
       return fail(IMPNN_E_BADARG, "encoder_fused: connectivity must be 8B aligned");
     pp.atom_ids[g] = ep.atom_ids[g] = a.atom_ids[g];
     pp.bond_ids[g] = a.bond_ids[g];
     pp.conn[g] = a.conn[g];
     ep.pooled[g] = a.pooled[g];
+    if (plan_phase) continue;
     if (a.prepared[g]) {
       if (!aligned16(a.prepared[g])) return fail(IMPNN_E_BADARG, "encoder_fused: prepared weights must be 16B aligned");
       ep.img[g] = static_cast<const float*>(a.prepared[g]);
@@ -586,7 +597,7 @@ int launch_encoder_fused(const EncoderArgs& a, hipStream_t s) {
   pp.nwg = w.nwg;
   pp.max_sub = w.max_sub;
   pp.nblk = w.nblk;
-  if (int rc = launch_plan(pp, s)) return rc;
+  if (plan_phase) return launch_plan(pp, s);
 
   ep.atom_table = a.atom_table;
   ep.bond_table = a.bond_table;
@@ -611,7 +622,8 @@ int launch_encoder_fused(const EncoderArgs& a, hipStream_t s) {
     attr_set[variant] = true;
   }
   profile_record_start(s);
-  kern<<<w.nwg, kThreads, kLdsBytes, s>>>(ep);
+  const size_t lds = kLdsFixedBytes + align_up((size_t)a.Vb * kKMax * sizeof(float), 512);
+  kern<<<w.nwg, kThreads, lds, s>>>(ep);
   profile_record_stop(s);
   return check_launch("encoder_fused");
 }

@@ -26,6 +26,9 @@ namespace {
 // -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * kPB) void plan_stats_kernel(PlanParams p) {
   __shared__ int vsum[kPB];
+  // Plan kernels are short chains of dependent loads; when they run beside the issue-bound encoder of
+  // the previous batch (pipelined callers) they must not queue behind its waves for every instruction.
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int g = blockIdx.x / p.nblk, blk = blockIdx.x - g * p.nblk;
   const int b = blk * kPB + wv;
@@ -172,6 +175,7 @@ __global__ void weight_image_kernel(ImageParams p) {
 __global__ __launch_bounds__(256) void plan_shares_kernel(PlanParams p) {
   extern __shared__ int32_t bp[];  // [n_ions][nblk + 1] exclusive prefix of the partial sums
   __shared__ int tot_s[2], nwg_s[2];
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int nblk = p.nblk;
   if (wv < p.n_ions) {
@@ -241,14 +245,16 @@ __global__ __launch_bounds__(256) void plan_shares_kernel(PlanParams p) {
 // plan_chunks: 256 threads (= kRCap: one per row) per chunk.
 // -----------------------------------------------------------------------------------------
 constexpr int kDegBins = 18;    // in-degree 0..15, ">= 16", and "row beyond the chunk" (placed last)
-constexpr int kShareCap = 2048;  // molecules of one share resolved in LDS
+constexpr int kShareCap = kECap;  // molecules of one share resolved in LDS (aliases the entry buffer)
 
 __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
   __shared__ int32_t moloff[kRCap + 2], molrows[kRCap], cnt[kRCap], place[kRCap], cursor[kRCap], rowptr[kRCap + 2];
   __shared__ int32_t bins[48], tilemax[16], scratch[8];
-  __shared__ uint32_t ent2[kECap];
-  __shared__ int32_t shst[kShareCap + 1];  // virtual-row prefix of the share's molecules (+ end)
+  __shared__ uint32_t ent2[kECap + 1];
+  int32_t* const shst = reinterpret_cast<int32_t*>(ent2);  // virtual-row prefix of the share's molecules (+ end),
+                                                           // dead before ent2 is filled (moloff keeps what is needed)
   __shared__ int chunk_s[4];              // first molecule (share-local), molecules, rows, chunks in the share
+  __builtin_amdgcn_s_setprio(3);
   const int j = blockIdx.x / p.max_sub, slot_i = blockIdx.x - j * p.max_sub;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int4 shr = reinterpret_cast<const int4*>(p.share)[j];

@@ -206,8 +206,25 @@ class MPNNModel:
             trace[f"{prefix}/pooled"] = pooled
         return pooled
 
-    def encode_pooled(self, inputs, fused=None, trace=None):
+    def plan_batch(self, inputs):
+        """Enqueues the graph-only plan of a batch on a side stream (ops.EncoderPipeline) and returns
+        a handle for ``encode_pooled(inputs, plan=handle)``.  Call it for batch i+1 before encoding
+        batch i: the plan then runs underneath the encoder of batch i."""
+        if getattr(self, "_pipeline", None) is None:
+            self._pipeline = ops.EncoderPipeline(self.device)
+        ions = [(inputs["cat_atom"], inputs["cat_bond"], inputs["cat_connectivity"]),
+                (inputs["an_atom"], inputs["an_bond"], inputs["an_connectivity"])]
+        return self._pipeline.plan(ions, self.atom_dim, self.bond_dim, self.num_steps, self.bond_vocab_size)
+
+    def encode_pooled(self, inputs, fused=None, trace=None, plan=None):
         """Both ions' GlobalSumPool outputs: the hot path."""
+        if plan is not None:
+            mode = self.resolve_encoder_mode(plan.shape[2])
+            pc, pa = self._pipeline.run(plan, self.atom_emb.embeddings, self.bond_emb.embeddings,
+                                        self._prepared_weights(mode), mode=mode)
+            if trace is not None:
+                trace["cat/pooled"], trace["an/pooled"] = pc, pa
+            return pc, pa
         ca, cb, cc = inputs["cat_atom"], inputs["cat_bond"], inputs["cat_connectivity"]
         aa, ab, ac = inputs["an_atom"], inputs["an_bond"], inputs["an_connectivity"]
         if fused is None:

@@ -315,3 +315,81 @@ def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=L
             check(lib.impnn_encoder_fused(n, *common, mk(ws_w), mk(pooled), B, N, E, D, K, S, float(eps), ptr(ws),
                                           ws.numel(), stream_ptr()))
     return pooled
+
+
+# ---------------------------------------------------------------------------------------------
+# pipelined use: plan of batch i+1 on a side stream while batch i is being encoded
+# ---------------------------------------------------------------------------------------------
+class EncoderPlan:
+    """A planned batch: its workspace, the event that marks the plan complete, and the shapes."""
+    __slots__ = ("slot", "ready", "ions", "shape", "n_ions")
+
+
+class EncoderPipeline:
+    """Two (or more) plan workspaces and a side stream.  ``plan()`` enqueues the graph-only plan
+    kernels of a batch on the side stream; ``run()`` enqueues the encoder kernel on torch's current
+    stream after the plan's event.  A workspace is reused only after the run that read it is done
+    (event-ordered, no host synchronisation)."""
+
+    def __init__(self, device, depth=2):
+        self.device = torch.device(device)
+        self.side = torch.cuda.Stream(device=self.device)
+        self.slots = [{"ws": None, "done": None} for _ in range(depth)]
+        self.next = 0
+
+    def plan(self, ions, D, K, S, Vb):
+        n = len(ions)
+        prep = []
+        for (a, b, c) in ions:
+            require_gpu(a, b, c)
+            prep.append((i32c(a), i32c(b), i32c(c)))
+        B, N = prep[0][0].shape
+        E = prep[0][1].shape[1]
+        lib = _lib.load()
+        need = C.c_size_t(0)
+        rc = lib.impnn_encoder_workspace_bytes(n, B, N, E, D, K, S, Vb, C.byref(need))
+        if rc == _lib.IMPNN_E_UNSUPPORTED:
+            raise EncoderUnsupported(lib.impnn_last_error_string().decode())
+        check(rc)
+        slot = self.slots[self.next]
+        self.next = (self.next + 1) % len(self.slots)
+        if slot["ws"] is None or slot["ws"].numel() < need.value:
+            slot["ws"] = torch.empty(max(need.value, 1 << 20), dtype=torch.uint8, device=self.device)
+        arr = C.c_void_p * n
+        mk = lambda ts: arr(*[t.data_ptr() for t in ts])
+        cur = torch.cuda.current_stream(self.device)
+        self.side.wait_stream(cur)  # the inputs were produced on the current stream
+        if slot["done"] is not None:
+            self.side.wait_event(slot["done"])  # the encoder that last read this workspace
+        with torch.cuda.device(self.device), torch.cuda.stream(self.side):
+            check(lib.impnn_encoder_plan(n, mk([p[0] for p in prep]), mk([p[1] for p in prep]), mk([p[2] for p in prep]),
+                                         B, N, E, D, K, S, Vb, ptr(slot["ws"]), slot["ws"].numel(),
+                                         C.c_void_p(self.side.cuda_stream)))
+            ready = torch.cuda.Event()
+            ready.record(self.side)
+        for trio in prep:
+            for t in trio:
+                t.record_stream(self.side)
+        h = EncoderPlan()
+        h.slot, h.ready, h.ions, h.shape, h.n_ions = slot, ready, prep, (B, N, E, D, K, S, Vb), n
+        return h
+
+    def run(self, plan, atom_table, bond_table, prepared, mode="f16x2", eps=LN_EPS):
+        B, N, E, D, K, S, Vb = plan.shape
+        n = plan.n_ions
+        atom_table, bond_table = f32c(atom_table), f32c(bond_table)
+        lib = _lib.load()
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(plan.ready)
+        pooled = [torch.empty(B, D, dtype=torch.float32, device=self.device) for _ in range(n)]
+        arr = C.c_void_p * n
+        mk = lambda ts: arr(*[t.data_ptr() for t in ts])
+        ws = plan.slot["ws"]
+        with torch.cuda.device(self.device):
+            check(lib.impnn_encoder_run(n, mk([p[0] for p in plan.ions]), ptr(atom_table), atom_table.shape[0],
+                                        ptr(bond_table), Vb, mk(prepared), ENCODER_MODES[mode], mk(pooled), B, N, E, D,
+                                        K, S, float(eps), ptr(ws), ws.numel(), stream_ptr()))
+            done = torch.cuda.Event()
+            done.record(cur)
+        plan.slot["done"] = done
+        return pooled

@@ -196,6 +196,24 @@ def test_prepared_and_per_call_weight_images_agree_bitwise(mode):
     assert_close(a[0].cpu().numpy(), outs["cat/pooled"], what="cat pooled")
 
 
+def test_pipelined_plan_run_matches_single_call(full):
+    """impnn_encoder_plan on a side stream + impnn_encoder_run == the one-call path, bit for bit, also when
+    two planned batches are in flight and run out of order of planning."""
+    inp, w, m, d, pc, pa = full
+    half = {k: v[:2000].contiguous() for k, v in d.items()}
+    h_full = m.plan_batch(d)
+    h_half = m.plan_batch(half)
+    c2, a2 = m.encode_pooled(half, plan=h_half)
+    c1, a1 = m.encode_pooled(d, plan=h_full)
+    assert torch.equal(c1, pc) and torch.equal(a1, pa)
+    assert torch.equal(c2, pc[:2000]) and torch.equal(a2, pa[:2000])
+    for _ in range(5):  # steady-state pipelining loop as in bench.py
+        nxt = m.plan_batch(d)
+        c, a = m.encode_pooled(d, plan=h_full)
+        h_full = nxt
+        assert torch.equal(c, pc) and torch.equal(a, pa)
+
+
 def test_auto_mode_uses_static_range_bound():
     """auto = f16x2 only when the LayerNorm / in-degree bound keeps every operand inside fp16 range."""
     w = weights.init_weights("viscosity", synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, num_steps=3, seed=1)
