@@ -14,6 +14,19 @@ namespace {
 
 constexpr int kBlock = 256;
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t ldv4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
+__device__ __forceinline__ f32x4_t mfma_f32(float a, float b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float fsig(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * x));
+}
+__device__ __forceinline__ float ftanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177793f * x));
+}
+
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ---------------------------------------------------------------------------------------
@@ -133,6 +146,140 @@ __global__ void bmm_message_typed_kernel(const float* __restrict__ h, const int3
 }
 
 // ---------------------------------------------------------------------------------------
+// a4 from bond ids for D = 32 (schedule A) on the matrix cores.
+// A workgroup takes kTM molecules, counting-sorts their valid edges by bond type in LDS and cuts
+// every type's run into tiles of 16 edges; a tile is the GEMM  m^T (32x16) = A_type (32x32) * h_src^T
+// (32x16) on v_mfma_f32_16x16x4_f32 (exact f32), with A_type fetched once per tile from L2 instead of
+// once per edge.  Masked / out-of-range edges get zero rows (models/layers.py:114-115).
+// ---------------------------------------------------------------------------------------
+constexpr int kTM = 32;          // molecules per workgroup
+constexpr int kTSlots = 4096;    // edge slots per workgroup held in LDS (kTM * E)
+constexpr int kTVb = 1024;       // bond types handled by the LDS histogram
+
+__global__ __launch_bounds__(512) void bmm_message_typed_d32_kernel(
+    const float* __restrict__ h, const int32_t* __restrict__ bond_ids, const int32_t* __restrict__ conn,
+    const float* __restrict__ A, float* __restrict__ m_out, int B, int N, int E, int Vb) {
+  constexpr int D = 32;
+  __shared__ int32_t hist[kTVb + 1], cursor[kTVb], tbase[kTVb + 1];
+  __shared__ uint32_t sorted[kTSlots];
+  __shared__ uint16_t tile_type[kTSlots / 16 + kTVb];
+  __shared__ int32_t wtot[8], carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x * kTM;
+  const int nm = (B - b0) < kTM ? (B - b0) : kTM;
+  const int n_slots = nm * E;
+  for (int t = tid; t <= Vb; t += blockDim.x) hist[t] = 0;
+  __syncthreads();
+  // pass 1: classify every edge slot; zero rows for masked edges; histogram of types
+  for (int slot = tid; slot < n_slots; slot += blockDim.x) {
+    const int ml = slot / E, e = slot - ml * E;
+    const int64_t g = (int64_t)(b0 + ml) * E + e;
+    const int2 st = *reinterpret_cast<const int2*>(conn + g * 2);
+    const int ty = bond_ids[g];
+    const bool ok = st.x > 0 && st.y > 0 && st.x < N && st.y < N && (unsigned)ty < (unsigned)Vb;
+    if (ok) {
+      atomicAdd(&hist[ty], 1);
+    } else {
+      f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+      float* o = m_out + g * D;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4_t*>(o + 4 * i) = z;
+    }
+  }
+  __syncthreads();
+  // exclusive scans over types: edge offsets (hist -> cursor) and tile offsets (tbase)
+  {
+    const int per = (Vb + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int t0 = tid * per, t1 = (t0 + per) < Vb ? (t0 + per) : Vb;
+    int le = 0, lt = 0;
+    for (int t = t0; t < t1; ++t) {
+      le += hist[t];
+      lt += (hist[t] + 15) >> 4;
+    }
+    int ie = le, it = lt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int ue = __shfl_up(ie, o), ut = __shfl_up(it, o);
+      if (lane >= o) {
+        ie += ue;
+        it += ut;
+      }
+    }
+    if (lane == 63) wtot[wave] = (ie << 16) | it;  // <= 4096 edges, <= 1280 tiles: 16 bits each
+    __syncthreads();
+    int oe = 0, ot = 0;
+    for (int w = 0; w < wave; ++w) {
+      oe += wtot[w] >> 16;
+      ot += wtot[w] & 0xffff;
+    }
+    int re = oe + ie - le, rt = ot + it - lt;
+    for (int t = t0; t < t1; ++t) {
+      const int c = hist[t];
+      cursor[t] = re;
+      tbase[t] = rt;
+      for (int j = 0; j < ((c + 15) >> 4); ++j) tile_type[rt + j] = (uint16_t)t;
+      re += c;
+      rt += (c + 15) >> 4;
+    }
+    if (tid == (int)blockDim.x - 1) carry_s = rt;  // total tiles (last thread sees the full prefix)
+  }
+  __syncthreads();
+  // pass 2: scatter the valid edges into their type's run (order inside a run is irrelevant: every
+  // edge's row is computed independently)
+  for (int slot = tid; slot < n_slots; slot += blockDim.x) {
+    const int ml = slot / E, e = slot - ml * E;
+    const int64_t g = (int64_t)(b0 + ml) * E + e;
+    const int2 st = *reinterpret_cast<const int2*>(conn + g * 2);
+    const int ty = bond_ids[g];
+    if (st.x > 0 && st.y > 0 && st.x < N && st.y < N && (unsigned)ty < (unsigned)Vb) {
+      const int pos = atomicAdd(&cursor[ty], 1);
+      sorted[pos] = ((uint32_t)ml << 27) | ((uint32_t)e << 12) | (uint32_t)st.x;  // 5 | 15 | 12 bits
+    }
+  }
+  __syncthreads();
+  // tiles: contiguous ranges per wave, so consecutive tiles mostly share their type's matrix
+  const int ntile = carry_s, nw = blockDim.x >> 6;
+  const int a = lane & 15, q = lane >> 4;
+  int cur_ty = -1;
+  f32x4_t A0[2], A1[2];
+  for (int tile = (ntile * wave) / nw; tile < (ntile * (wave + 1)) / nw; ++tile) {
+    const int ty = tile_type[tile];
+    if (ty != cur_ty) {  // wave-uniform
+      cur_ty = ty;
+      const float* At = A + (int64_t)ty * D * D;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        A0[u] = ldv4(At + a * D + 16 * u + 4 * q);         // rows 0..15 of A_type, columns 16u+4q..
+        A1[u] = ldv4(At + (16 + a) * D + 16 * u + 4 * q);  // rows 16..31
+      }
+    }
+    const int run_end = cursor[ty];                 // after pass 2: one past the type's run
+    const int idx = run_end - hist[ty] + (tile - tbase[ty]) * 16 + a;
+    const bool live = idx < run_end;
+    const uint32_t ent = sorted[live ? idx : run_end - 1];
+    const int ml = ent >> 27, e = (ent >> 12) & 0x7fff, src = ent & 0xfff;
+    const float* hs = h + ((int64_t)(b0 + ml) * N + src) * D;
+    const f32x4_t x0 = ldv4(hs + 4 * q), x1 = ldv4(hs + 16 + 4 * q);
+    f32x4_t o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o0 = mfma_f32(A0[0][r], x0[r], o0);
+      o1 = mfma_f32(A1[0][r], x0[r], o1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      o0 = mfma_f32(A0[1][r], x1[r], o0);
+      o1 = mfma_f32(A1[1][r], x1[r], o1);
+    }
+    if (live) {
+      float* o = m_out + ((int64_t)(b0 + ml) * E + e) * D;
+      *reinterpret_cast<f32x4_t*>(o + 4 * q) = o0;
+      *reinterpret_cast<f32x4_t*>(o + 16 + 4 * q) = o1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // a5  Reduce.call (models/layers.py:57-83).  Thread (molecule, column) walks the E edge slots in
 // order and adds into its own column of agg[b] - no atomics, bitwise equal to a sequential
 // scatter_nd.  agg[b] lives in LDS when it fits, else directly in HBM/L2.
@@ -152,10 +299,31 @@ __global__ void reduce_scatter_kernel(const float* __restrict__ m, const int32_t
       for (int i = c0; i < D; i += cols) acc[(size_t)n * D + i] = 0.f;
     const float* mb = m + (int64_t)b * E * D;
     const int32_t* tb = tgt + (int64_t)b * E * tgt_stride;
-    for (int e = 0; e < E; ++e) {
-      const int t = tb[(int64_t)e * tgt_stride];
-      if (t > 0 && t < N)
-        for (int i = c0; i < D; i += cols) acc[(size_t)t * D + i] += mb[(int64_t)e * D + i];
+    if (cols == D) {  // one column per thread: keep 8 edge rows in flight; adds stay in edge-slot order
+      constexpr int kU = 8;
+      int e = 0;
+      for (; e + kU <= E; e += kU) {
+        float v[kU];
+        int t[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          v[u] = mb[(int64_t)(e + u) * D + c0];
+          t[u] = tb[(int64_t)(e + u) * tgt_stride];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+          if (t[u] > 0 && t[u] < N) acc[(size_t)t[u] * D + c0] += v[u];
+      }
+      for (; e < E; ++e) {
+        const int t = tb[(int64_t)e * tgt_stride];
+        if (t > 0 && t < N) acc[(size_t)t * D + c0] += mb[(int64_t)e * D + c0];
+      }
+    } else {
+      for (int e = 0; e < E; ++e) {
+        const int t = tb[(int64_t)e * tgt_stride];
+        if (t > 0 && t < N)
+          for (int i = c0; i < D; i += cols) acc[(size_t)t * D + i] += mb[(int64_t)e * D + i];
+      }
     }
     if (use_lds) {
       float* ab = agg + (int64_t)b * N * D;
@@ -236,6 +404,122 @@ __global__ void gated_update_kernel(const float* __restrict__ h, const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// a7 for D = 32 on the matrix cores (exact f32 products, v_mfma_f32_16x16x4_f32): 16 atom rows per
+// wave and iteration, atoms on the MFMA N dimension, features on M, so the gate accumulators are
+// directly the operands of the candidate GEMM and of LayerNorm (same scheme as encoder_fused.hip).
+// Weights are transposed into LDS once per workgroup ((gate, out) rows of 2D inputs, stride 68).
+// ---------------------------------------------------------------------------------------
+constexpr int kGuRS = 68;  // LDS row stride of the transposed gate kernels
+
+__global__ __launch_bounds__(256) void gated_update_d32_kernel(
+    const float* __restrict__ h, const float* __restrict__ agg, const float* __restrict__ Wz,
+    const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
+    const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float* __restrict__ out, int64_t rows) {
+  constexpr int D = 32;
+  __shared__ __align__(16) float wimg[3 * D * kGuRS + 5 * D];
+  for (int t = threadIdx.x; t < 3 * D * 2 * D; t += blockDim.x) {
+    const int gate = t / (2 * D * D), rem = t - gate * 2 * D * D;
+    const int jj = rem / D, io = rem - jj * D;  // keras kernel (in=jj, out=io), read coalesced along io
+    const float* Wg = gate == 0 ? Wz : (gate == 1 ? Wr : Wh);
+    wimg[(gate * D + io) * kGuRS + jj] = Wg[rem];
+  }
+  for (int t = threadIdx.x; t < 5 * D; t += blockDim.x) {
+    const int v = t / D, i = t - v * D;
+    const float* src = v == 0 ? bz : v == 1 ? br : v == 2 ? bh : v == 3 ? gamma : beta;
+    wimg[3 * D * kGuRS + t] = src[i];
+  }
+  __syncthreads();
+  const float* wvec = wimg + 3 * D * kGuRS;
+  const int lane = threadIdx.x & 63, a = lane & 15, q = lane >> 4;
+  const int64_t ntiles = (rows + 15) >> 4;
+  const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+  for (int64_t tile = wave_id; tile < ntiles; tile += nwaves) {
+    const int64_t row = tile * 16 + a;
+    const int64_t rl = row < rows ? row : rows - 1;  // clamped load address; the store is masked
+    const f32x4_t h0 = ldv4(h + rl * D + 4 * q), h1 = ldv4(h + rl * D + 16 + 4 * q);
+    const f32x4_t a0 = ldv4(agg + rl * D + 4 * q), a1 = ldv4(agg + rl * D + 16 + 4 * q);
+    f32x4_t z0 = ldv4(wvec + 4 * q), z1 = ldv4(wvec + 16 + 4 * q);
+    f32x4_t r0 = ldv4(wvec + D + 4 * q), r1 = ldv4(wvec + D + 16 + 4 * q);
+    f32x4_t t0 = ldv4(wvec + 2 * D + 4 * q), t1 = ldv4(wvec + 2 * D + 16 + 4 * q);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int col = 32 * half + 16 * u + 4 * q;
+        const f32x4_t Az0 = ldv4(wimg + (0 * D + a) * kGuRS + col), Az1 = ldv4(wimg + (0 * D + 16 + a) * kGuRS + col);
+        const f32x4_t Ar0 = ldv4(wimg + (1 * D + a) * kGuRS + col), Ar1 = ldv4(wimg + (1 * D + 16 + a) * kGuRS + col);
+        const f32x4_t Bv = half == 0 ? (u == 0 ? h0 : h1) : (u == 0 ? a0 : a1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          z0 = mfma_f32(Az0[r], Bv[r], z0);
+          z1 = mfma_f32(Az1[r], Bv[r], z1);
+          r0 = mfma_f32(Ar0[r], Bv[r], r0);
+          r1 = mfma_f32(Ar1[r], Bv[r], r1);
+        }
+      }
+    }
+    f32x4_t rh0, rh1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      z0[i] = fsig(z0[i]);
+      z1[i] = fsig(z1[i]);
+      rh0[i] = fsig(r0[i]) * h0[i];  // models/layers.py:149
+      rh1[i] = fsig(r1[i]) * h1[i];
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int col = 32 * half + 16 * u + 4 * q;
+        const f32x4_t Ah0 = ldv4(wimg + (2 * D + a) * kGuRS + col), Ah1 = ldv4(wimg + (2 * D + 16 + a) * kGuRS + col);
+        const f32x4_t Bv = half == 0 ? (u == 0 ? rh0 : rh1) : (u == 0 ? a0 : a1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          t0 = mfma_f32(Ah0[r], Bv[r], t0);
+          t1 = mfma_f32(Ah1[r], Bv[r], t1);
+        }
+      }
+    }
+    f32x4_t n0, n1;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      n0[i] = fmaf(z0[i], ftanh(t0[i]) - h0[i], h0[i]);  // (1-z) h + z tanh(.)
+      n1[i] = fmaf(z1[i], ftanh(t1[i]) - h1[i], h1[i]);
+      sum += n0[i] + n1[i];
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / D);
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      n0[i] -= mean;
+      n1[i] -= mean;
+      var = fmaf(n0[i], n0[i], var);
+      var = fmaf(n1[i], n1[i], var);
+    }
+    var += __shfl_xor(var, 16);
+    var += __shfl_xor(var, 32);
+    const float inv = 1.0f / sqrtf(var * (1.0f / D) + eps);
+    const f32x4_t g0 = ldv4(wvec + 3 * D + 4 * q), g1 = ldv4(wvec + 3 * D + 16 + 4 * q);
+    const f32x4_t b0 = ldv4(wvec + 4 * D + 4 * q), b1 = ldv4(wvec + 4 * D + 16 + 4 * q);
+    f32x4_t o0, o1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o0[i] = n0[i] * inv * g0[i] + b0[i] + h0[i];
+      o1[i] = n1[i] * inv * g1[i] + b1[i] + h1[i];
+    }
+    if (row < rows) {
+      *reinterpret_cast<f32x4_t*>(out + row * D + 4 * q) = o0;
+      *reinterpret_cast<f32x4_t*>(out + row * D + 16 + 4 * q) = o1;
+    }
+  }
+}
+
 // a8  GlobalSumPool.call (models/layers.py:161-164)
 __global__ void global_sum_pool_kernel(const float* __restrict__ h, const int32_t* __restrict__ ids,
                                        float* __restrict__ out, int B, int N, int D) {
@@ -245,7 +529,21 @@ __global__ void global_sum_pool_kernel(const float* __restrict__ h, const int32_
     const int64_t b = t / D;
     const int i = (int)(t - b * D);
     float acc = 0.f;
-    for (int n = 0; n < N; ++n)
+    constexpr int kU = 8;
+    int n = 0;
+    for (; n + kU <= N; n += kU) {  // 8 rows in flight; the sum stays in ascending n
+      float v[kU];
+      int id[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        v[u] = h[(b * N + n + u) * D + i];
+        id[u] = ids[b * N + n + u];
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (id[u] > 0) acc += v[u];
+    }
+    for (; n < N; ++n)
       if (ids[b * N + n] > 0) acc += h[(b * N + n) * D + i];
     out[t] = acc;
   }
@@ -317,6 +615,11 @@ int launch_bmm_message_typed(const float* h, const int32_t* bond_ids, const int3
                              const float* type_mats, float* m, int B, int N, int E, int D, int Vb,
                              hipStream_t s) {
   if (B == 0) return IMPNN_OK;
+  if (D == 32 && Vb <= kTVb && (int64_t)kTM * E <= kTSlots && E < (1 << 15) && N < (1 << 12) && aligned16(h) &&
+      aligned16(type_mats) && aligned16(m) && (reinterpret_cast<uintptr_t>(conn) & 7u) == 0) {
+    bmm_message_typed_d32_kernel<<<(B + kTM - 1) / kTM, 512, 0, s>>>(h, bond_ids, conn, type_mats, m, B, N, E, Vb);
+    return check_launch("bmm_message_typed_d32");
+  }
   size_t lds = (size_t)N * D * sizeof(float);
   if (lds > kMaxLds) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed: N*D=%d floats exceed LDS", N * D);
   if (lds > 64 * 1024)
@@ -347,6 +650,13 @@ int launch_gated_update(const float* h, const float* agg, const float* Wz, const
                         const float* gamma, const float* beta, float eps, float* out, int64_t rows,
                         int D, hipStream_t s) {
   if (rows == 0) return IMPNN_OK;
+  if (D == 32 && aligned16(h) && aligned16(agg) && aligned16(out)) {
+    const int64_t tiles = (rows + 15) / 16;
+    int64_t blocks = (tiles + 3) / 4;
+    if (blocks > 256 * 4) blocks = 256 * 4;  // grid-stride: the weight transpose is paid once per workgroup
+    gated_update_d32_kernel<<<(unsigned)blocks, 256, 0, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, out, rows);
+    return check_launch("gated_update_d32");
+  }
   int R = kBlock / D;
   if (R < 1) R = 1;
   size_t lds = ((size_t)5 * R * D + 2 * R) * sizeof(float);
