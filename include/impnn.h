@@ -146,6 +146,20 @@ int impnn_encoder_fused_prepared(int32_t n_ions, const int32_t* const* atom_ids,
                                  int32_t K, int32_t S, float ln_eps, void* workspace,
                                  size_t workspace_bytes, impnn_stream_t stream);
 
+/* ---- f1: everything after GlobalSumPool in one launch.
+ *      kind 0 (viscosity, train_viscosity.py:189,197-214 + models/layers.py:10-49):
+ *        fp_g = relu(pooled_g Wfp_g + bfp_g); mixed = relu(fp_cat Wp_cat + bp_cat) + relu(fp_an Wp_an + bp_an);
+ *        [A,b,c] = mixed Wv + bv; out = A + clip(softplus(b),0,20) / (T/100 + clip(softplus(c),0.1,50) + 1e-6)
+ *      kind 1 (melting point, train_melting_point.py:173,191-198): out = relu(mixed Wh + bh) Wo + bo
+ *      head_weights (keras Dense kernels (in,out) then bias, in this order; impnn_model_head_floats):
+ *        Wfp_cat D*F | bfp_cat F | Wfp_an | bfp_an | Wp_cat F*Mx | bp_cat Mx | Wp_an | bp_an |
+ *        kind 0: Wv Mx*3 | bv 3        kind 1: Wh Mx*F | bh F | Wo F | bo 1
+ *      pooled_* (B,D), temperature (B,1) in kelvin (kind 0 only), out (B,1).  D, F, Mx <= 64. */
+int64_t impnn_model_head_floats(int32_t kind, int32_t D, int32_t F, int32_t Mx);
+int impnn_model_head(int32_t kind, const float* pooled_cat, const float* pooled_an,
+                     const float* temperature, const float* head_weights, float* out, int32_t B,
+                     int32_t D, int32_t F, int32_t Mx, impnn_stream_t stream);
+
 /* ---- a9 in two halves, for callers that pipeline batches.  impnn_encoder_plan runs only the
  *      graph-dependent plan kernels (row counts, shares, chunk records) of a batch into `workspace`;
  *      impnn_encoder_run runs only the encoder kernel from a planned workspace.  The plan needs no

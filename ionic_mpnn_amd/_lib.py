@@ -40,6 +40,8 @@ SIGNATURES = {
                                      i32, vp, sz, vp]),
     "impnn_encoder_run": (C.c_int, [i32, C.POINTER(vp), vp, i32, vp, i32, C.POINTER(vp), i32, C.POINTER(vp), i32, i32,
                                     i32, i32, i32, i32, f32, vp, sz, vp]),
+    "impnn_model_head_floats": (i64, [i32, i32, i32, i32]),
+    "impnn_model_head": (C.c_int, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "impnn_validate_indices": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "impnn_profile_enable": (C.c_int, [i32]),
     "impnn_profile_collect": (C.c_int, [C.POINTER(C.c_float), i32, C.POINTER(i32)]),

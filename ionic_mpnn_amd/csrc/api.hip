@@ -259,6 +259,22 @@ int impnn_encoder_fused_prepared(int32_t n_ions, const int32_t* const* atom_ids,
                         mode, pooled, B, N, E, D, K, S, ln_eps, workspace, workspace_bytes, stream);
 }
 
+int64_t impnn_model_head_floats(int32_t kind, int32_t D, int32_t F, int32_t Mx) {
+  if (D <= 0 || F <= 0 || Mx <= 0 || (kind != 0 && kind != 1)) return -1;
+  const int64_t common = 2 * ((int64_t)D * F + F) + 2 * ((int64_t)F * Mx + Mx);
+  return common + (kind == 0 ? (int64_t)Mx * 3 + 3 : (int64_t)Mx * F + F + F + 1);
+}
+
+int impnn_model_head(int32_t kind, const float* pooled_cat, const float* pooled_an, const float* temperature,
+                     const float* head_weights, float* out, int32_t B, int32_t D, int32_t F, int32_t Mx,
+                     impnn_stream_t stream) {
+  REQUIRE(kind == 0 || kind == 1, "kind must be 0 (viscosity) or 1 (melting point)");
+  REQUIRE(B >= 0 && D > 0 && F > 0 && Mx > 0, "bad shape");
+  if (B == 0) return IMPNN_OK;
+  REQUIRE(pooled_cat && pooled_an && head_weights && out && (kind == 1 || temperature), "null pointer");
+  return launch_model_head(kind, pooled_cat, pooled_an, temperature, head_weights, out, B, D, F, Mx, as_stream(stream));
+}
+
 int impnn_profile_enable(int32_t capacity) {
   REQUIRE(capacity > 0 && capacity <= (1 << 20), "capacity out of range");
   impnn_profile_disable();

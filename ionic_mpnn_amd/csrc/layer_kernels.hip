@@ -566,6 +566,78 @@ __global__ void validate_indices_kernel(const int32_t* conn, const int32_t* atom
   if (c2) atomicAdd(&counts[2], c2);
 }
 
+// ---------------------------------------------------------------------------------------
+// f1  model head after GlobalSumPool, one launch (train_viscosity.py:189,197-214 + models/layers.py:10-49;
+// train_melting_point.py:173,191-198).  One thread per sample; the sample's small vectors live in
+// a lane-strided LDS scratch (conflict-free), the weights are read at wave-uniform addresses.
+//   fp_g  = relu(pooled_g @ Wfp_g + bfp_g)         (D -> F)     g in {cat, an}
+//   mixed = relu(fp_cat @ Wp_cat + bp_cat) + relu(fp_an @ Wp_an + bp_an)      (F -> Mx)
+//   kind 0: vp = mixed @ Wv + bv (Mx -> 3); A = vp0; Bc = clip(softplus(vp1), 0, 20);
+//           Cc = clip(softplus(vp2), 0.1, 50); out = A + Bc / (T/100 + Cc + 1e-6)
+//   kind 1: out = relu(mixed @ Wh + bh) @ Wo + bo   (Mx -> F -> 1)
+// ---------------------------------------------------------------------------------------
+constexpr int kHeadMaxDim = 64;
+
+__device__ __forceinline__ float softplus_exact(float x) { return x > 20.f ? x + log1pf(expf(-x)) : log1pf(expf(x)); }
+
+__global__ __launch_bounds__(64) void model_head_kernel(int kind, const float* __restrict__ pc,
+                                                        const float* __restrict__ pa, const float* __restrict__ T,
+                                                        const float* __restrict__ w, float* __restrict__ out, int B, int D,
+                                                        int F, int Mx) {
+  __shared__ float sc[3 * kHeadMaxDim * 64];  // x / fp (reused), mixed, hidden : [dim][lane]
+  float* xs = sc;
+  float* mix = sc + kHeadMaxDim * 64;
+  float* hid = sc + 2 * kHeadMaxDim * 64;
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * 64 + lane;
+  const bool live = b < B;
+  const int64_t br = live ? b : 0;
+  const float* Wfp[2] = {w, w + (int64_t)D * F + F};
+  const float* wp = w + 2 * ((int64_t)D * F + F);
+  const float* Wp[2] = {wp, wp + (int64_t)F * Mx + Mx};
+  const float* wt = wp + 2 * ((int64_t)F * Mx + Mx);
+  for (int j = 0; j < Mx; ++j) mix[j * 64 + lane] = 0.f;
+  for (int g = 0; g < 2; ++g) {
+    const float* pooled = (g == 0 ? pc : pa) + br * D;
+    for (int i = 0; i < D; ++i) xs[i * 64 + lane] = pooled[i];
+    // fp = relu(x @ Wfp + b) -> hid
+    for (int j = 0; j < F; ++j) {
+      float acc = Wfp[g][(int64_t)D * F + j];
+      for (int i = 0; i < D; ++i) acc = fmaf(xs[i * 64 + lane], Wfp[g][(int64_t)i * F + j], acc);
+      hid[j * 64 + lane] = fmaxf(acc, 0.f);
+    }
+    for (int j = 0; j < Mx; ++j) {
+      float acc = Wp[g][(int64_t)F * Mx + j];
+      for (int i = 0; i < F; ++i) acc = fmaf(hid[i * 64 + lane], Wp[g][(int64_t)i * Mx + j], acc);
+      mix[j * 64 + lane] += fmaxf(acc, 0.f);  // AddTwoTensors / keras Add
+    }
+  }
+  float res;
+  if (kind == 0) {
+    float vp[3];
+    for (int j = 0; j < 3; ++j) {
+      float acc = wt[(int64_t)Mx * 3 + j];
+      for (int i = 0; i < Mx; ++i) acc = fmaf(mix[i * 64 + lane], wt[(int64_t)i * 3 + j], acc);
+      vp[j] = acc;
+    }
+    const float Bc = fminf(fmaxf(softplus_exact(vp[1]), 0.f), 20.f);
+    const float Cc = fminf(fmaxf(softplus_exact(vp[2]), 0.1f), 50.f);
+    res = vp[0] + Bc / (T[br] / 100.0f + Cc + 1e-6f);
+  } else {
+    const float* Wh = wt;
+    const float* bh = Wh + (int64_t)Mx * F;
+    const float* Wo = bh + F;
+    float acc_o = Wo[F];
+    for (int j = 0; j < F; ++j) {
+      float acc = bh[j];
+      for (int i = 0; i < Mx; ++i) acc = fmaf(mix[i * 64 + lane], Wh[(int64_t)i * F + j], acc);
+      acc_o = fmaf(fmaxf(acc, 0.f), Wo[j], acc_o);
+    }
+    res = acc_o;
+  }
+  if (live) out[b] = res;
+}
+
 inline int grid_for(int64_t items, int block = kBlock, int cap = 256 * 8) {
   int64_t g = (items + block - 1) / block;
   if (g < 1) g = 1;
@@ -675,6 +747,15 @@ int launch_global_sum_pool(const float* h, const int32_t* ids, float* out, int B
   if (B == 0) return IMPNN_OK;
   global_sum_pool_kernel<<<grid_for((int64_t)B * D), kBlock, 0, s>>>(h, ids, out, B, N, D);
   return check_launch("global_sum_pool");
+}
+
+int launch_model_head(int kind, const float* pc, const float* pa, const float* T, const float* w, float* out, int B,
+                      int D, int F, int Mx, hipStream_t s) {
+  if (B == 0) return IMPNN_OK;
+  if (D > kHeadMaxDim || F > kHeadMaxDim || Mx > kHeadMaxDim)
+    return fail(IMPNN_E_UNSUPPORTED, "model_head: dims D=%d F=%d Mx=%d exceed %d", D, F, Mx, kHeadMaxDim);
+  model_head_kernel<<<(B + 63) / 64, 64, 0, s>>>(kind, pc, pa, T, w, out, B, D, F, Mx);
+  return check_launch("model_head");
 }
 
 int launch_validate_indices(const int32_t* conn, const int32_t* atom_ids, const int32_t* bond_ids,

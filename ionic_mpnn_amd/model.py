@@ -148,6 +148,21 @@ class MPNNModel:
         self._packed = None
         self._prepared = {}
         self._split_deg_limit = None
+        self._head_packed = None
+
+    def _packed_head(self):
+        """Head weights in the layout of impnn_model_head (include/impnn.h), cached per weight version."""
+        if getattr(self, "_head_packed", None) is None:
+            parts = []
+            for p in ("cat", "an"):
+                parts += [self.branches[p]["fp"].kernel, self.branches[p]["fp"].bias]
+            parts += [self.cat_proj.kernel, self.cat_proj.bias, self.an_proj.kernel, self.an_proj.bias]
+            if self.kind == "viscosity":
+                parts += [self.visc_params.kernel, self.visc_params.bias]
+            else:
+                parts += [self.mp_hidden.kernel, self.mp_hidden.bias, self.mp_out.kernel, self.mp_out.bias]
+            self._head_packed = torch.cat([t.reshape(-1) for t in parts]).contiguous()
+        return self._head_packed
 
     def _prepared_weights(self, mode):
         """Kernel-side weight images (one per ion), built once per weight version and mode."""
@@ -242,6 +257,9 @@ class MPNNModel:
         return (self.encode_layered("cat", ca, cb, cc, trace), self.encode_layered("an", aa, ab, ac, trace))
 
     def head(self, pooled_cat, pooled_an, temperature=None, trace=None):
+        if trace is None and max(self.atom_dim, self.fp_size, self.mixing_size) <= 64:
+            return ops.model_head(self.kind, pooled_cat, pooled_an, temperature, self._packed_head(), self.fp_size,
+                                  self.mixing_size)  # one launch
         fp_cat = self.branches["cat"]["fp"](pooled_cat)   # Dense(fp_size, relu), :189
         fp_an = self.branches["an"]["fp"](pooled_an)
         mixed = self.mix([self.cat_proj(fp_cat), self.an_proj(fp_an)])

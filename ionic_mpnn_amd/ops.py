@@ -393,3 +393,25 @@ class EncoderPipeline:
             done.record(cur)
         plan.slot["done"] = done
         return pooled
+
+
+def model_head(kind, pooled_cat, pooled_an, temperature, head_weights, fp_size, mixing_size):
+    """Everything after GlobalSumPool in one launch (impnn_model_head): kind "viscosity" or "melting_point"."""
+    require_gpu(pooled_cat, pooled_an, head_weights)
+    pooled_cat, pooled_an, head_weights = f32c(pooled_cat), f32c(pooled_an), f32c(head_weights)
+    B, D = pooled_cat.shape
+    k = {"viscosity": 0, "melting_point": 1}[kind]
+    lib = _lib.load()
+    if head_weights.numel() != lib.impnn_model_head_floats(k, D, fp_size, mixing_size):
+        raise ValueError("packed head weights have the wrong length")
+    T = None
+    if k == 0:
+        require_gpu(temperature)
+        T = f32c(temperature).reshape(-1)
+        if T.numel() != B:
+            raise ValueError("temperature must hold one value per sample")
+    out = torch.empty(B, 1, dtype=torch.float32, device=pooled_cat.device)
+    with torch.cuda.device(pooled_cat.device):
+        check(lib.impnn_model_head(k, ptr(pooled_cat), ptr(pooled_an), ptr(T) if T is not None else None,
+                                   ptr(head_weights), ptr(out), B, D, fp_size, mixing_size, stream_ptr()))
+    return out

@@ -233,6 +233,28 @@ def test_auto_mode_uses_static_range_bound():
     assert m._packed_weights() is not None and m._split_deg_limit == 0.0 and m.resolve_encoder_mode(1) == "f32"
 
 
+@pytest.mark.parametrize("name", ["config2_perturbed_b6", "tiny_melting_point", "tiny_viscosity"])
+def test_model_head_kernel_vs_oracle_and_torch_head(name):
+    """impnn_model_head (one launch after GlobalSumPool) against the oracle's final output and the torch head."""
+    kind, inp, w, outs = load_case(name)
+    D, K = w["atom_embedding"].shape[1], w["bond_embedding"].shape[1]
+    Va, Vb = w["atom_embedding"].shape[0], w["bond_embedding"].shape[0]
+    F, Mx = w["cat_fp/kernel"].shape[1], w["cat_proj/kernel"].shape[1]
+    if kind == "viscosity":
+        m = MM.build_model(Va, Vb, atom_dim=D, bond_dim=K, fp_size=F, mixing_size=Mx, num_steps=weights.num_steps_of(w), device=DEV)
+    else:
+        m = MM.build_melting_point_model(Va, Vb, atom_dim=D, fp_size=F, mixing_size=Mx, num_steps=weights.num_steps_of(w), device=DEV)
+    m.load_weights(w)
+    pc = torch.from_numpy(outs["cat/pooled"].astype(np.float32)).to(DEV)
+    pa = torch.from_numpy(outs["an/pooled"].astype(np.float32)).to(DEV)
+    T = torch.from_numpy(inp["temperature"]).to(DEV) if kind == "viscosity" else None
+    y_kernel = m.head(pc, pa, T)
+    y_torch = m.head(pc, pa, T, trace={})
+    assert_close(y_kernel.cpu().numpy(), outs["final"], what="head kernel vs oracle")
+    assert_close(y_kernel.cpu().numpy(), y_torch.cpu().numpy(), what="head kernel vs torch head")
+    assert_close(m(inp).cpu().numpy(), outs["final"], what="full forward")
+
+
 def test_config1_dataset_plumbing_batch32():
     """BASELINE config 1: records in the *_id_data.pkl schema -> restated loader -> batch 32 -> HIP forward
     vs the oracle."""
