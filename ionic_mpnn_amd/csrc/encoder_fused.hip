@@ -597,6 +597,13 @@ int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
   pp.nwg = w.nwg;
   pp.max_sub = w.max_sub;
   pp.nblk = w.nblk;
+  pp.stamps = nullptr;
+  {
+    size_t sb = 0;
+    void* sp = debug_stamp_buffer(&sb);
+    if (sp && sb >= ((size_t)w.nwg * 32 + 16) * sizeof(unsigned long long))
+      pp.stamps = static_cast<unsigned long long*>(sp) + (size_t)w.nwg * 32;
+  }
   if (plan_phase) return launch_plan(pp, s);
 
   ep.atom_table = a.atom_table;

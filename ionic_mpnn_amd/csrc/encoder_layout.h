@@ -124,6 +124,7 @@ struct PlanParams {
   int32_t* desc;      // [nwg][max_sub][4]
   unsigned char* rec; // [nwg][max_sub][kRecBytes]
   int n_ions, B, N, E, Vb, nwg, max_sub, nblk;
+  unsigned long long* stamps;  // diagnostics only: 16 words written by plan_chunks workgroup 0
 };
 
 struct ImageParams {

@@ -3,12 +3,11 @@
 //
 //   plan_stats   one wave per molecule: kept rows r_b, valid edges v_b -> virtual rows; one partial
 //                sum per 16 molecules
-//   plan_shares  one small workgroup: prefix over the partial sums (a few hundred values); the rows
-//                are dealt to `nwg` persistent encoder workgroups in equal contiguous shares (per
-//                ion, proportional to its rows): share = [first virtual row, last virtual row)
 //   plan_chunks  one 256-thread workgroup per (share, chunk slot) (8+ resident per CU, so its
-//                dependent loads overlap): resolves the share's molecules and its next-fit chain of
-//                chunks (<= 256 rows / <= 1024 edges) locally, then builds its chunk: in-degrees,
+//                dependent loads overlap).  The rows of the batch are dealt to `nwg` persistent
+//                encoder workgroups in equal contiguous shares (per ion, proportional to its rows);
+//                the workgroup resolves its share from the partial sums, the share's molecules and
+//                its next-fit chain of chunks (<= 256 rows / <= 1024 edges), then builds its chunk: in-degrees,
 //                placement of rows by descending in-degree, CSR of in-edges in edge-slot order,
 //                pool map -> one 8 KB chunk record in HBM
 //   weight_image canonical weights -> the encoder's LDS image (weights only; run when they change)
@@ -170,75 +169,61 @@ __global__ void weight_image_kernel(ImageParams p) {
 
 
 // -----------------------------------------------------------------------------------------
-// plan_shares: one 256-thread workgroup; wave g scans the partial sums of ion g.
+// Share of persistent encoder workgroup j, resolved by ONE WAVE from the 16-molecule partial sums
+// (a few hundred values): the rows of the batch are dealt to the `nwg` workgroups in equal contiguous
+// shares, per ion, in proportion to the ion's rows.  Returns false for an empty share.
+//   g: ion; k0: 16-molecule block that holds virtual row t_lo; bp0: virtual-row prefix at that block;
+//   [t_lo, t_hi): the share's virtual rows.
+// Every plan_chunks workgroup of a share recomputes this (a handful of L2 hits) instead of reading it
+// from a separate single-workgroup kernel: one launch and one dependent stage fewer.
 // -----------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void plan_shares_kernel(PlanParams p) {
-  extern __shared__ int32_t bp[];  // [n_ions][nblk + 1] exclusive prefix of the partial sums
-  __shared__ int tot_s[2], nwg_s[2];
-  __builtin_amdgcn_s_setprio(3);
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+__device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int lane, int& g, int& k0, int& bp0,
+                                              int& t_lo, int& t_hi) {
   const int nblk = p.nblk;
-  if (wv < p.n_ions) {
-    const int g = wv;
-    const int32_t* part = p.partial + (int64_t)g * nblk;
-    int32_t* out = bp + g * (nblk + 1);
-    int carry = 0;
-    for (int k0 = 0; k0 < nblk; k0 += 64 * 8) {  // 8 consecutive blocks per lane and round
-      int v[8];
-      const int kb = k0 + lane * 8;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = part[(kb + i) < nblk ? (kb + i) : (nblk - 1)];  // clamped, masked below
-      int local = 0;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (kb + i >= nblk) v[i] = 0;
-        local += v[i];
-      }
-      const int incl = wave_incl_scan(local);
-      int run = carry + incl - local;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (kb + i < nblk) out[kb + i] = run;
-        run += v[i];
-      }
-      carry += __shfl(incl, 63);
-    }
-    if (lane == 0) {
-      out[nblk] = carry;
-      tot_s[g] = carry;
-    }
+  long long tot[2] = {0, 0};
+  for (int gi = 0; gi < p.n_ions; ++gi) {
+    const int32_t* part = p.partial + (int64_t)gi * nblk;
+    int acc = 0;
+    for (int k = lane; k < nblk; k += 64) acc += part[k];
+    tot[gi] = wave_incl_scan(acc);
+    tot[gi] = __shfl((int)tot[gi], 63);
   }
-  lds_barrier();
-  if (threadIdx.x == 0) {  // workgroups per ion, proportional to its rows
-    if (p.n_ions == 1) {
-      nwg_s[0] = p.nwg;
-      nwg_s[1] = 0;
-    } else {
-      const long long t0 = tot_s[0], t1 = tot_s[1];
-      int n0 = (t0 + t1) > 0 ? (int)((p.nwg * t0 + (t0 + t1) / 2) / (t0 + t1)) : p.nwg / 2;
-      if (p.nwg >= 2) n0 = n0 < 1 ? 1 : (n0 > p.nwg - 1 ? p.nwg - 1 : n0);
-      nwg_s[0] = n0;
-      nwg_s[1] = p.nwg - n0;
-    }
+  int nwg0 = p.nwg, nwg1 = 0;
+  if (p.n_ions == 2) {
+    const long long t0 = tot[0], t1 = tot[1];
+    int n0 = (t0 + t1) > 0 ? (int)((p.nwg * t0 + (t0 + t1) / 2) / (t0 + t1)) : p.nwg / 2;
+    if (p.nwg >= 2) n0 = n0 < 1 ? 1 : (n0 > p.nwg - 1 ? p.nwg - 1 : n0);
+    nwg0 = n0;
+    nwg1 = p.nwg - n0;
   }
-  lds_barrier();
-  for (int j = threadIdx.x; j < p.nwg; j += blockDim.x) {
-    const int g = j < nwg_s[0] ? 0 : 1;
-    const int jj = j - (g ? nwg_s[0] : 0);
-    const long long tg = tot_s[g];
-    const int t_lo = (int)(tg * jj / nwg_s[g]);
-    const int t_hi = (jj + 1 == nwg_s[g]) ? (int)tg : (int)(tg * (jj + 1) / nwg_s[g]);
-    // block that holds virtual row t_lo: largest k with bp[k] <= t_lo (branch-free)
-    const int32_t* bg = bp + g * (nblk + 1);
-    int lo = 0, hi = nblk - 1;
-    for (int it = 0; it < 32 && lo < hi; ++it) {
-      const int mid = (lo + hi + 1) >> 1;
-      const bool le = bg[mid] <= t_lo;
-      lo = le ? mid : lo;
-      hi = le ? hi : mid - 1;
+  g = j < nwg0 ? 0 : 1;
+  const int jj = j - (g ? nwg0 : 0);
+  const int nwg_g = g ? nwg1 : nwg0;
+  const long long tg = tot[g];
+  t_lo = (int)(tg * jj / nwg_g);
+  t_hi = (jj + 1 == nwg_g) ? (int)tg : (int)(tg * (jj + 1) / nwg_g);
+  k0 = 0;
+  bp0 = 0;
+  if (t_hi <= t_lo) return false;
+  // block that holds virtual row t_lo: prefix[k] <= t_lo < prefix[k] + partial[k]
+  const int32_t* part = p.partial + (int64_t)g * nblk;
+  int carry = 0;
+  bool found = false;
+  for (int kbase = 0; kbase < nblk && !found; kbase += 64) {
+    const int k = kbase + lane;
+    const int v = k < nblk ? part[k < nblk ? k : nblk - 1] : 0;
+    const int incl = wave_incl_scan(v);
+    const int st = carry + incl - v;
+    const unsigned long long hit = __ballot(k < nblk && st <= t_lo && t_lo < st + v);
+    if (hit) {
+      const int src = __builtin_ctzll(hit);
+      k0 = kbase + src;
+      bp0 = __shfl(st, src);
+      found = true;
     }
-    reinterpret_cast<int4*>(p.share)[j] = make_int4(g | (lo << 1), bg[lo], t_lo, t_hi);
+    carry += __shfl(incl, 63);
   }
+  return found;
 }
 
 // -----------------------------------------------------------------------------------------
@@ -253,22 +238,25 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
   __shared__ uint32_t ent2[kECap + 1];
   int32_t* const shst = reinterpret_cast<int32_t*>(ent2);  // virtual-row prefix of the share's molecules (+ end),
                                                            // dead before ent2 is filled (moloff keeps what is needed)
-  __shared__ int chunk_s[4];              // first molecule (share-local), molecules, rows, chunks in the share
+  __shared__ int chunk_s[5];              // first molecule, molecules, rows, share-local first molecule, ion
   __builtin_amdgcn_s_setprio(3);
+#define CSTAMP(i) do { if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+  CSTAMP(0);
   const int j = blockIdx.x / p.max_sub, slot_i = blockIdx.x - j * p.max_sub;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int4 shr = reinterpret_cast<const int4*>(p.share)[j];
-  const int g = __builtin_amdgcn_readfirstlane(shr.x & 1), k0 = __builtin_amdgcn_readfirstlane(shr.x >> 1);
-  const int t_lo = __builtin_amdgcn_readfirstlane(shr.z), t_hi = __builtin_amdgcn_readfirstlane(shr.w);
-  if (t_hi <= t_lo) {
-    if (slot_i == 0 && tid == 0) p.nsub[j] = 0;
-    return;
-  }
   // ---- resolve the share: molecules whose first virtual row lies in [t_lo, t_hi), their prefix, and
   //      the next-fit chain of chunks; wave 0 does it, everybody else waits at the barrier.
   if (wave == 0) {
+    int g = 0, k0 = 0, bp0 = 0, t_lo = 0, t_hi = 0;
+    const bool have = resolve_share(p, j, lane, g, k0, bp0, t_lo, t_hi);
+    if (!have) {
+      if (lane == 0) {
+        chunk_s[0] = -1; chunk_s[1] = 0; chunk_s[2] = 0; chunk_s[3] = 0; chunk_s[4] = 0;
+        if (slot_i == 0) p.nsub[j] = 0;
+      }
+    } else {
     const int32_t* vrg = p.vr + (int64_t)g * p.B;
-    int run = __builtin_amdgcn_readfirstlane(shr.y);  // prefix at molecule k0 * 16
+    int run = bp0;  // prefix at molecule k0 * 16
     int first = -1, nsh = 0;                          // first share molecule (global index), count
     int end_row = -1;                                 // first virtual row after the share's last molecule
     for (int mbase = k0 * kPB; mbase < p.B && end_row < 0; mbase += 64) {
@@ -318,11 +306,14 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
       chunk_s[1] = my_mb >= 0 ? my_e - my_mb : 0;
       chunk_s[2] = my_mb >= 0 ? shst[my_e] - shst[my_mb] : 0;
       chunk_s[3] = my_mb;
+      chunk_s[4] = g;
       if (slot_i == 0) p.nsub[j] = hop;
+    }
     }
   }
   lds_barrier();
-  const int m0 = chunk_s[0], M = chunk_s[1], R = chunk_s[2], mb_local = chunk_s[3];
+  CSTAMP(1);
+  const int m0 = chunk_s[0], M = chunk_s[1], R = chunk_s[2], mb_local = chunk_s[3], g = chunk_s[4];
   if (M <= 0) return;
   const int idx = blockIdx.x;
   if (tid == 0) reinterpret_cast<int4*>(p.desc)[idx] = make_int4(m0, M, 0, R | (g << 16));
@@ -372,6 +363,7 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
   if (tid < 48) bins[tid] = 0;
   if (tid < 16) tilemax[tid] = 0;
   lds_barrier();
+  CSTAMP(2);
 
   // P1: in-degree of every logical row (edge-parallel, coalesced reads of conn / bond ids);
   //     logical row -> (molecule, n), atom id
@@ -399,6 +391,7 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
     }
   }
   lds_barrier();
+  CSTAMP(3);
 
   // P2: place rows by descending in-degree (counting sort over 18 bins) so that a tile's lanes walk
   //     in-edge lists of similar length.  The placement inside a bin comes from an LDS atomic and
@@ -408,6 +401,7 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
   const int my_bin = tid >= R ? 0 : (my_deg >= 16 ? 1 : 17 - my_deg);  // bin 0 = beyond chunk (placed last)
   atomicAdd(&bins[my_bin], 1);
   lds_barrier();
+  CSTAMP(4);
   if (wave == 0) {  // exclusive scan in placement order: bins 1..17, then bin 0
     const int bidx = lane < kDegBins ? (lane == kDegBins - 1 ? 0 : lane + 1) : 0;
     const int v = lane < kDegBins ? bins[bidx] : 0;
@@ -420,6 +414,7 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
     if (lane < kDegBins) bins[24 + bidx] = incl - v;
   }
   lds_barrier();
+  CSTAMP(5);
   const int pos = bins[24 + my_bin] + atomicAdd(&bins[my_bin], -1) - 1;
   place[tid] = pos;
   cursor[pos] = my_deg;  // in-degree per placed row (scanned below)
@@ -427,6 +422,7 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
   r_rowatom[pos] = my_real ? my_id : -1;  // out-of-range ids (incl. negative) read as a zero row in the encoder
   r_poolrow[tid] = (uint16_t)(pos | ((my_real && my_id > 0) ? 0x8000 : 0));
   lds_barrier();
+  CSTAMP(6);
 
   // P3: exclusive scan of the placed in-degrees -> rowptr; cursor = fill position
   {
@@ -439,6 +435,7 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
     }
     if (lane == 63) scratch[wave] = incl;
     lds_barrier();
+  CSTAMP(7);
     int off = 0;
     for (int w = 0; w < wave; ++w) off += scratch[w];
     const int excl = off + incl - my_cnt;
@@ -452,6 +449,7 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
     if (tid < 16) r_tilemax[tid] = (unsigned char)tilemax[tid];
   }
   lds_barrier();
+  CSTAMP(8);
 
   // P4: fill.  entry = edge slot (16b) | bond id (8b) | placed source row (8b); the slot in the top
   //     bits lets P5 restore edge-slot order, so the accumulation order is fixed run to run.
@@ -474,6 +472,7 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
     }
   }
   lds_barrier();
+  CSTAMP(9);
 
   // P5: every row's in-edge list in edge-slot order: entry-parallel rank sort, straight into the record
   {
@@ -491,6 +490,8 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
       r_ent[b0 + rank] = v;
     }
   }
+  CSTAMP(15);
+#undef CSTAMP
 }
 
 }  // namespace
@@ -504,11 +505,8 @@ int launch_weight_image(const ImageParams& ip, int S, hipStream_t s) {
 int launch_plan(const PlanParams& pp, hipStream_t s) {
   plan_stats_kernel<<<pp.n_ions * pp.nblk, 64 * kPB, 0, s>>>(pp);
   if (int rc = check_launch("plan_stats")) return rc;
-  const size_t lds = (size_t)pp.n_ions * (pp.nblk + 1) * sizeof(int32_t);
-  if (lds > 60 * 1024 || (int64_t)2 * pp.n_ions * pp.B / pp.nwg + 64 > kShareCap)
+  if ((int64_t)2 * pp.n_ions * pp.B / pp.nwg + 64 > kShareCap)
     return fail(IMPNN_E_UNSUPPORTED, "encoder plan: batch of %d molecules per ion is too large", pp.B);
-  plan_shares_kernel<<<1, 256, lds, s>>>(pp);
-  if (int rc = check_launch("plan_shares")) return rc;
   plan_chunks_kernel<<<pp.nwg * pp.max_sub, kRCap, 0, s>>>(pp);
   return check_launch("plan_chunks");
 }

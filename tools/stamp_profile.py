@@ -35,6 +35,9 @@ m.encode_pooled(d, fused=True)
 torch.cuda.synchronize()
 lib.impnn_debug_set_stamp_buffer(None, 0)
 allb = buf.cpu().numpy().astype(np.int64)
+ps = allb[nwg * 32:]
+idx = [i for i in range(16) if ps[i] != 0]
+print('plan_chunks workgroup 0 stamps (cycles from start):', [(i, int(ps[i] - ps[0])) for i in idx])
 st = allb[:nwg * 32].reshape(nwg, 32)
 live = st[:, 7] != 0
 st = st[live]
