@@ -54,13 +54,14 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("IMPNN_BENCH_CORES", "16"))))  # GPU-box share: 16 cores per GPU
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per encoder launch from the committed rocprofv3 --pmc passes (profiles/pmc_*.json,
-    FETCH_SIZE doubled per MI355X_MICROARCH.md HBM section + WRITE_SIZE), or None if absent."""
+def pmc_field(name):
+    """A figure for the encoder kernel from the committed rocprofv3 --pmc passes (profiles/pmc_*.json,
+    latest round wins), or None.  hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the gfx950
+    FETCH_SIZE correction of MI355X_MICROARCH.md's HBM section."""
     best = None
     for f in sorted((ROOT / "profiles").glob("pmc_*.json")):
         try:
-            best = json.loads(f.read_text()).get("encoder_fused", {}).get("hbm_bytes_per_launch", best)
+            best = json.loads(f.read_text()).get("encoder_fused", {}).get(name, best)
         except (OSError, ValueError):
             pass
     return best
@@ -177,6 +178,18 @@ def main():
         local_sum = t
     total_pairs = float(local_sum[1].item())
 
+    # extra (not `value`): the whole model forward = hot path + impnn_model_head, same batch
+    full_ms = None
+    if fused and world == 1:
+        for _ in range(3):
+            y = m(d_in, fused=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            y = m(d_in, fused=True)
+        torch.cuda.synchronize()
+        full_ms = (time.perf_counter() - t1) / args.steps * 1e3
+
     kernel_ms = None
     if fused:
         buf = (C.c_float * args.steps)()
@@ -215,15 +228,21 @@ def main():
                    "no data-path collective; one all-reduce of the fingerprint checksum after the timed region",
                    "checksum": float(local_sum[0].item())},
     }
+    if full_ms:
+        out["config"]["full_model_forward"] = {"ms_per_step": full_ms, "graph_pairs_per_s": B / (full_ms * 1e-3),
+                                               "note": "hot path + heads (impnn_model_head) -> log_eta; not `value`"}
     if rehearsal:
         out["config"]["rehearsal"] = f"{world} ranks share {ndev} GPU(s) over gloo - not a scaling number"
     if kernel_ms:
         ach = flops_launch / (kernel_ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": "encoder_fused_kernel", "achieved": ach,
                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                           "traffic": pmc_traffic_bytes(), "kernel_ms": kernel_ms,
+                           "traffic": pmc_field("hbm_bytes_per_launch"), "kernel_ms": kernel_ms,
+                           "matrix_pipe_busy_frac_pmc": pmc_field("mfma_pipe_busy_frac"),
                            "note": "achieved = SURVEY 8(d) algorithmic f32 flops / measured kernel time; peak = dense "
-                                   "f32 MFMA (= f32 VALU) peak, the rate an exact-f32 implementation is bound by",
+                                   "f32 MFMA (= f32 VALU) peak, the rate an exact-f32 implementation is bound by. "
+                                   "In mode f16x2 the products run on the fp16 matrix pipe (3 per f32 product), so "
+                                   "frac may exceed 1; the kernel is then VALU-issue bound (DESIGN.md 4.1)",
                            "algorithmic_flops_per_launch": flops_launch,
                            "hbm": {"algorithmic_bytes_per_launch": bytes_launch,
                                    "achieved_GBs": bytes_launch / (kernel_ms * 1e-3) / 1e9,

@@ -568,8 +568,7 @@ __global__ void validate_indices_kernel(const int32_t* conn, const int32_t* atom
 
 // ---------------------------------------------------------------------------------------
 // f1  model head after GlobalSumPool, one launch (train_viscosity.py:189,197-214 + models/layers.py:10-49;
-// train_melting_point.py:173,191-198).  One thread per sample; the sample's small vectors live in
-// a lane-strided LDS scratch (conflict-free), the weights are read at wave-uniform addresses.
+// train_melting_point.py:173,191-198).
 //   fp_g  = relu(pooled_g @ Wfp_g + bfp_g)         (D -> F)     g in {cat, an}
 //   mixed = relu(fp_cat @ Wp_cat + bp_cat) + relu(fp_an @ Wp_an + bp_an)      (F -> Mx)
 //   kind 0: vp = mixed @ Wv + bv (Mx -> 3); A = vp0; Bc = clip(softplus(vp1), 0, 20);
@@ -580,62 +579,80 @@ constexpr int kHeadMaxDim = 64;
 
 __device__ __forceinline__ float softplus_exact(float x) { return x > 20.f ? x + log1pf(expf(-x)) : log1pf(expf(x)); }
 
-__global__ __launch_bounds__(64) void model_head_kernel(int kind, const float* __restrict__ pc,
-                                                        const float* __restrict__ pa, const float* __restrict__ T,
-                                                        const float* __restrict__ w, float* __restrict__ out, int B, int D,
-                                                        int F, int Mx) {
-  __shared__ float sc[3 * kHeadMaxDim * 64];  // x / fp (reused), mixed, hidden : [dim][lane]
-  float* xs = sc;
-  float* mix = sc + kHeadMaxDim * 64;
-  float* hid = sc + 2 * kHeadMaxDim * 64;
-  const int lane = threadIdx.x;
-  const int b = blockIdx.x * 64 + lane;
+// 8 samples per 256-thread workgroup, 32 threads per sample: thread (s, jj) owns outputs jj, jj+32 of
+// every layer; the sample's vectors and all weights sit in LDS (13.6 KB of weights at the defaults).
+constexpr int kHeadSPB = 8;
+
+__global__ __launch_bounds__(256) void model_head_kernel(int kind, const float* __restrict__ pc,
+                                                         const float* __restrict__ pa, const float* __restrict__ T,
+                                                         const float* __restrict__ w, float* __restrict__ out, int B, int D,
+                                                         int F, int Mx, int wfloats) {
+  extern __shared__ __align__(16) float hsm[];
+  float* ws = hsm;                                   // all head weights
+  float* xs = ws + ((wfloats + 3) & ~3);             // [kHeadSPB][2][kHeadMaxDim] pooled rows
+  float* fp = xs + kHeadSPB * 2 * kHeadMaxDim;       // [kHeadSPB][2][kHeadMaxDim]
+  float* mix = fp + kHeadSPB * 2 * kHeadMaxDim;      // [kHeadSPB][kHeadMaxDim]
+  float* hid = mix + kHeadSPB * kHeadMaxDim;         // [kHeadSPB][kHeadMaxDim]
+  const int tid = threadIdx.x, sl = tid >> 5, jj = tid & 31;
+  const int b = blockIdx.x * kHeadSPB + sl;
   const bool live = b < B;
-  const int64_t br = live ? b : 0;
-  const float* Wfp[2] = {w, w + (int64_t)D * F + F};
-  const float* wp = w + 2 * ((int64_t)D * F + F);
-  const float* Wp[2] = {wp, wp + (int64_t)F * Mx + Mx};
-  const float* wt = wp + 2 * ((int64_t)F * Mx + Mx);
-  for (int j = 0; j < Mx; ++j) mix[j * 64 + lane] = 0.f;
-  for (int g = 0; g < 2; ++g) {
-    const float* pooled = (g == 0 ? pc : pa) + br * D;
-    for (int i = 0; i < D; ++i) xs[i * 64 + lane] = pooled[i];
-    // fp = relu(x @ Wfp + b) -> hid
-    for (int j = 0; j < F; ++j) {
-      float acc = Wfp[g][(int64_t)D * F + j];
-      for (int i = 0; i < D; ++i) acc = fmaf(xs[i * 64 + lane], Wfp[g][(int64_t)i * F + j], acc);
-      hid[j * 64 + lane] = fmaxf(acc, 0.f);
+  for (int t = tid; t < wfloats; t += blockDim.x) ws[t] = w[t];
+  for (int g = 0; g < 2; ++g)
+    for (int i = jj; i < D; i += 32) xs[(sl * 2 + g) * kHeadMaxDim + i] = live ? (g == 0 ? pc : pa)[(int64_t)b * D + i] : 0.f;
+  __syncthreads();
+  const float* Wfp[2] = {ws, ws + D * F + F};
+  const float* wp = ws + 2 * (D * F + F);
+  const float* Wp[2] = {wp, wp + F * Mx + Mx};
+  const float* wt = wp + 2 * (F * Mx + Mx);
+  for (int g = 0; g < 2; ++g)
+    for (int j = jj; j < F; j += 32) {
+      float acc = Wfp[g][D * F + j];
+      const float* x = xs + (sl * 2 + g) * kHeadMaxDim;
+      for (int i = 0; i < D; ++i) acc = fmaf(x[i], Wfp[g][i * F + j], acc);
+      fp[(sl * 2 + g) * kHeadMaxDim + j] = fmaxf(acc, 0.f);
     }
-    for (int j = 0; j < Mx; ++j) {
-      float acc = Wp[g][(int64_t)F * Mx + j];
-      for (int i = 0; i < F; ++i) acc = fmaf(hid[i * 64 + lane], Wp[g][(int64_t)i * Mx + j], acc);
-      mix[j * 64 + lane] += fmaxf(acc, 0.f);  // AddTwoTensors / keras Add
+  __syncthreads();
+  for (int j = jj; j < Mx; j += 32) {
+    float m = 0.f;
+    for (int g = 0; g < 2; ++g) {
+      float acc = Wp[g][F * Mx + j];
+      const float* x = fp + (sl * 2 + g) * kHeadMaxDim;
+      for (int i = 0; i < F; ++i) acc = fmaf(x[i], Wp[g][i * Mx + j], acc);
+      m += fmaxf(acc, 0.f);  // AddTwoTensors / keras Add
     }
+    mix[sl * kHeadMaxDim + j] = m;
   }
-  float res;
+  __syncthreads();
+  const float* mx = mix + sl * kHeadMaxDim;
   if (kind == 0) {
-    float vp[3];
-    for (int j = 0; j < 3; ++j) {
-      float acc = wt[(int64_t)Mx * 3 + j];
-      for (int i = 0; i < Mx; ++i) acc = fmaf(mix[i * 64 + lane], wt[(int64_t)i * 3 + j], acc);
-      vp[j] = acc;
+    if (jj < 3) {
+      float acc = wt[Mx * 3 + jj];
+      for (int i = 0; i < Mx; ++i) acc = fmaf(mx[i], wt[i * 3 + jj], acc);
+      hid[sl * kHeadMaxDim + jj] = acc;
     }
-    const float Bc = fminf(fmaxf(softplus_exact(vp[1]), 0.f), 20.f);
-    const float Cc = fminf(fmaxf(softplus_exact(vp[2]), 0.1f), 50.f);
-    res = vp[0] + Bc / (T[br] / 100.0f + Cc + 1e-6f);
+    __syncthreads();
+    if (jj == 0 && live) {
+      const float* vp = hid + sl * kHeadMaxDim;
+      const float Bc = fminf(fmaxf(softplus_exact(vp[1]), 0.f), 20.f);
+      const float Cc = fminf(fmaxf(softplus_exact(vp[2]), 0.1f), 50.f);
+      out[b] = vp[0] + Bc / (T[b] / 100.0f + Cc + 1e-6f);
+    }
   } else {
     const float* Wh = wt;
-    const float* bh = Wh + (int64_t)Mx * F;
+    const float* bh = Wh + Mx * F;
     const float* Wo = bh + F;
-    float acc_o = Wo[F];
-    for (int j = 0; j < F; ++j) {
+    for (int j = jj; j < F; j += 32) {
       float acc = bh[j];
-      for (int i = 0; i < Mx; ++i) acc = fmaf(mix[i * 64 + lane], Wh[(int64_t)i * F + j], acc);
-      acc_o = fmaf(fmaxf(acc, 0.f), Wo[j], acc_o);
+      for (int i = 0; i < Mx; ++i) acc = fmaf(mx[i], Wh[i * F + j], acc);
+      hid[sl * kHeadMaxDim + j] = fmaxf(acc, 0.f);
     }
-    res = acc_o;
+    __syncthreads();
+    if (jj == 0 && live) {
+      float acc = Wo[F];
+      for (int j = 0; j < F; ++j) acc = fmaf(hid[sl * kHeadMaxDim + j], Wo[j], acc);
+      out[b] = acc;
+    }
   }
-  if (live) out[b] = res;
 }
 
 inline int grid_for(int64_t items, int block = kBlock, int cap = 256 * 8) {
@@ -754,7 +771,10 @@ int launch_model_head(int kind, const float* pc, const float* pa, const float* T
   if (B == 0) return IMPNN_OK;
   if (D > kHeadMaxDim || F > kHeadMaxDim || Mx > kHeadMaxDim)
     return fail(IMPNN_E_UNSUPPORTED, "model_head: dims D=%d F=%d Mx=%d exceed %d", D, F, Mx, kHeadMaxDim);
-  model_head_kernel<<<(B + 63) / 64, 64, 0, s>>>(kind, pc, pa, T, w, out, B, D, F, Mx);
+  const int wfloats = (int)impnn_model_head_floats(kind, D, F, Mx);
+  const size_t lds = sizeof(float) * (((size_t)wfloats + 3) / 4 * 4 + (size_t)kHeadSPB * 6 * kHeadMaxDim);
+  if (lds > 64 * 1024) return fail(IMPNN_E_UNSUPPORTED, "model_head: weights do not fit LDS");
+  model_head_kernel<<<(B + kHeadSPB - 1) / kHeadSPB, 256, lds, s>>>(kind, pc, pa, T, w, out, B, D, F, Mx, wfloats);
   return check_launch("model_head");
 }
 
