@@ -522,7 +522,7 @@ bool encoder_fused_supported(int N, int E, int D, int K, int S, int Vb) {
   return true;
 }
 
-static int encoder_workgroups() {
+static int compute_units() {
   static int cus = 0;
   if (cus == 0) {
     int dev = 0, n = 0;
@@ -534,9 +534,18 @@ static int encoder_workgroups() {
   return cus;
 }
 
+// One persistent workgroup per CU; for very large batches a multiple of that, so that a share never
+// holds more molecules than plan_chunks resolves in LDS (the extra workgroups simply run in rounds).
+static int encoder_workgroups(int n_ions, int B) {
+  const int cus = compute_units();
+  int f = 1;
+  while ((int64_t)2 * n_ions * B / ((int64_t)cus * f) + 64 > enc::kECap) ++f;
+  return cus * f;
+}
+
 size_t encoder_fused_workspace_bytes(int n_ions, int B, int N, int E, int D, int K, int S, int Vb) {
   (void)D; (void)Vb;
-  return enc::ws_layout(n_ions, B, N, E, K, S, encoder_workgroups()).total;
+  return enc::ws_layout(n_ions, B, N, E, K, S, encoder_workgroups(n_ions, B)).total;
 }
 
 size_t encoder_prepared_bytes(int S) { return (size_t)(S > 0 ? S : 1) * enc::kImgSlot * sizeof(float); }
@@ -562,7 +571,7 @@ int launch_encoder_fused(const EncoderArgs& a, hipStream_t s) {
 
 int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
   using namespace enc;
-  const Ws w = ws_layout(a.n_ions, a.B, a.N, a.E, a.K, a.S, encoder_workgroups());
+  const Ws w = ws_layout(a.n_ions, a.B, a.N, a.E, a.K, a.S, encoder_workgroups(a.n_ions, a.B));
   if (!aligned16(a.workspace)) return fail(IMPNN_E_BADARG, "encoder_fused: workspace must be 16B aligned");
   if (!aligned16(a.atom_table)) return fail(IMPNN_E_BADARG, "encoder_fused: atom_table must be 16B aligned");
   char* base = static_cast<char*>(a.workspace);

@@ -196,6 +196,27 @@ def test_prepared_and_per_call_weight_images_agree_bitwise(mode):
     assert_close(a[0].cpu().numpy(), outs["cat/pooled"], what="cat pooled")
 
 
+@pytest.mark.parametrize("B", [8192, 70000])
+def test_large_batches_shard_consistently(B):
+    """Config 3/4 sizes and a batch big enough to need more persistent workgroups than CUs: sampled molecules
+    against the oracle, and halves recomputed separately must match bit for bit."""
+    inp = synthetic.make_batch(B, seed=12)
+    w = weights.init_weights("viscosity", synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, num_steps=2, seed=13, perturb=True)
+    m = make_model(w, synthetic.DEFAULT_VA, synthetic.DEFAULT_VB)
+    d = to_dev(inp)
+    pc, pa = m.encode_pooled(d, fused=True)
+    idx = np.random.default_rng(1).choice(B, size=48, replace=False)
+    sub = {k: v[idx] for k, v in inp.items()}
+    assert_close(pc.cpu().numpy()[idx], O.encode(w, "cat", sub["cat_atom"], sub["cat_bond"], sub["cat_connectivity"],
+                                                 pooled_only=True), what="cat pooled (sample)")
+    assert_close(pa.cpu().numpy()[idx], O.encode(w, "an", sub["an_atom"], sub["an_bond"], sub["an_connectivity"],
+                                                 pooled_only=True), what="an pooled (sample)")
+    h = B // 2 + 17
+    c0, a0 = m.encode_pooled({k: v[:h].contiguous() for k, v in d.items()}, fused=True)
+    c1, a1 = m.encode_pooled({k: v[h:].contiguous() for k, v in d.items()}, fused=True)
+    assert torch.equal(torch.cat([c0, c1]), pc) and torch.equal(torch.cat([a0, a1]), pa)
+
+
 def test_pipelined_plan_run_matches_single_call(full):
     """impnn_encoder_plan on a side stream + impnn_encoder_run == the one-call path, bit for bit, also when
     two planned batches are in flight and run out of order of planning."""
