@@ -179,6 +179,29 @@ int impnn_encoder_run(int32_t n_ions, const int32_t* const* atom_ids, const floa
                       int32_t K, int32_t S, float ln_eps, void* workspace, size_t workspace_bytes,
                       impnn_stream_t stream);
 
+/* ---- f2: batch assembly on the GPU - the step before the path.  Replaces, per batch, the host list
+ *      handling of train_viscosity.py:291-314: np.array(list)[idx] of id lists shifted by +1
+ *      (train_viscosity.py:255-262), pad_sequences_1d (utils/mp_utils.py:12-16) and
+ *      preprocess_edges_and_bonds (utils/mp_utils.py:18-45: every (src,tgt) followed by (tgt,src) with
+ *      the same bond id, then [0,0]/0 padding or truncation to L = 2*max_edges slots).
+ *      The id dataset of M samples is flattened once, per ion g, into ragged device arrays:
+ *        atom_flat[g] raw atom ids, atom_off[g] (M+1) offsets; edge_flat[g] (src,tgt) pairs and
+ *        bond_flat[g] raw bond ids, both indexed by edge_off[g] (M+1) offsets (a sample's edge and bond
+ *        lists are cut to the shorter of the two, as the reference's zip() does).
+ *      For b < B and s = sample_idx[b]:
+ *        atom_ids[g][b,:]  = atom_flat[g][sample s] + id_shift, right-padded with 0 to N;
+ *        conn[g][b,2e,:]   = edge e, conn[g][b,2e+1,:] = its reverse (NOT shifted), bond_ids[g][b,2e..2e+1] =
+ *        bond e + id_shift; slots >= min(2*n_edges, L) are 0;  t_out[b] = t_flat[s] (optional, may be NULL).
+ *      A sample index outside [0,M) yields an all-padding sample; a sample with more than N atoms is cut
+ *      at N (the reference raises on both: the Python wrapper checks them on the host).
+ *      Pointer arrays are HOST arrays of device pointers; edge_flat / conn 8-byte aligned. */
+int impnn_batch_assemble(int32_t n_ions, const int32_t* sample_idx, int32_t B, int32_t M,
+                         const int32_t* const* atom_flat, const int32_t* const* atom_off,
+                         const int32_t* const* edge_flat, const int32_t* const* bond_flat,
+                         const int32_t* const* edge_off, int32_t id_shift, int32_t N, int32_t L,
+                         int32_t* const* atom_ids, int32_t* const* bond_ids, int32_t* const* conn,
+                         const float* t_flat, float* t_out, impnn_stream_t stream);
+
 /* ---- measurement: HIP-event timing of the dominant kernel (encoder_fused_kernel), recorded on the
  *      stream the kernel is launched on.  After impnn_profile_enable(capacity) every
  *      impnn_encoder_fused call of this thread records one (start, stop) event pair around that

@@ -13,6 +13,7 @@ _lock = threading.Lock()
 _lib = None
 
 i32, i64, f32, vp, sz = C.c_int32, C.c_int64, C.c_float, C.c_void_p, C.c_size_t
+PP = C.POINTER(vp)
 
 # name -> (restype, argtypes); mirrors include/impnn.h one to one
 SIGNATURES = {
@@ -42,6 +43,7 @@ SIGNATURES = {
                                     i32, i32, i32, i32, f32, vp, sz, vp]),
     "impnn_model_head_floats": (i64, [i32, i32, i32, i32]),
     "impnn_model_head": (C.c_int, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "impnn_batch_assemble": (C.c_int, [i32, vp, i32, i32, PP, PP, PP, PP, PP, i32, i32, i32, PP, PP, PP, vp, vp, vp]),
     "impnn_validate_indices": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "impnn_profile_enable": (C.c_int, [i32]),
     "impnn_profile_collect": (C.c_int, [C.POINTER(C.c_float), i32, C.POINTER(i32)]),

@@ -332,6 +332,29 @@ int impnn_debug_set_stamp_buffer(void* device_buffer, size_t bytes) {
   return IMPNN_OK;
 }
 
+int impnn_batch_assemble(int32_t n_ions, const int32_t* sample_idx, int32_t B, int32_t M,
+                         const int32_t* const* atom_flat, const int32_t* const* atom_off,
+                         const int32_t* const* edge_flat, const int32_t* const* bond_flat,
+                         const int32_t* const* edge_off, int32_t id_shift, int32_t N, int32_t L,
+                         int32_t* const* atom_ids, int32_t* const* bond_ids, int32_t* const* conn,
+                         const float* t_flat, float* t_out, impnn_stream_t stream) {
+  REQUIRE(n_ions >= 1 && n_ions <= 2, "n_ions must be 1 or 2");
+  REQUIRE(B >= 0 && M >= 1 && N >= 1 && L >= 0, "bad shape");
+  REQUIRE(atom_flat && atom_off && edge_flat && bond_flat && edge_off && atom_ids && bond_ids && conn,
+          "null pointer array");
+  if (B == 0) return IMPNN_OK;
+  REQUIRE(sample_idx, "null sample_idx");
+  for (int g = 0; g < n_ions; ++g) {
+    REQUIRE(atom_flat[g] && atom_off[g] && edge_off[g] && atom_ids[g], "null per-ion pointer");
+    REQUIRE(L == 0 || (edge_flat[g] && bond_flat[g] && bond_ids[g] && conn[g]), "null per-ion edge pointer");
+    REQUIRE((reinterpret_cast<uintptr_t>(edge_flat[g]) & 7u) == 0 && (reinterpret_cast<uintptr_t>(conn[g]) & 7u) == 0,
+            "edge_flat / conn must be 8-byte aligned");
+  }
+  REQUIRE(!t_out || t_flat, "t_out without t_flat");
+  return launch_batch_assemble(n_ions, sample_idx, B, M, atom_flat, atom_off, edge_flat, bond_flat, edge_off,
+                               id_shift, N, L, atom_ids, bond_ids, conn, t_flat, t_out, as_stream(stream));
+}
+
 int impnn_validate_indices(const int32_t* conn, const int32_t* atom_ids, const int32_t* bond_ids,
                            int32_t* counts, int32_t B, int32_t N, int32_t E, int32_t Va, int32_t Vb,
                            impnn_stream_t stream) {

@@ -50,6 +50,13 @@ int launch_model_head(int kind, const float* pc, const float* pa, const float* T
 int launch_validate_indices(const int32_t* conn, const int32_t* atom_ids, const int32_t* bond_ids,
                             int32_t* counts, int B, int N, int E, int Va, int Vb, hipStream_t s);
 
+// ---- batch assembly (loader_kernels.hip)
+int launch_batch_assemble(int n_ions, const int32_t* sample_idx, int B, int M, const int32_t* const* atom_flat,
+                          const int32_t* const* atom_off, const int32_t* const* edge_flat,
+                          const int32_t* const* bond_flat, const int32_t* const* edge_off, int shift, int N, int L,
+                          int32_t* const* atom_ids, int32_t* const* bond_ids, int32_t* const* conn,
+                          const float* t_flat, float* t_out, hipStream_t s);
+
 // ---- event-pair profiler (api.hip); record_* are no-ops unless enabled on this thread
 void profile_record_start(hipStream_t s);
 void profile_record_stop(hipStream_t s);

@@ -1,0 +1,89 @@
+// Batch assembly on the GPU: the step before the hot path.
+//
+// The reference builds every batch on the host from Python lists: +1 id shift
+// (train_viscosity.py:255-262), a second reverse-edge expansion with [0,0] padding / truncation
+// (utils/mp_utils.py:18-45), atom-id padding (utils/mp_utils.py:12-16), np.array(list)[idx]
+// (train_viscosity.py:291-314).  Here the id dataset is flattened once into ragged arrays that stay
+// resident in HBM, and one launch writes the padded (B,N) / (B,L) / (B,L,2) model inputs of both ions
+// for an arbitrary list of sample indices.  Integer copies only: HBM-bound, one wave per (ion, sample),
+// every store coalesced.
+#include "common.h"
+
+namespace impnn {
+namespace {
+
+struct AssembleParams {
+  int n_ions, B, M, N, L, shift;
+  const int32_t* sample_idx;
+  const int32_t* atom_flat[2];
+  const int32_t* atom_off[2];
+  const int32_t* edge_flat[2];
+  const int32_t* bond_flat[2];
+  const int32_t* edge_off[2];
+  int32_t* atom_ids[2];
+  int32_t* bond_ids[2];
+  int32_t* conn[2];
+  const float* t_flat;
+  float* t_out;
+};
+
+constexpr int kUnitsPerBlock = 4;
+
+__global__ __launch_bounds__(kUnitsPerBlock* kWave) void batch_assemble_kernel(AssembleParams p) {
+  const int unit = blockIdx.x * kUnitsPerBlock + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (unit >= p.n_ions * p.B) return;
+  const int g = unit >= p.B ? 1 : 0;
+  const int b = unit - g * p.B;
+  int s = __builtin_amdgcn_readfirstlane(p.sample_idx[b]);
+  const bool present = s >= 0 && s < p.M;  // an index outside the dataset yields an all-padding sample
+  if (!present) s = 0;
+
+  const int a0 = __builtin_amdgcn_readfirstlane(p.atom_off[g][s]);
+  const int na = present ? min(__builtin_amdgcn_readfirstlane(p.atom_off[g][s + 1]) - a0, p.N) : 0;
+  int32_t* arow = p.atom_ids[g] + (size_t)b * p.N;
+  for (int n = lane; n < p.N; n += kWave) arow[n] = n < na ? p.atom_flat[g][a0 + n] + p.shift : 0;
+
+  const int e0 = __builtin_amdgcn_readfirstlane(p.edge_off[g][s]);
+  const int ne = present ? __builtin_amdgcn_readfirstlane(p.edge_off[g][s + 1]) - e0 : 0;
+  const int take = min(2 * ne, p.L);  // slots 2e, 2e+1 = edge e and its reverse; cut at L
+  int2* crow = reinterpret_cast<int2*>(p.conn[g]) + (size_t)b * p.L;
+  int32_t* brow = p.bond_ids[g] + (size_t)b * p.L;
+  const int2* eflat = reinterpret_cast<const int2*>(p.edge_flat[g]);
+  for (int j = lane; j < p.L; j += kWave) {
+    int2 c = make_int2(0, 0);
+    int bd = 0;
+    if (j < take) {
+      const int2 uv = eflat[e0 + (j >> 1)];
+      c = (j & 1) ? make_int2(uv.y, uv.x) : uv;
+      bd = p.bond_flat[g][e0 + (j >> 1)] + p.shift;
+    }
+    crow[j] = c;
+    brow[j] = bd;
+  }
+  if (g == 0 && p.t_out && lane == 0) p.t_out[b] = present ? p.t_flat[s] : 0.0f;
+}
+
+}  // namespace
+
+int launch_batch_assemble(int n_ions, const int32_t* sample_idx, int B, int M, const int32_t* const* atom_flat,
+                          const int32_t* const* atom_off, const int32_t* const* edge_flat,
+                          const int32_t* const* bond_flat, const int32_t* const* edge_off, int shift, int N, int L,
+                          int32_t* const* atom_ids, int32_t* const* bond_ids, int32_t* const* conn,
+                          const float* t_flat, float* t_out, hipStream_t s) {
+  AssembleParams p{};
+  p.n_ions = n_ions; p.B = B; p.M = M; p.N = N; p.L = L; p.shift = shift;
+  p.sample_idx = sample_idx;
+  for (int g = 0; g < n_ions; ++g) {
+    p.atom_flat[g] = atom_flat[g]; p.atom_off[g] = atom_off[g]; p.edge_flat[g] = edge_flat[g];
+    p.bond_flat[g] = bond_flat[g]; p.edge_off[g] = edge_off[g];
+    p.atom_ids[g] = atom_ids[g]; p.bond_ids[g] = bond_ids[g]; p.conn[g] = conn[g];
+  }
+  p.t_flat = t_flat; p.t_out = t_out;
+  const int units = n_ions * B;
+  hipLaunchKernelGGL(batch_assemble_kernel, dim3((units + kUnitsPerBlock - 1) / kUnitsPerBlock),
+                     dim3(kUnitsPerBlock * kWave), 0, s, p);
+  return check_launch("batch_assemble");
+}
+
+}  // namespace impnn

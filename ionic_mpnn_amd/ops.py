@@ -52,6 +52,39 @@ def validate_indices(conn=None, atom_ids=None, bond_ids=None, N=None, Va=1 << 30
         raise ValueError(f"out-of-range indices: connectivity={c[0]} atom_ids={c[1]} bond_ids={c[2]}")
 
 
+def batch_assemble(sample_idx, ions, max_atoms, slots, id_shift=1, t_flat=None):
+    """train_viscosity.py:291-314 build_inputs(idx) on the GPU (impnn_batch_assemble).
+
+    ions: per ion a dict of resident int32 device tensors atom_flat, atom_off (M+1), edge_flat (n,2),
+    bond_flat, edge_off (M+1).  Returns per ion (atom_ids (B,N), bond_ids (B,slots), conn (B,slots,2))
+    and the gathered t (B,1) or None."""
+    require_gpu(sample_idx, *[t for ion in ions for t in ion.values()])
+    sample_idx = i32c(sample_idx)
+    dev = sample_idx.device
+    B, n = int(sample_idx.numel()), len(ions)
+    M = int(ions[0]["atom_off"].numel()) - 1
+    outs = [(torch.empty(B, max_atoms, dtype=torch.int32, device=dev),
+             torch.empty(B, slots, dtype=torch.int32, device=dev),
+             torch.empty(B, slots, 2, dtype=torch.int32, device=dev)) for _ in range(n)]
+    t_out = torch.empty(B, 1, dtype=torch.float32, device=dev) if t_flat is not None else None
+    arr = C.c_void_p * n
+    mk = lambda ts: arr(*[t.data_ptr() for t in ts])
+    for ion in ions:
+        for k in ("atom_flat", "atom_off", "edge_flat", "bond_flat", "edge_off"):
+            if ion[k].dtype != torch.int32 or not ion[k].is_contiguous():
+                raise ValueError(f"{k} must be a contiguous int32 tensor")
+        if ion["atom_off"].numel() != M + 1 or ion["edge_off"].numel() != M + 1:
+            raise ValueError("offset tables must have M+1 entries")
+    with torch.cuda.device(dev):
+        check(_lib.load().impnn_batch_assemble(
+            n, ptr(sample_idx), B, M, mk([i["atom_flat"] for i in ions]), mk([i["atom_off"] for i in ions]),
+            mk([i["edge_flat"] for i in ions]), mk([i["bond_flat"] for i in ions]), mk([i["edge_off"] for i in ions]),
+            int(id_shift), int(max_atoms), int(slots), mk([o[0] for o in outs]), mk([o[1] for o in outs]),
+            mk([o[2] for o in outs]), ptr(f32c(t_flat)) if t_flat is not None else None,
+            ptr(t_out) if t_out is not None else None, stream_ptr()))
+    return outs, t_out
+
+
 def bmm_message(h, bond_state, conn, W):
     """BondMatrixMessage.call, models/layers.py:100-117 -> messages (B,E,D)."""
     require_gpu(h, bond_state, conn, W)

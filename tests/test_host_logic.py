@@ -91,3 +91,19 @@ def test_initialisers():
     assert abs(e).max() <= 0.05
     w = W.init_weights("viscosity", 124, 72, num_steps=3)
     assert W.num_steps_of(w) == 3 and float(abs(w["cat_gu_0/dense_z/bias"]).max()) == 0.0
+
+
+def test_flatten_ion_ragged_layout():
+    """The resident layout of the loader (data.flatten_ion): raw ids, zip()-cut edge/bond lists, int32 offsets."""
+    from ionic_mpnn_amd import data
+    recs = [
+        {"cation": {"atom_ids": [3, 1], "bond_ids": [2, 2], "edge_indices": [(0, 1), (1, 0)]}},
+        {"cation": {"atom_ids": [], "bond_ids": [], "edge_indices": []}},
+        {"cation": {"atom_ids": [5, 6, 7], "bond_ids": [1, 1, 4], "edge_indices": [(0, 1), (1, 0), (1, 2), (2, 1)]}},
+    ]
+    f = data.flatten_ion(recs, "cation")
+    assert f["atom_off"].tolist() == [0, 2, 2, 5] and f["edge_off"].tolist() == [0, 2, 2, 5]
+    assert f["atom_flat"][:5].tolist() == [3, 1, 5, 6, 7]
+    assert f["edge_flat"][:5].tolist() == [[0, 1], [1, 0], [0, 1], [1, 0], [1, 2]]  # 4th edge cut: only 3 bond ids
+    assert f["bond_flat"][:5].tolist() == [2, 2, 1, 1, 4]
+    assert all(v.dtype == np.int32 for v in f.values())
