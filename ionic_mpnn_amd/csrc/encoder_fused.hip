@@ -49,18 +49,46 @@ namespace {
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ float fast_sigmoid(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * x));
+// Keeps a quad assembled from scalar results in one register tuple (no instruction is emitted): without
+// it the compiler splits the following vector arithmetic back into scalar v_add / v_mul.
+__device__ __forceinline__ f32x4 as_tuple(f32x4 v) {
+  asm("" : "+v"(v));
+  return v;
 }
-__device__ __forceinline__ float fast_tanh(float x) {
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177793f * x));
+// Activations on whole accumulator quads, written as vector arithmetic so that the multiplies / adds
+// around the quarter-rate v_exp_f32 / v_rcp_f32 become packed v_pk_{mul,add,fma}_f32 (two lanes of work
+// per instruction).  SCALED: the accumulator carries the mode-1 scale kAcc (folded into the constant).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// A splat constant held in an SGPR pair: packed-f32 instructions cannot encode a 32-bit literal, so with a
+// literal the compiler falls back to one scalar multiply per element.
+__device__ __forceinline__ f32x4 splat_sgpr(float c) {
+  f32x2 v = {c, c};
+  asm("" : "+s"(v));
+  return __builtin_shufflevector(v, v, 0, 1, 0, 1);
 }
-// the same on an accumulator that carries the mode-1 scale kAcc (the division is folded into the constant)
-__device__ __forceinline__ float fast_sigmoid_scaled(float x) {
-  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((-1.44269504088896f / kAcc) * x));
+template <bool SCALED>
+__device__ __forceinline__ f32x4 sigmoid4(f32x4 x) {
+  const f32x4 a = x * splat_sgpr(SCALED ? -1.44269504088896f / kAcc : -1.44269504088896f);
+  f32x4 e;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(a[i]);
+  const f32x4 d = as_tuple(as_tuple(e) + 1.0f);
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_rcpf(d[i]);
+  return as_tuple(r);
 }
-__device__ __forceinline__ float fast_tanh_scaled(float x) {
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((2.88539008177793f / kAcc) * x));
+template <bool SCALED>
+__device__ __forceinline__ f32x4 tanh4(f32x4 x) {
+  const f32x4 a = x * splat_sgpr(SCALED ? 2.88539008177793f / kAcc : 2.88539008177793f);
+  f32x4 e;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(a[i]);
+  const f32x4 d = as_tuple(as_tuple(e) + 1.0f);
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_rcpf(d[i]);
+  return 1.0f - 2.0f * as_tuple(r);
 }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
@@ -302,11 +330,8 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
             }
           }
           // accumulators carry kAcc; keep agg as agg*kSX: the B-operand scale of the next GEMMs
-  #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            agg0[i] *= (kSX / kAcc);
-            agg1[i] *= (kSX / kAcc);
-          }
+          agg0 *= (kSX / kAcc);
+          agg1 *= (kSX / kAcc);
         } else {
   #pragma unroll
           for (int k = 0; k < kKMax; ++k) {
@@ -338,12 +363,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
         f32x4 t0 = ld4(wvec + 2 * kD + 4 * q), t1 = ld4(wvec + 2 * kD + 16 + 4 * q);
         f32x4 rh0, rh1;
         if constexpr (SPLIT) {
-          f32x4 hs0, hs1;  // h * kSX
-  #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            hs0[i] = h0[i] * kSX;
-            hs1[i] = h1[i] * kSX;
-          }
+          const f32x4 hs0 = h0 * kSX, hs1 = h1 * kSX;
           const H8 sh = split8(hs0, hs1);
           const H8 sa = split8(agg0, agg1);
           // block index = ((gate*2 + T)*2 + half), 1024 halfs each
@@ -356,14 +376,9 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
           mma3(r0, hupd + ((1 * 2 + 0) * 2 + 1) * 1024, lane, sa);
           mma3(r1, hupd + ((1 * 2 + 1) * 2 + 1) * 1024, lane, sa);
           if (tstamp && lane == 0) stamp[11] = __builtin_amdgcn_s_memtime();
-          f32x4 rs0, rs1;  // sigmoid(r) * h * kSX
-  #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            z0[i] = fast_sigmoid_scaled(z0[i]);  // accumulators carry kAcc: folded into the exp2 constant
-            z1[i] = fast_sigmoid_scaled(z1[i]);
-            rs0[i] = fast_sigmoid_scaled(r0[i]) * hs0[i];  // :149
-            rs1[i] = fast_sigmoid_scaled(r1[i]) * hs1[i];
-          }
+          z0 = sigmoid4<true>(z0);  // accumulators carry kAcc: folded into the exp2 constant
+          z1 = sigmoid4<true>(z1);
+          const f32x4 rs0 = sigmoid4<true>(r0) * hs0, rs1 = sigmoid4<true>(r1) * hs1;  // :149, times kSX
           const H8 srh = split8(rs0, rs1);
           mma3(t0, hupd + ((2 * 2 + 0) * 2 + 0) * 1024, lane, srh);
           mma3(t1, hupd + ((2 * 2 + 1) * 2 + 0) * 1024, lane, srh);
@@ -390,13 +405,10 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
             }
           }
           if (tstamp && lane == 0) stamp[11] = __builtin_amdgcn_s_memtime();
-  #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            z0[i] = fast_sigmoid(z0[i]);
-            z1[i] = fast_sigmoid(z1[i]);
-            rh0[i] = fast_sigmoid(r0[i]) * h0[i];  // :149
-            rh1[i] = fast_sigmoid(r1[i]) * h1[i];
-          }
+          z0 = sigmoid4<false>(z0);
+          z1 = sigmoid4<false>(z1);
+          rh0 = sigmoid4<false>(r0) * h0;  // :149
+          rh1 = sigmoid4<false>(r1) * h1;
   #pragma unroll
           for (int half = 0; half < 2; ++half) {
   #pragma unroll
@@ -415,37 +427,25 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
         }
         if (tstamp && lane == 0) stamp[12] = __builtin_amdgcn_s_memtime();
         // ---- blend, LayerNorm, residual  (models/layers.py:153-155)
-        f32x4 n0, n1;
-        float sum = 0.f;
-  #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          // (1-z) h + z t == h + z (t - h)
-          n0[i] = fmaf(z0[i], (SPLIT ? fast_tanh_scaled(t0[i]) : fast_tanh(t0[i])) - h0[i], h0[i]);
-          n1[i] = fmaf(z1[i], (SPLIT ? fast_tanh_scaled(t1[i]) : fast_tanh(t1[i])) - h1[i], h1[i]);
-          sum += n0[i] + n1[i];
-        }
+        // (1-z) h + z t == h + z (t - h); vector arithmetic throughout (packed f32 instructions)
+        f32x4 n0 = z0 * (tanh4<SPLIT>(t0) - h0) + h0;
+        f32x4 n1 = z1 * (tanh4<SPLIT>(t1) - h1) + h1;
+        const f32x4 s4 = n0 + n1;
+        float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         sum += __shfl_xor(sum, 16);
         sum += __shfl_xor(sum, 32);
         const float mean = sum * (1.0f / kD);
-        float var = 0.f;
-  #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          n0[i] -= mean;
-          n1[i] -= mean;
-          var = fmaf(n0[i], n0[i], var);
-          var = fmaf(n1[i], n1[i], var);
-        }
+        n0 -= mean;
+        n1 -= mean;
+        const f32x4 q4 = n0 * n0 + n1 * n1;
+        float var = (q4[0] + q4[1]) + (q4[2] + q4[3]);
         var += __shfl_xor(var, 16);
         var += __shfl_xor(var, 32);
-        const float inv = 1.0f / sqrtf(var * (1.0f / kD) + p.ln_eps);
+        const float inv = __builtin_amdgcn_rsqf(var * (1.0f / kD) + p.ln_eps);
         const f32x4 g0 = ld4(wvec + 3 * kD + 4 * q), g1 = ld4(wvec + 3 * kD + 16 + 4 * q);
         const f32x4 b0 = ld4(wvec + 4 * kD + 4 * q), b1 = ld4(wvec + 4 * kD + 16 + 4 * q);
-        f32x4 o0, o1;
-  #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          o0[i] = n0[i] * inv * g0[i] + b0[i] + h0[i];
-          o1[i] = n1[i] * inv * g1[i] + b1[i] + h1[i];
-        }
+        const f32x4 o0 = n0 * (g0 * inv) + (b0 + h0);
+        const f32x4 o1 = n1 * (g1 * inv) + (b1 + h1);
         st4(hnext + row * kHS + 4 * q, o0);
         st4(hnext + row * kHS + 16 + 4 * q, o1);
 

@@ -180,6 +180,65 @@ __global__ void weight_image_kernel(ImageParams p) {
 __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int lane, int& g, int& k0, int& bp0,
                                               int& t_lo, int& t_hi) {
   const int nblk = p.nblk;
+  // All partial sums are fetched up front with clamped, unconditional addresses (kPU x 64 per ion and
+  // pass): the loads of a pass are in flight together, and the block search below works on the same
+  // registers instead of reading the table a second time.
+  constexpr int kPU = 4;
+  const int npass = (nblk + 64 * kPU - 1) / (64 * kPU);
+  if (npass == 1) {  // B <= 4096 molecules per ion: one pass, everything stays in registers
+    int v[2][kPU];
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+      for (int i = 0; i < kPU; ++i) {
+        const int k = lane + 64 * i;
+        const int kk = k < nblk ? k : nblk - 1;
+        const int x = gi < p.n_ions ? p.partial[(int64_t)gi * nblk + kk] : 0;
+        v[gi][i] = k < nblk ? x : 0;
+      }
+    int incl[2][kPU], tot[2];
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+      int carry = 0;
+#pragma unroll
+      for (int i = 0; i < kPU; ++i) {
+        incl[gi][i] = carry + wave_incl_scan(v[gi][i]);
+        carry = __builtin_amdgcn_readlane(incl[gi][i], 63);
+      }
+      tot[gi] = carry;
+    }
+    int nwg0 = p.nwg, nwg1 = 0;
+    if (p.n_ions == 2) {
+      const long long t0 = tot[0], t1 = tot[1];
+      int n0 = (t0 + t1) > 0 ? (int)((p.nwg * t0 + (t0 + t1) / 2) / (t0 + t1)) : p.nwg / 2;
+      if (p.nwg >= 2) n0 = n0 < 1 ? 1 : (n0 > p.nwg - 1 ? p.nwg - 1 : n0);
+      nwg0 = n0;
+      nwg1 = p.nwg - n0;
+    }
+    g = j < nwg0 ? 0 : 1;
+    const int jj = j - (g ? nwg0 : 0);
+    const int nwg_g = g ? nwg1 : nwg0;
+    const long long tg = tot[g];
+    t_lo = (int)(tg * jj / nwg_g);
+    t_hi = (jj + 1 == nwg_g) ? (int)tg : (int)(tg * (jj + 1) / nwg_g);
+    k0 = 0;
+    bp0 = 0;
+    if (t_hi <= t_lo) return false;
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < kPU; ++i) {
+      const int vv = g ? v[1][i] : v[0][i];
+      const int st = (g ? incl[1][i] : incl[0][i]) - vv;
+      const unsigned long long hit = __ballot(st <= t_lo && t_lo < st + vv);
+      if (hit && !found) {
+        const int src = __builtin_ctzll(hit);
+        k0 = 64 * i + src;
+        bp0 = __shfl(st, src);
+        found = true;
+      }
+    }
+    return found;
+  }
   long long tot[2] = {0, 0};
   for (int gi = 0; gi < p.n_ions; ++gi) {
     const int32_t* part = p.partial + (int64_t)gi * nblk;
@@ -259,9 +318,14 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
     int run = bp0;  // prefix at molecule k0 * 16
     int first = -1, nsh = 0;                          // first share molecule (global index), count
     int end_row = -1;                                 // first virtual row after the share's last molecule
+    // clamped addresses, masked values; the loads of the next two 64-molecule groups are always in flight
+    auto vr_at = [&](int m) { return vrg[m < p.B ? m : p.B - 1]; };
+    int v_n1 = vr_at(k0 * kPB + lane), v_n2 = vr_at(k0 * kPB + 64 + lane);
     for (int mbase = k0 * kPB; mbase < p.B && end_row < 0; mbase += 64) {
       const int m = mbase + lane;
-      const int v = vrg[m < p.B ? m : p.B - 1];  // clamped address, masked value
+      const int v = v_n1;
+      v_n1 = v_n2;
+      v_n2 = vr_at(mbase + 128 + lane);
       const int vv = m < p.B ? v : 0;
       const int incl = wave_incl_scan(vv);
       const int st = run + incl - vv;  // first virtual row of molecule m
