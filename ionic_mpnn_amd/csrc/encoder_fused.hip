@@ -264,17 +264,21 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
           my_tile = heavy + slot * r4 + grp;
         }
       }
-      for (int tile = my_tile; tile >= 0 && tile < ntiles; tile = -1) {
-        const bool tstamp = false;
-        const int row = tile * 16 + a;
-        const f32x4 h0 = ld4(hcur + row * kHS + 4 * q);
-        const f32x4 h1 = ld4(hcur + row * kHS + 16 + 4 * q);
+      const bool has_tile = my_tile >= 0 && my_tile < ntiles;
+      const int tile = has_tile ? my_tile : 0;
+      const int row = tile * 16 + a;
+      const bool tstamp = false;
+      float G[kKMax][8];
+      if (has_tile) {
+        // A wave's issue priority falls as it advances through its tile (gather 3, message 2, gates 1, rest 0): the SIMD
+        // arbiter otherwise serves the oldest wave first, so the four waves of a SIMD finish one after
+        // another and the last one runs alone, with every latency exposed (measured: -4% step time).
+        __builtin_amdgcn_s_setprio(3);
 
         // ---- pull gather: G[k][j] = sum_{in-edges} tb[bond][k] * h[src][j]   (edge-slot order)
         const int p0 = r_rowptr[row];
         const int deg = r_rowptr[row + 1] - p0;
         const int maxdeg = __builtin_amdgcn_readfirstlane(r_tilemax[tile]);
-        float G[kKMax][8];
         {
           // first in-edge initialises G (rows without in-edges use a zero coefficient vector)
           const uint32_t ent = r_ent[deg > 0 ? p0 : 0];
@@ -317,6 +321,13 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
           }
         }
         if (tstamp && lane == 0) stamp[9] = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_setprio(2);
+        // The image of this step was stored after the previous step's barrier, without a barrier of its own:
+        // the gather above needs no weights, so those LDS stores ran under it.  From here on they are needed.
+        // (Waves without a tile meet this barrier in the else branch below: whole waves take either path.)
+        if (s > 0) lds_barrier();
+        const f32x4 h0 = ld4(hcur + row * kHS + 4 * q);  // the row's own state
+        const f32x4 h1 = ld4(hcur + row * kHS + 16 + 4 * q);
 
         // ---- agg^T = sum_k W_k * G_k   (models/layers.py:108-112 + 78-82, reassociated)
         f32x4 agg0 = {0.f, 0.f, 0.f, 0.f}, agg1 = {0.f, 0.f, 0.f, 0.f};
@@ -350,6 +361,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
           }
         }
         if (tstamp && lane == 0) stamp[10] = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_setprio(1);
         // next step's weight image starts its flight now (G is dead: registers are free)
         if (!pf_issued) {
   #pragma unroll
@@ -426,6 +438,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
           }
         }
         if (tstamp && lane == 0) stamp[12] = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_setprio(0);
         // ---- blend, LayerNorm, residual  (models/layers.py:153-155)
         // (1-z) h + z t == h + z (t - h); vector arithmetic throughout (packed f32 instructions)
         f32x4 n0 = z0 * (tanh4<SPLIT>(t0) - h0) + h0;
@@ -451,13 +464,17 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
 
       }
       if (!pf_issued) {  // waves without a tile in this chunk still carry their share of the image
+        if (s > 0) lds_barrier();
 #pragma unroll
         for (int i = 0; i < kPf; ++i) pf[i] = ld4(nxt + 4 * (tid + i * kThreads));
       }
+      const bool wstamp = stamp && c == c_begin && s == 1;  // diagnostics: when each wave reaches the step barrier
+      if (wstamp && lane == 0) stamp[16 + wave] = __builtin_amdgcn_s_memtime();
       __syncthreads();
+      if (wstamp && tid == 0) stamp[13] = __builtin_amdgcn_s_memtime();
 #pragma unroll
       for (int i = 0; i < kPf; ++i) st4(wimg + 4 * (tid + i * kThreads), pf[i]);
-      __syncthreads();
+      if (stamp && c == c_begin && s < 2 && tid == 0) stamp[14 + s] = __builtin_amdgcn_s_memtime();  // 14: end of step 0, 15: end of step 1
     }
     if (stamp && tid == 0) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();

@@ -47,3 +47,18 @@ print(f"persistent workgroups with work: {live.sum()} of {nwg}; chunks per workg
 print(f"cycles per workgroup: total mean {tot.mean():.0f} max {tot.max()} min {tot.min()} | prologues {pro.mean():.0f} "
       f"steps {steps.mean():.0f} pools {pool.mean():.0f}")
 print(f"per chunk: prologue {(pro / nch).mean():.0f}  steps {(steps / nch).mean():.0f}  pool {(pool / nch).mean():.0f}")
+
+# one step (first chunk, step 1) in detail: when each wave reaches the step barrier, barrier + image copy cost
+t0 = st[:, 14]                      # end of step 0 == start of step 1
+arr = st[:, 16:32] - t0[:, None]    # per-wave arrival at the barrier
+rel = st[:, 13] - t0                # all waves through the first barrier
+end = st[:, 15] - t0                # image copied, second barrier passed
+ok = (t0 > 0) & (st[:, 15] > 0)
+arr, rel, end = arr[ok], rel[ok], end[ok]
+srt = np.sort(arr, axis=1)
+print(f"step 1 of the first chunk ({ok.sum()} workgroups): duration {end.mean():.0f}; waves reach the barrier at "
+      f"min {srt[:, 0].mean():.0f} / 25% {srt[:, 4].mean():.0f} / median {srt[:, 8].mean():.0f} / 75% {srt[:, 12].mean():.0f} / "
+      f"last {srt[:, 15].mean():.0f}; barrier released {rel.mean():.0f}; copy + 2nd barrier {(end - rel).mean():.0f}")
+bysimd = arr.reshape(-1, 4, 4)      # [wg, slot, simd]  (wave = slot * 4 + simd)
+print("  last arrival per SIMD (mean):", [int(x) for x in bysimd.max(axis=1).mean(axis=0)],
+      " first:", [int(x) for x in bysimd.min(axis=1).mean(axis=0)])
