@@ -103,6 +103,9 @@ def main():
                     help="enqueue the plan kernels of step i+1 on a side stream before the encoder of step i "
                          "(default: plan and encode every batch back to back on one stream, which is faster on "
                          "MI355X: the encoder fills every CU's register file, see include/impnn.h)")
+    ap.add_argument("--ramp-ms", type=float, default=150.0,
+                    help="untimed clock ramp before the W warm-up steps: the same step() repeated for this many "
+                         "milliseconds (0 disables)")
     ap.add_argument("--mode", choices=["auto", "f32", "f16x2"], default="auto",
                     help="GEMM arithmetic of the fused encoder (include/impnn.h); auto = f16x2 when the static "
                          "range bound holds, else exact f32")
@@ -149,6 +152,16 @@ def main():
         return out
 
     lib = _lib.load()
+    # Untimed: bring the GPU to its sustained clock first.  An idle MI355X runs the first few hundred
+    # launches ~13 % slower (measured: 92 us -> 80 us per encoder launch after ~30 ms of load), and the
+    # default W=10 warm-up is 1 ms of work.  Same step() as the timed loop; nothing is cached across steps.
+    ramp_steps = 0
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < args.ramp_ms:
+        for _ in range(20):
+            pc, pa = step()
+        torch.cuda.synchronize()
+        ramp_steps += 20
     for _ in range(args.warmup):
         pc, pa = step()
     torch.cuda.synchronize()
@@ -226,6 +239,8 @@ def main():
                                 "step still plans and encodes one full batch") if pipelined else "none",
                    "global_batch": int(total_pairs), "parallelism": f"batch-sharded x{world}, weights replicated, "
                    "no data-path collective; one all-reduce of the fingerprint checksum after the timed region",
+                   "clock_ramp": f"{ramp_steps} untimed steps ({args.ramp_ms:g} ms) before the {args.warmup} warm-up steps, "
+                                 "so that the timed steps run at the sustained GPU clock",
                    "checksum": float(local_sum[0].item())},
     }
     if full_ms:
