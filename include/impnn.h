@@ -202,6 +202,49 @@ int impnn_batch_assemble(int32_t n_ions, const int32_t* sample_idx, int32_t B, i
                          int32_t* const* atom_ids, int32_t* const* bond_ids, int32_t* const* conn,
                          const float* t_flat, float* t_out, impnn_stream_t stream);
 
+/* ---- f4: backward of the layer-at-a-time path and the optimizer step - what Keras autodiff and
+ *      keras.optimizers.Adam(1e-3, clipnorm=1.0) do inside model.fit (train_viscosity.py:227-230,328-338;
+ *      train_melting_point.py:205-208).  Every kernel is the adjoint of the forward entry of the same name,
+ *      with the same masks and the same "out-of-range index == padding" rule.  Buffers marked (+=) must be
+ *      zeroed (or hold a running sum) before the call: they are accumulated with float atomics.
+ *
+ *  Embedding (a1/a2):        dtable[ids[r],:] (+=) dout[r,:]
+ *  Reduce (a5, :57-83):      dmessages[b,e,:] = tgt > 0 ? dagg[b,tgt,:] : 0
+ *  GlobalSumPool (a8):       dh[b,n,:] = atom_ids[b,n] > 0 ? dpooled[b,:] : 0
+ *  BondMatrixMessage (a4) in the per-bond-type schedule (impnn_bond_type_matrices + impnn_bmm_message_typed):
+ *      dh[b,src,:] (+=) A[type]^T dmessages[b,e,:];   dtype_mats[type] (+=) dmessages[b,e,:] (x) h[b,src,:]
+ *      then   dW[k] = sum_v Tb[v,k] dtype_mats[v];     dbond_table[v,k] = <dtype_mats[v], W[k]>
+ *  GatedUpdate (a7, :142-156): dh, dagg (rows,D) and dparams in the canonical order
+ *      Wz 2D*D | bz D | Wr | br | Wh | bh | gamma | beta  (impnn_gated_update_param_floats(D) floats, overwritten);
+ *      intermediates are recomputed from (h, agg); the parameter sums go through per-workgroup partials in
+ *      `workspace` (impnn_gated_update_bwd_workspace_floats) added in a fixed order: bitwise reproducible. */
+int impnn_embed_gather_bwd(const int32_t* ids, const float* dout, float* dtable, int64_t rows, int32_t vocab,
+                           int32_t dim, impnn_stream_t stream);
+int impnn_reduce_scatter_bwd(const float* dagg, const int32_t* tgt, int32_t tgt_stride, float* dmessages, int32_t B,
+                             int32_t N, int32_t E, int32_t D, impnn_stream_t stream);
+int impnn_global_sum_pool_bwd(const float* dpooled, const int32_t* atom_ids, float* dh, int32_t B, int32_t N,
+                              int32_t D, impnn_stream_t stream);
+int impnn_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn,
+                                const float* type_mats, const float* dmessages, float* dh, float* dtype_mats,
+                                int32_t B, int32_t N, int32_t E, int32_t D, int32_t Vb, impnn_stream_t stream);
+int impnn_bond_type_matrices_bwd(const float* bond_table, const float* W, const float* dtype_mats, float* dW,
+                                 float* dbond_table, int32_t Vb, int32_t K, int32_t D, impnn_stream_t stream);
+int64_t impnn_gated_update_param_floats(int32_t D);
+int64_t impnn_gated_update_bwd_workspace_floats(int64_t rows, int32_t D);
+int impnn_gated_update_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
+                           const float* br, const float* Wh, const float* bh, const float* gamma, float ln_eps,
+                           const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
+                           int64_t workspace_floats, int64_t rows, int32_t D, impnn_stream_t stream);
+
+/*  Optimizer step, one launch for all variables (train_viscosity.py:227-230):
+ *      g <- g * clipnorm / max(||g||_2, clipnorm)      per variable (tf.clip_by_norm); clipnorm <= 0: off
+ *      m <- b1 m + (1-b1) g;   v <- b2 v + (1-b2) g^2
+ *      w <- w - lr * sqrt(1 - b2^step) / (1 - b1^step) * m / (sqrt(v) + eps)         (step counts from 1)
+ *  var_table: DEVICE array of 4*n_vars device pointers (w, g, m, v per variable, all f32);
+ *  sizes: DEVICE array of n_vars element counts. */
+int impnn_adam_clipnorm_step(const void* var_table, const int64_t* sizes, int32_t n_vars, int64_t step, float lr,
+                             float beta1, float beta2, float eps, float clipnorm, impnn_stream_t stream);
+
 /* ---- measurement: HIP-event timing of the dominant kernel (encoder_fused_kernel), recorded on the
  *      stream the kernel is launched on.  After impnn_profile_enable(capacity) every
  *      impnn_encoder_fused call of this thread records one (start, stop) event pair around that

@@ -1,0 +1,153 @@
+"""Autograd nodes of the layer-at-a-time path: each forward is the libimpnn entry of
+the reference layer, each backward the matching ``impnn_*_bwd`` entry (csrc/train_kernels.hip).
+``ops.*`` routes through these nodes whenever an input requires grad and grad mode is on; with no grad
+the calls are the plain forward entries.  torch.autograd only keeps the graph - no torch op computes here."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, ops
+from ._lib import check, f32c, i32c, ptr, stream_ptr
+
+
+def _lib_call(device, fn, *args):
+    with torch.cuda.device(device):
+        check(fn(*args, stream_ptr()))
+
+
+class EmbedGather(torch.autograd.Function):
+    """Embedding lookup (train_viscosity.py:171-172)."""
+
+    @staticmethod
+    def forward(ctx, ids, table):
+        ids = i32c(ids)
+        ctx.save_for_backward(ids)
+        ctx.table_shape = tuple(table.shape)
+        return ops.embed_gather(ids, table)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        V, dim = ctx.table_shape
+        dtable = torch.zeros(V, dim, dtype=torch.float32, device=dout.device)
+        dout = f32c(dout)
+        _lib_call(dout.device, _lib.load().impnn_embed_gather_bwd, ptr(ids), ptr(dout), ptr(dtable), ids.numel(), V, dim)
+        return None, dtable
+
+
+class BondTypeMatrices(torch.autograd.Function):
+    """A[v] = sum_k Tb[v,k] W[k] (models/layers.py:108, once per vocabulary entry)."""
+
+    @staticmethod
+    def forward(ctx, bond_table, W):
+        bond_table, W = f32c(bond_table), f32c(W)
+        ctx.save_for_backward(bond_table, W)
+        return ops.bond_type_matrices(bond_table, W)
+
+    @staticmethod
+    def backward(ctx, dmats):
+        bond_table, W = ctx.saved_tensors
+        Vb, K = bond_table.shape
+        D = W.shape[-1]
+        dmats = f32c(dmats)
+        dW, dtb = torch.empty_like(W), torch.empty_like(bond_table)
+        _lib_call(W.device, _lib.load().impnn_bond_type_matrices_bwd, ptr(bond_table), ptr(W), ptr(dmats), ptr(dW),
+                  ptr(dtb), Vb, K, D)
+        return dtb, dW
+
+
+class BmmMessageTyped(torch.autograd.Function):
+    """BondMatrixMessage.call in the per-bond-type schedule (models/layers.py:100-117)."""
+
+    @staticmethod
+    def forward(ctx, h, bond_ids, conn, type_mats):
+        h, type_mats, bond_ids, conn = f32c(h), f32c(type_mats), i32c(bond_ids), i32c(conn)
+        ctx.save_for_backward(h, bond_ids, conn, type_mats)
+        return ops.bmm_message_typed(h, bond_ids, conn, type_mats)
+
+    @staticmethod
+    def backward(ctx, dm):
+        h, bond_ids, conn, mats = ctx.saved_tensors
+        B, N, D = h.shape
+        E, Vb = conn.shape[1], mats.shape[0]
+        dm = f32c(dm)
+        dh, dmats = torch.zeros_like(h), torch.zeros_like(mats)
+        _lib_call(h.device, _lib.load().impnn_bmm_message_typed_bwd, ptr(h), ptr(bond_ids), ptr(conn), ptr(mats),
+                  ptr(dm), ptr(dh), ptr(dmats), B, N, E, D, Vb)
+        return dh, None, None, dmats
+
+
+class ReduceScatterAdd(torch.autograd.Function):
+    """Reduce.call (models/layers.py:57-83)."""
+
+    @staticmethod
+    def forward(ctx, messages, tgt_idx, num_atoms):
+        tgt = i32c(tgt_idx)
+        ctx.save_for_backward(tgt)
+        ctx.num_atoms = int(num_atoms)
+        return ops.reduce_scatter_add(messages, tgt, num_atoms)
+
+    @staticmethod
+    def backward(ctx, dagg):
+        (tgt,) = ctx.saved_tensors
+        B, E = tgt.shape
+        dagg = f32c(dagg)
+        D = dagg.shape[-1]
+        dm = torch.empty(B, E, D, dtype=torch.float32, device=dagg.device)
+        _lib_call(dagg.device, _lib.load().impnn_reduce_scatter_bwd, ptr(dagg), ptr(tgt), 1, ptr(dm), B, ctx.num_atoms, E, D)
+        return dm, None, None
+
+
+class GatedUpdate(torch.autograd.Function):
+    """GatedUpdate.call (models/layers.py:142-156)."""
+
+    @staticmethod
+    def forward(ctx, h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps):
+        ts = [f32c(t) for t in (h, agg, Wz, bz, Wr, br, Wh, bh, gamma)]
+        ctx.save_for_backward(*ts)
+        ctx.eps = float(eps)
+        return ops.gated_update(*ts, beta, eps)
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, agg, Wz, bz, Wr, br, Wh, bh, gamma = ctx.saved_tensors
+        D = h.shape[-1]
+        rows = h.numel() // D
+        lib = _lib.load()
+        dout = f32c(dout)
+        dh, dagg = torch.empty_like(h), torch.empty_like(agg)
+        P = int(lib.impnn_gated_update_param_floats(D))
+        wsn = int(lib.impnn_gated_update_bwd_workspace_floats(rows, D))
+        dparams = torch.empty(P, dtype=torch.float32, device=h.device)
+        ws = torch.empty(max(wsn, 1), dtype=torch.float32, device=h.device)
+        _lib_call(h.device, lib.impnn_gated_update_bwd, ptr(h), ptr(agg), ptr(Wz), ptr(bz), ptr(Wr), ptr(br), ptr(Wh),
+                  ptr(bh), ptr(gamma), ctx.eps, ptr(dout), ptr(dh), ptr(dagg), ptr(dparams), ptr(ws), wsn, rows, D)
+        n_w, o = 2 * D * D, 0
+        grads = []
+        for _ in range(3):
+            grads.append(dparams[o:o + n_w].view(2 * D, D))
+            grads.append(dparams[o + n_w:o + n_w + D])
+            o += n_w + D
+        grads.append(dparams[o:o + D])
+        grads.append(dparams[o + D:o + 2 * D])
+        return (dh, dagg, *grads, None)
+
+
+class GlobalSumPool(torch.autograd.Function):
+    """GlobalSumPool.call (models/layers.py:161-164)."""
+
+    @staticmethod
+    def forward(ctx, h, atom_ids):
+        ids = i32c(atom_ids)
+        ctx.save_for_backward(ids)
+        ctx.D = int(h.shape[-1])
+        return ops.global_sum_pool(h, ids)
+
+    @staticmethod
+    def backward(ctx, dp):
+        (ids,) = ctx.saved_tensors
+        B, N = ids.shape
+        dp = f32c(dp)
+        dh = torch.empty(B, N, ctx.D, dtype=torch.float32, device=dp.device)
+        _lib_call(dp.device, _lib.load().impnn_global_sum_pool_bwd, ptr(dp), ptr(ids), ptr(dh), B, N, ctx.D)
+        return dh, None

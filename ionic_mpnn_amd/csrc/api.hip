@@ -332,6 +332,75 @@ int impnn_debug_set_stamp_buffer(void* device_buffer, size_t bytes) {
   return IMPNN_OK;
 }
 
+int impnn_embed_gather_bwd(const int32_t* ids, const float* dout, float* dtable, int64_t rows, int32_t vocab,
+                           int32_t dim, impnn_stream_t stream) {
+  REQUIRE(rows >= 0 && vocab > 0 && dim > 0, "bad shape");
+  if (rows == 0) return IMPNN_OK;
+  REQUIRE(ids && dout && dtable, "null pointer");
+  return launch_embed_gather_bwd(ids, dout, dtable, rows, vocab, dim, as_stream(stream));
+}
+
+int impnn_reduce_scatter_bwd(const float* dagg, const int32_t* tgt, int32_t tgt_stride, float* dmessages, int32_t B,
+                             int32_t N, int32_t E, int32_t D, impnn_stream_t stream) {
+  REQUIRE(B >= 0 && N > 0 && E >= 0 && D > 0 && tgt_stride >= 1, "bad shape");
+  if (B == 0 || E == 0) return IMPNN_OK;
+  REQUIRE(dagg && tgt && dmessages, "null pointer");
+  return launch_reduce_scatter_bwd(dagg, tgt, tgt_stride, dmessages, B, N, E, D, as_stream(stream));
+}
+
+int impnn_global_sum_pool_bwd(const float* dpooled, const int32_t* atom_ids, float* dh, int32_t B, int32_t N,
+                              int32_t D, impnn_stream_t stream) {
+  REQUIRE(B >= 0 && N > 0 && D > 0, "bad shape");
+  if (B == 0) return IMPNN_OK;
+  REQUIRE(dpooled && atom_ids && dh, "null pointer");
+  return launch_global_sum_pool_bwd(dpooled, atom_ids, dh, B, N, D, as_stream(stream));
+}
+
+int impnn_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn,
+                                const float* type_mats, const float* dmessages, float* dh, float* dtype_mats,
+                                int32_t B, int32_t N, int32_t E, int32_t D, int32_t Vb, impnn_stream_t stream) {
+  REQUIRE(B >= 0 && N > 0 && E >= 0 && D > 0 && Vb > 0, "bad shape");
+  if (B == 0 || E == 0) return IMPNN_OK;
+  REQUIRE(h && bond_ids && conn && type_mats && dmessages && dh && dtype_mats, "null pointer");
+  return launch_bmm_message_typed_bwd(h, bond_ids, conn, type_mats, dmessages, dh, dtype_mats, B, N, E, D, Vb,
+                                      as_stream(stream));
+}
+
+int impnn_bond_type_matrices_bwd(const float* bond_table, const float* W, const float* dtype_mats, float* dW,
+                                 float* dbond_table, int32_t Vb, int32_t K, int32_t D, impnn_stream_t stream) {
+  REQUIRE(Vb > 0 && K > 0 && D > 0, "bad shape");
+  REQUIRE(bond_table && W && dtype_mats && dW && dbond_table, "null pointer");
+  return launch_bond_type_matrices_bwd(bond_table, W, dtype_mats, dW, dbond_table, Vb, K, D, as_stream(stream));
+}
+
+int64_t impnn_gated_update_param_floats(int32_t D) { return D > 0 ? gated_update_param_floats(D) : 0; }
+
+int64_t impnn_gated_update_bwd_workspace_floats(int64_t rows, int32_t D) {
+  if (rows < 0 || D <= 0) return 0;
+  return (int64_t)gated_update_bwd_blocks(rows, D) * gated_update_param_floats(D);
+}
+
+int impnn_gated_update_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
+                           const float* br, const float* Wh, const float* bh, const float* gamma, float ln_eps,
+                           const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
+                           int64_t workspace_floats, int64_t rows, int32_t D, impnn_stream_t stream) {
+  REQUIRE(rows >= 0 && D > 0 && D <= 256, "bad shape (D <= 256)");
+  REQUIRE(h && agg && Wz && bz && Wr && br && Wh && bh && gamma && dout && dh && dagg && dparams && workspace,
+          "null pointer");
+  if (workspace_floats < impnn_gated_update_bwd_workspace_floats(rows, D))
+    return fail(IMPNN_E_WORKSPACE, "gated_update_bwd: workspace of %lld floats is too small", (long long)workspace_floats);
+  return launch_gated_update_bwd(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, ln_eps, dout, dh, dagg, dparams, workspace,
+                                 rows, D, as_stream(stream));
+}
+
+int impnn_adam_clipnorm_step(const void* var_table, const int64_t* sizes, int32_t n_vars, int64_t step, float lr,
+                             float beta1, float beta2, float eps, float clipnorm, impnn_stream_t stream) {
+  REQUIRE(n_vars >= 0 && step >= 1, "bad arguments (step counts from 1)");
+  if (n_vars == 0) return IMPNN_OK;
+  REQUIRE(var_table && sizes, "null pointer");
+  return launch_adam_clipnorm(var_table, sizes, n_vars, step, lr, beta1, beta2, eps, clipnorm, as_stream(stream));
+}
+
 int impnn_batch_assemble(int32_t n_ions, const int32_t* sample_idx, int32_t B, int32_t M,
                          const int32_t* const* atom_flat, const int32_t* const* atom_off,
                          const int32_t* const* edge_flat, const int32_t* const* bond_flat,

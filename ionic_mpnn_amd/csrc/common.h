@@ -50,6 +50,26 @@ int launch_model_head(int kind, const float* pc, const float* pa, const float* T
 int launch_validate_indices(const int32_t* conn, const int32_t* atom_ids, const int32_t* bond_ids,
                             int32_t* counts, int B, int N, int E, int Va, int Vb, hipStream_t s);
 
+// ---- backward + optimizer (train_kernels.hip)
+int launch_embed_gather_bwd(const int32_t* ids, const float* dout, float* dtable, int64_t rows, int vocab, int dim,
+                            hipStream_t s);
+int launch_reduce_scatter_bwd(const float* dagg, const int32_t* tgt, int tgt_stride, float* dm, int B, int N, int E,
+                              int D, hipStream_t s);
+int launch_global_sum_pool_bwd(const float* dp, const int32_t* ids, float* dh, int B, int N, int D, hipStream_t s);
+int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn, const float* A,
+                                 const float* dm, float* dh, float* dA, int B, int N, int E, int D, int Vb,
+                                 hipStream_t s);
+int launch_bond_type_matrices_bwd(const float* tb, const float* W, const float* dA, float* dW, float* dtb, int Vb,
+                                  int K, int D, hipStream_t s);
+int gated_update_bwd_blocks(int64_t rows, int D);
+int64_t gated_update_param_floats(int D);
+int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
+                            const float* br, const float* Wh, const float* bh, const float* gamma, float eps,
+                            const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
+                            int64_t rows, int D, hipStream_t s);
+int launch_adam_clipnorm(const void* table, const void* sizes, int n_vars, int64_t step, float lr, float b1, float b2,
+                         float eps, float clipnorm, hipStream_t s);
+
 // ---- batch assembly (loader_kernels.hip)
 int launch_batch_assemble(int n_ions, const int32_t* sample_idx, int B, int M, const int32_t* const* atom_flat,
                           const int32_t* const* atom_off, const int32_t* const* edge_flat,

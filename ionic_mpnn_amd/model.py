@@ -30,6 +30,7 @@ class MPNNModel:
         self.atom_vocab_size, self.bond_vocab_size = int(atom_vocab_size), int(bond_vocab_size)
         self.atom_dim, self.bond_dim = int(atom_dim), int(bond_dim)
         self.fp_size, self.mixing_size, self.num_steps = int(fp_size), int(mixing_size), int(num_steps)
+        self.fp_l2 = float(fp_l2)
         self.device = device or L.default_device()
         dev = dict(device=self.device)
         D, K, S = self.atom_dim, self.bond_dim, self.num_steps
@@ -140,7 +141,8 @@ class MPNNModel:
             a = np.ascontiguousarray(np.asarray(weights[k], dtype=np.float32))
             if tuple(a.shape) != tuple(t.shape):
                 raise ValueError(f"{k}: shape {a.shape} != {tuple(t.shape)}")
-            t.copy_(torch.from_numpy(a))
+            with torch.no_grad():
+                t.copy_(torch.from_numpy(a))
         self.invalidate_packed_weights()
 
     def invalidate_packed_weights(self):
@@ -256,8 +258,8 @@ class MPNNModel:
             return pc, pa
         return (self.encode_layered("cat", ca, cb, cc, trace), self.encode_layered("an", aa, ab, ac, trace))
 
-    def head(self, pooled_cat, pooled_an, temperature=None, trace=None):
-        if trace is None and max(self.atom_dim, self.fp_size, self.mixing_size) <= 64:
+    def head(self, pooled_cat, pooled_an, temperature=None, trace=None, differentiable=False):
+        if trace is None and not differentiable and max(self.atom_dim, self.fp_size, self.mixing_size) <= 64:
             return ops.model_head(self.kind, pooled_cat, pooled_an, temperature, self._packed_head(), self.fp_size,
                                   self.mixing_size)  # one launch
         fp_cat = self.branches["cat"]["fp"](pooled_cat)   # Dense(fp_size, relu), :189
@@ -273,10 +275,129 @@ class MPNNModel:
             return self.log_eta([self.param_A(vp), self.param_B(vp), T, self.param_C(vp)])
         return self.mp_out(self.mp_hidden(mixed))
 
-    def __call__(self, inputs, fused=None, trace=None):
+    def __call__(self, inputs, fused=None, trace=None, training=False):
+        """Inference by default (no graph is kept, the fused encoder and the head kernel run).  With
+        ``training=True`` the call is differentiable: layer-at-a-time path (ionic_mpnn_amd.autograd) and the
+        head in torch ops."""
         inputs = self._to_device(inputs)
-        pc, pa = self.encode_pooled(inputs, fused=fused, trace=trace)
-        return self.head(pc, pa, inputs.get("temperature"), trace=trace)
+        if training:
+            pc, pa = self.encode_pooled(inputs, fused=False)
+            return self.head(pc, pa, inputs.get("temperature"), differentiable=True)
+        with torch.no_grad():
+            pc, pa = self.encode_pooled(inputs, fused=fused, trace=trace)
+            return self.head(pc, pa, inputs.get("temperature"), trace=trace)
+
+    # ------------------------------------------------------------------ training (SURVEY.md 8 f4)
+    def trainable_variables(self):
+        """[(name, tensor)] in a fixed order; every variable of the reference model is trainable."""
+        return list(self._named_tensors().items())
+
+    def compile(self, optimizer=None, loss="mse"):
+        """model.compile(optimizer=Adam(1e-3, clipnorm=1.0), loss="mse") (train_viscosity.py:227-230)."""
+        from . import train
+        if loss != "mse":
+            raise ValueError("the reference trainers use loss='mse'")
+        self.optimizer = optimizer if optimizer is not None else train.Adam(1e-3, clipnorm=1.0)
+        for _, t in self.trainable_variables():
+            t.requires_grad_(True)
+        self.optimizer.build([t for _, t in self.trainable_variables()])
+        return self
+
+    def regularization_loss(self):
+        """keras l2(fp_l2) on the fingerprint Dense kernels (train_viscosity.py:189) and, for the melting-point
+        model, on the hidden Dense (train_melting_point.py:173,197): fp_l2 * sum(w^2)."""
+        ks = [self.branches["cat"]["fp"].kernel, self.branches["an"]["fp"].kernel]
+        if self.kind != "viscosity":
+            ks.append(self.mp_hidden.kernel)
+        return self.fp_l2 * sum((k * k).sum() for k in ks)
+
+    def _loss(self, inputs, y, training):
+        from . import train
+        y = torch.as_tensor(y, dtype=torch.float32).to(self.device).reshape(-1, 1)
+        pred = self(inputs, training=True) if training else self(inputs)
+        if training:
+            return train.mse(y, pred) + self.regularization_loss()
+        with torch.no_grad():
+            return train.mse(y, pred) + self.regularization_loss()
+
+    def train_on_batch(self, inputs, y, group=None):
+        """One optimizer step on one mini-batch -> the batch loss (MSE + penalties) as a 0-d tensor.
+        With torch.distributed initialised (or ``group`` given) every rank calls this with its shard of
+        the global mini-batch: the gradients are averaged over ranks (weighted by shard size) with one
+        all-reduce of the flat gradient buffer, then every rank applies the same step."""
+        import torch.distributed as dist
+        if getattr(self, "optimizer", None) is None:
+            self.compile()
+        opt = self.optimizer
+        n_local = len(inputs["cat_atom"])
+        loss = self._loss(inputs, y, training=True) if n_local else None
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world > 1:
+            cnt = torch.tensor([float(n_local)], dtype=torch.float32, device=opt.flat_grad.device)
+            dist.all_reduce(cnt, group=group)
+            scale = n_local / float(cnt.item())  # local mean -> this rank's share of the global mean
+            if loss is not None:
+                (loss * scale).backward()
+            dist.all_reduce(opt.flat_grad, group=group)  # one collective for every gradient
+        elif loss is not None:
+            loss.backward()
+        opt.apply_gradients()   # clips, updates, and leaves the gradients in place ...
+        opt.zero_grad()         # ... so clear them for the next accumulation
+        self.invalidate_packed_weights()
+        return loss.detach() if loss is not None else torch.zeros((), device=opt.flat_grad.device)
+
+    def evaluate(self, inputs, y, batch_size=32):
+        """model.evaluate: sample-weighted mean of the batch losses (MSE + penalties)."""
+        n = len(inputs["cat_atom"])
+        tot = 0.0
+        for lo in range(0, n, batch_size):
+            sl = slice(lo, min(n, lo + batch_size))
+            tot += float(self._loss({k: v[sl] for k, v in inputs.items()}, y[sl], training=False)) * (sl.stop - sl.start)
+        return tot / max(n, 1)
+
+    def fit(self, x, y, validation_data=None, epochs=1, batch_size=32, callbacks=None, shuffle=True, verbose=0,
+            seed=None):
+        """model.fit as the trainers call it (train_viscosity.py:328-338): per epoch a fresh shuffle,
+        mini-batches of ``batch_size``, `loss` = sample-weighted mean of the batch losses, `val_loss` from
+        evaluate(); callbacks see on_train_begin / on_epoch_end / on_train_end.  Returns a History."""
+        from . import train
+        if getattr(self, "optimizer", None) is None:
+            self.compile()
+        x = self._to_device(x)
+        y = np.asarray(y, dtype=np.float32)
+        n = len(y)
+        rng = np.random.default_rng(seed)
+        hist = train.History()
+        callbacks = list(callbacks or [])
+        for cb in callbacks:
+            if hasattr(cb, "on_train_begin"):
+                cb.on_train_begin(self)
+        for epoch in range(int(epochs)):
+            order = rng.permutation(n) if shuffle else np.arange(n)
+            tot = torch.zeros((), dtype=torch.float64, device=self.device)
+            for lo in range(0, n, batch_size):
+                idx = order[lo:lo + batch_size]
+                tidx = torch.from_numpy(idx).to(self.device)
+                loss = self.train_on_batch({k: v[tidx] for k, v in x.items()}, y[idx])
+                tot += loss.double() * len(idx)
+            logs = {"loss": float(tot) / max(n, 1)}
+            if validation_data is not None:
+                vx, vy = validation_data
+                logs["val_loss"] = self.evaluate(self._to_device(vx), np.asarray(vy, np.float32), batch_size)
+            hist._log(epoch, logs)
+            if verbose:
+                print(f"Epoch {epoch + 1}/{epochs} - " + " - ".join(f"{k}: {v:.4f}" for k, v in logs.items()), flush=True)
+            stop = False
+            for cb in callbacks:
+                if hasattr(cb, "on_epoch_end") and cb.on_epoch_end(self, epoch, logs):
+                    stop = True
+            if stop:
+                break
+        for cb in callbacks:
+            if hasattr(cb, "on_train_end"):
+                cb.on_train_end(self)
+        self.history = hist
+        return hist
 
     def predict(self, inputs, batch_size=None, fused=None):
         """model.predict(x) (train_viscosity.py:366): returns a numpy (n,1) array.  The reference's

@@ -14,8 +14,20 @@ LN_EPS = 1e-3  # keras LayerNormalization default (models/layers.py:139)
 DEBUG_VALIDATE = False  # True: raise like TF-CPU on out-of-range indices (costs a device sync)
 
 
+def _wants_grad(*tensors):
+    """Training: an input requires grad and grad mode is on -> go through ionic_mpnn_amd.autograd."""
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
+
+
+class NoBackward(NotImplementedError):
+    """Raised when a forward-only entry (dense bond_state message, fused encoder) is asked for gradients."""
+
+
 def embed_gather(ids, table):
     """Embedding(mask_zero=False) lookup, train_viscosity.py:171-172."""
+    if _wants_grad(table):
+        from . import autograd
+        return autograd.EmbedGather.apply(ids, table)
     require_gpu(ids, table)
     ids = i32c(ids)
     table = f32c(table)
@@ -87,6 +99,9 @@ def batch_assemble(sample_idx, ions, max_atoms, slots, id_shift=1, t_flat=None):
 
 def bmm_message(h, bond_state, conn, W):
     """BondMatrixMessage.call, models/layers.py:100-117 -> messages (B,E,D)."""
+    if _wants_grad(h, bond_state, W):
+        raise NoBackward("gradients of BondMatrixMessage are implemented for bond states that come from an "
+                         "Embedding(lazy=True) (per-bond-type schedule), as the reference wires it")
     require_gpu(h, bond_state, conn, W)
     _check_bmm_shapes(h, conn)
     h, bond_state, W, conn = f32c(h), f32c(bond_state), f32c(W), i32c(conn)
@@ -106,6 +121,9 @@ def bmm_message(h, bond_state, conn, W):
 
 def bond_type_matrices(bond_table, W):
     """A[v] = sum_k bond_table[v,k] W[k]  (models/layers.py:108 once per vocabulary entry)."""
+    if _wants_grad(bond_table, W):
+        from . import autograd
+        return autograd.BondTypeMatrices.apply(bond_table, W)
     require_gpu(bond_table, W)
     bond_table, W = f32c(bond_table), f32c(W)
     Vb, K = bond_table.shape
@@ -119,6 +137,9 @@ def bond_type_matrices(bond_table, W):
 
 
 def bmm_message_typed(h, bond_ids, conn, type_mats):
+    if _wants_grad(h, type_mats):
+        from . import autograd
+        return autograd.BmmMessageTyped.apply(h, bond_ids, conn, type_mats)
     require_gpu(h, bond_ids, conn, type_mats)
     _check_bmm_shapes(h, conn)
     h, type_mats, conn, bond_ids = f32c(h), f32c(type_mats), i32c(conn), i32c(bond_ids)
@@ -136,6 +157,9 @@ def bmm_message_typed(h, bond_ids, conn, type_mats):
 def reduce_scatter_add(messages, tgt_idx, num_atoms):
     """Reduce.call, models/layers.py:57-83.  `tgt_idx` may be the strided view conn[:, :, 1]
     (train_viscosity.py:182); it is then read in place."""
+    if _wants_grad(messages):
+        from . import autograd
+        return autograd.ReduceScatterAdd.apply(messages, tgt_idx, num_atoms)
     require_gpu(messages, tgt_idx)
     messages = f32c(messages)
     B, E, D = messages.shape
@@ -160,6 +184,8 @@ def reduce_scatter_add(messages, tgt_idx, num_atoms):
 
 def bmm_fused(h, bond_state, conn, W):
     """Orphan models/bond_matrix_message.py:37-65 signature: -> aggregated (B,N,D)."""
+    if _wants_grad(h, bond_state, W):
+        raise NoBackward("the fused message+reduce entry is forward-only; train with fused=False")
     require_gpu(h, bond_state, conn, W)
     _check_bmm_shapes(h, conn)
     h, bond_state, W, conn = f32c(h), f32c(bond_state), f32c(W), i32c(conn)
@@ -178,6 +204,9 @@ def bmm_fused(h, bond_state, conn, W):
 
 def gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps=LN_EPS):
     """GatedUpdate.call, models/layers.py:142-156."""
+    if _wants_grad(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta):
+        from . import autograd
+        return autograd.GatedUpdate.apply(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps)
     require_gpu(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta)
     if h.shape != agg.shape:
         raise ValueError(f"atom_state {tuple(h.shape)} and agg {tuple(agg.shape)} differ")
@@ -195,6 +224,9 @@ def gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps=LN_EPS):
 
 def global_sum_pool(h, atom_ids):
     """GlobalSumPool.call, models/layers.py:161-164."""
+    if _wants_grad(h):
+        from . import autograd
+        return autograd.GlobalSumPool.apply(h, atom_ids)
     require_gpu(h, atom_ids)
     h, atom_ids = f32c(h), i32c(atom_ids)
     B, N, D = h.shape

@@ -1,0 +1,132 @@
+"""model.compile / fit / evaluate as the reference's trainers use them:
+Adam(1e-3, clipnorm=1.0) + MSE (+ the l2(1e-4) penalty of the fingerprint Dense kernels), mini-batches of
+32 in a fresh shuffle per epoch, EarlyStopping(monitor="val_loss", patience=50, restore_best_weights=True)
+(train_viscosity.py:189,227-230,328-338; train_melting_point.py:173,205-208,300-311).
+
+Forward and backward of the message-passing layers run in libimpnn (ionic_mpnn_amd.autograd); the
+optimizer step of all variables is one launch (impnn_adam_clipnorm_step).  The tiny head layers after
+GlobalSumPool differentiate through torch autograd.  Multi-GPU: one process per GPU, every rank takes
+its contiguous shard of each mini-batch, and the flat gradient buffer is averaged with ONE all-reduce
+per step (RCCL; gloo in the CPU tests) before the replicated optimizer step."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, stream_ptr
+
+
+class Adam:
+    """keras.optimizers.Adam(learning_rate, clipnorm): per-variable tf.clip_by_norm, then Adam with
+    epsilon 1e-7 and the bias-corrected step size lr*sqrt(1-b2^t)/(1-b1^t)."""
+
+    def __init__(self, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, clipnorm=None):
+        self.learning_rate, self.beta_1, self.beta_2 = float(learning_rate), float(beta_1), float(beta_2)
+        self.epsilon, self.clipnorm = float(epsilon), (None if clipnorm is None else float(clipnorm))
+        self.iterations = 0
+        self._vars = None
+
+    def get_config(self):
+        return {"name": "Adam", "learning_rate": self.learning_rate, "beta_1": self.beta_1, "beta_2": self.beta_2,
+                "epsilon": self.epsilon, "clipnorm": self.clipnorm}
+
+    def build(self, variables):
+        """variables: list of leaf tensors on one GPU.  Gradients live in ONE flat buffer (views become the
+        variables' .grad), so the data-parallel average is a single collective and the kernel's pointer table
+        stays valid for the whole run."""
+        variables = list(variables)
+        dev = variables[0].device
+        sizes = [int(v.numel()) for v in variables]
+        total = sum(sizes)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        table, off = [], 0
+        for var, n in zip(variables, sizes):
+            if var.dtype != torch.float32 or not var.is_contiguous():
+                raise ValueError("optimizer variables must be contiguous float32 tensors")
+            var.grad = self.flat_grad[off:off + n].view_as(var)
+            table += [var.data_ptr(), self.flat_grad.data_ptr() + 4 * off, self.m.data_ptr() + 4 * off,
+                      self.v.data_ptr() + 4 * off]
+            off += n
+        # data_ptr values are < 2^63: store them as int64 bit patterns
+        self._table = torch.tensor(table, dtype=torch.int64, device=dev)
+        self._sizes = torch.tensor(sizes, dtype=torch.int64, device=dev)
+        self._vars = variables
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def apply_gradients(self):
+        """One launch: clip, moments, update for every variable (gradients are read from the flat buffer)."""
+        if self._vars is None:
+            raise RuntimeError("Adam.build(variables) has not been called")
+        for var in self._vars:  # autograd may have swapped .grad for a fresh tensor if it was reset to None
+            if var.grad is None or var.grad.data_ptr() < self.flat_grad.data_ptr() or \
+                    var.grad.data_ptr() >= self.flat_grad.data_ptr() + 4 * self.flat_grad.numel():
+                raise RuntimeError("a variable's .grad no longer points into the optimizer's flat buffer; "
+                                   "use optimizer.zero_grad() instead of setting .grad = None")
+        self.iterations += 1
+        dev = self.flat_grad.device
+        with torch.cuda.device(dev):
+            check(_lib.load().impnn_adam_clipnorm_step(
+                C.c_void_p(self._table.data_ptr()), C.c_void_p(self._sizes.data_ptr()), len(self._vars),
+                self.iterations, self.learning_rate, self.beta_1, self.beta_2, self.epsilon,
+                self.clipnorm if self.clipnorm else 0.0, stream_ptr()))
+
+
+class History:
+    def __init__(self):
+        self.history = {}
+        self.epoch = []
+
+    def _log(self, epoch, logs):
+        self.epoch.append(epoch)
+        for k, v in logs.items():
+            self.history.setdefault(k, []).append(float(v))
+
+
+class EarlyStopping:
+    """keras.callbacks.EarlyStopping(monitor, patience, restore_best_weights) with mode "min"
+    (train_viscosity.py:334)."""
+
+    def __init__(self, monitor="val_loss", patience=0, restore_best_weights=False, min_delta=0.0):
+        self.monitor, self.patience, self.restore_best_weights = monitor, int(patience), bool(restore_best_weights)
+        self.min_delta = abs(float(min_delta))
+        self.best, self.wait, self.best_weights, self.stopped_epoch, self.best_epoch = np.inf, 0, None, 0, 0
+
+    def on_train_begin(self, model):
+        self.best, self.wait, self.best_weights, self.stopped_epoch, self.best_epoch = np.inf, 0, None, 0, 0
+
+    def on_epoch_end(self, model, epoch, logs):
+        cur = logs.get(self.monitor)
+        if cur is None:
+            return False
+        if self.restore_best_weights and self.best_weights is None:
+            self.best_weights = model.state_dict()
+        self.wait += 1
+        if cur < self.best - self.min_delta:
+            self.best, self.best_epoch, self.wait = cur, epoch, 0
+            if self.restore_best_weights:
+                self.best_weights = model.state_dict()
+            return False
+        if self.wait >= self.patience and epoch > 0:
+            self.stopped_epoch = epoch
+            return True
+        return False
+
+    def on_train_end(self, model):
+        if self.restore_best_weights and self.best_weights is not None:
+            model.load_weights(self.best_weights)
+
+
+def mse(y_true, y_pred):
+    """keras "mse": mean over the last axis, then over the batch."""
+    return torch.mean((y_pred.reshape(y_true.shape[0], -1) - y_true.reshape(y_true.shape[0], -1)) ** 2)
+
+
+def slice_inputs(inputs, idx):
+    return {k: v[idx] for k, v in inputs.items()}

@@ -1,0 +1,163 @@
+"""f4: backward kernels, optimizer step and fit().  Gradient oracle: torch-CPU fp64 autograd
+through oracle/torch_ref.py (the reference's op schedule); tolerance 1e-4 of each tensor's scale (f32
+kernels, sums of a few thousand terms).  Optimizer oracle: oracle/train_oracle.py."""
+import numpy as np
+import pytest
+import torch
+
+from ionic_mpnn_amd import model as MM, ops, synthetic, train, weights
+from oracle import torch_ref as TR, train_oracle as TO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def close(got, ref, tol=1e-4, what=""):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    ref = ref.detach().cpu().double().numpy() if torch.is_tensor(ref) else np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(np.abs(ref).max(), 1e-12)
+    err = np.abs(got - ref).max() / scale
+    assert err <= tol, f"{what}: rel err {err:.3e} > {tol}"
+
+
+def rand_graph(B, N, E, Vb, rng):
+    conn = rng.integers(0, N, size=(B, E, 2)).astype(np.int32)
+    conn[:, ::5, 0] = 0  # padding-like edges (masked: src == 0)
+    bond = rng.integers(0, Vb, size=(B, E)).astype(np.int32)
+    ids = rng.integers(0, 9, size=(B, N)).astype(np.int32)
+    return conn, bond, ids
+
+
+@pytest.mark.parametrize("D,K", [(8, 4), (32, 8), (64, 3)])
+def test_message_reduce_backward(D, K):
+    rng = np.random.default_rng(D)
+    B, N, E, Vb = 5, 9, 14, 7
+    conn, bond, _ = rand_graph(B, N, E, Vb, rng)
+    h = rng.normal(size=(B, N, D)); tb = rng.normal(size=(Vb, K)); W = rng.normal(size=(K, D, D)) / np.sqrt(D)
+    go = rng.normal(size=(B, N, D))
+    # oracle (fp64)
+    ho, tbo, Wo = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (h, tb, W))
+    bs = torch.nn.functional.embedding(torch.tensor(bond).long(), tbo)
+    m = TR.bond_matrix_message(ho, bs, torch.tensor(conn), Wo)
+    agg = TR.reduce_messages(m, torch.tensor(conn)[:, :, 1], N)
+    (agg * torch.tensor(go)).sum().backward()
+    # HIP
+    hg, tbg, Wg = (torch.tensor(a, dtype=torch.float32, device=DEV, requires_grad=True) for a in (h, tb, W))
+    cg, bg = torch.tensor(conn, device=DEV), torch.tensor(bond, device=DEV)
+    mats = ops.bond_type_matrices(tbg, Wg)
+    mg = ops.bmm_message_typed(hg, bg, cg, mats)
+    ag = ops.reduce_scatter_add(mg, cg[:, :, 1], N)
+    close(ag, agg, 1e-5, "agg")
+    (ag * torch.tensor(go, dtype=torch.float32, device=DEV)).sum().backward()
+    close(hg.grad, ho.grad, what="dh")
+    close(Wg.grad, Wo.grad, what="dW")
+    close(tbg.grad, tbo.grad, what="dbond_table")
+
+
+@pytest.mark.parametrize("D,rows", [(8, 37), (32, 301), (128, 19)])
+def test_gated_update_backward(D, rows):
+    rng = np.random.default_rng(D + 1)
+    names = ["Wz", "bz", "Wr", "br", "Wh", "bh", "gamma", "beta"]
+    vals = {"Wz": rng.normal(size=(2 * D, D)) / np.sqrt(2 * D), "Wr": rng.normal(size=(2 * D, D)) / np.sqrt(2 * D),
+            "Wh": rng.normal(size=(2 * D, D)) / np.sqrt(2 * D), "bz": rng.normal(size=D) * 0.1,
+            "br": rng.normal(size=D) * 0.1, "bh": rng.normal(size=D) * 0.1, "gamma": 1 + 0.1 * rng.normal(size=D),
+            "beta": 0.1 * rng.normal(size=D)}
+    h, agg, go = rng.normal(size=(rows, D)), rng.normal(size=(rows, D)), rng.normal(size=(rows, D))
+    po = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in vals.items()}
+    ho, ao = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (h, agg))
+    out = TR.gated_update(ho, ao, po)
+    (out * torch.tensor(go)).sum().backward()
+    pg = {k: torch.tensor(v, dtype=torch.float32, device=DEV, requires_grad=True) for k, v in vals.items()}
+    hg, ag = (torch.tensor(a, dtype=torch.float32, device=DEV, requires_grad=True) for a in (h, agg))
+    og = ops.gated_update(hg, ag, *[pg[k] for k in names])
+    close(og, out, 1e-5, "out")
+    (og * torch.tensor(go, dtype=torch.float32, device=DEV)).sum().backward()
+    close(hg.grad, ho.grad, what="dh")
+    close(ag.grad, ao.grad, what="dagg")
+    for k in names:
+        close(pg[k].grad, po[k].grad, what=f"d{k}")
+    # parameter gradients go through fixed-order partial sums: bitwise reproducible
+    g1 = pg["Wz"].grad.clone()
+    for t in list(pg.values()) + [hg, ag]:
+        t.grad = None
+    og = ops.gated_update(hg, ag, *[pg[k] for k in names])
+    (og * torch.tensor(go, dtype=torch.float32, device=DEV)).sum().backward()
+    assert torch.equal(pg["Wz"].grad, g1)
+
+
+def test_embedding_and_pool_backward():
+    rng = np.random.default_rng(3)
+    B, N, D, V = 6, 11, 16, 9
+    ids = rng.integers(0, V, size=(B, N)).astype(np.int32)
+    table, go = rng.normal(size=(V, D)), rng.normal(size=(B, D))
+    to = torch.tensor(table, dtype=torch.float64, requires_grad=True)
+    p = TR.global_sum_pool(torch.nn.functional.embedding(torch.tensor(ids).long(), to), torch.tensor(ids))
+    (p * torch.tensor(go)).sum().backward()
+    tg = torch.tensor(table, dtype=torch.float32, device=DEV, requires_grad=True)
+    ig = torch.tensor(ids, device=DEV)
+    pg = ops.global_sum_pool(ops.embed_gather(ig, tg), ig)
+    close(pg, p, 1e-6, "pooled")
+    (pg * torch.tensor(go, dtype=torch.float32, device=DEV)).sum().backward()
+    close(tg.grad, to.grad, what="dtable")
+
+
+def _tiny_model(kind="viscosity", S=2, seed=5):
+    Va, Vb, D, K = 11, 6, 16, 4
+    w = weights.init_weights(kind, Va, Vb, atom_dim=D, bond_dim=K, fp_size=12, mixing_size=10, num_steps=S,
+                             seed=seed, perturb=True)
+    m = MM.build_model(Va, Vb, atom_dim=D, bond_dim=K, fp_size=12, mixing_size=10, num_steps=S, device=DEV)
+    m.load_weights(w)
+    inp = synthetic.make_batch(24, max_atoms=10, max_edges=16, atom_vocab_size=Va, bond_vocab_size=Vb, min_atoms=3, seed=seed)
+    y = np.random.default_rng(seed).normal(1.0, 0.5, size=24).astype(np.float32)
+    return m, w, inp, y
+
+
+def test_whole_model_gradients_match_the_oracle():
+    m, w, inp, y = _tiny_model()
+    m.compile(train.Adam(1e-3, clipnorm=1.0))
+    loss = m._loss(m._to_device(inp), y, training=True)
+    loss.backward()
+    wo = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w.items()}
+    pred = TR.viscosity_forward(wo, inp, torch.float64)
+    lo = torch.mean((pred.reshape(-1) - torch.tensor(y, dtype=torch.float64)) ** 2) \
+        + 1e-4 * ((wo["cat_fp/kernel"] ** 2).sum() + (wo["an_fp/kernel"] ** 2).sum())
+    lo.backward()
+    close(loss, lo, 1e-5, "loss")
+    for name, t in m.trainable_variables():
+        close(t.grad, wo[name].grad, 2e-4, f"grad {name}")
+
+
+def test_adam_clipnorm_step_matches_the_oracle():
+    rng = np.random.default_rng(0)
+    shapes = [(7, 5), (33,), (4, 8, 8), (1,)]
+    ws = [rng.normal(size=s).astype(np.float32) for s in shapes]
+    vars_ = [torch.tensor(a, device=DEV, requires_grad=True) for a in ws]
+    opt = train.Adam(1e-3, clipnorm=1.0)
+    opt.build(vars_)
+    ref = [(a.astype(np.float64), np.zeros(a.shape), np.zeros(a.shape)) for a in ws]
+    for t in range(1, 6):
+        gs = [(rng.normal(size=s) * (3.0 if i % 2 else 0.05)).astype(np.float32) for i, s in enumerate(shapes)]
+        for v, g in zip(vars_, gs):
+            v.grad.copy_(torch.tensor(g, device=DEV))
+        opt.apply_gradients()
+        opt.zero_grad()
+        ref = [TO.adam_step(w_, g, m_, v_, t, clipnorm=1.0) for (w_, m_, v_), g in zip(ref, gs)]
+        for v, (w_, _, _) in zip(vars_, ref):
+            close(v, w_, 2e-6, f"step {t}")
+
+
+def test_fit_reduces_the_loss_and_early_stopping_restores_the_best_weights():
+    m, _, inp, y = _tiny_model(S=1, seed=7)
+    m.compile(train.Adam(1e-2, clipnorm=1.0))
+    first = m.evaluate(m._to_device(inp), y)
+    es = train.EarlyStopping(monitor="val_loss", patience=3, restore_best_weights=True)
+    hist = m.fit(inp, y, validation_data=(inp, y), epochs=25, batch_size=8, callbacks=[es], seed=0)
+    assert hist.history["loss"][-1] < 0.6 * first
+    assert len(hist.history["val_loss"]) == len(hist.history["loss"])
+    best = min(hist.history["val_loss"])
+    assert abs(m.evaluate(m._to_device(inp), y) - best) <= 1e-5 * max(best, 1.0)   # restored
+    # inference after training runs the fused encoder on the updated weights
+    a = m.predict(inp)
+    b = m.predict(inp, fused=False)
+    close(a, b, 1e-5, "fused vs layered after training")
