@@ -9,6 +9,8 @@ are replicated.  Two optional epilogue collectives exist for callers that want t
   * all_gather_fingerprints - the full (B, F) fingerprint / prediction matrix on every rank
     (per-sample rows, so all-gather is the right op);
   * all_reduce_loss_stats   - sum of squared error + sample count (2 scalars) for the MSE.
+  * shard_loss_weight / all_reduce_flat_gradients_ - data-parallel training: loss weight of a shard and the
+    single all-reduce of the flat gradient buffer (ionic_mpnn_amd.train).
 
 Payloads are <= ~1 MB/rank (B=65536, D=32), i.e. latency-bound on xGMI's point-to-point links; one
 fused buffer per call, RCCL picks its direct algorithms at this size.
@@ -90,6 +92,25 @@ def all_reduce_sum_(t, group=None):
     if is_distributed():
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+def shard_loss_weight(n_local, device="cpu", group=None):
+    """Data-parallel training: every rank holds ``n_local`` samples of the global
+    mini-batch and computes the MEAN loss of its shard.  Scaling that loss by n_local / n_global before
+    backward() makes the SUM of the ranks' gradients the gradient of the global mean - also for uneven
+    shards and for penalties that every rank adds in full.  Returns (weight, n_global); one all-reduce."""
+    cnt = torch.tensor([float(n_local)], dtype=torch.float64, device=device)
+    if is_distributed():
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    n_global = float(cnt.item())
+    return (float(n_local) / n_global if n_global > 0 else 0.0), int(n_global)
+
+
+def all_reduce_flat_gradients_(flat, group=None):
+    """One collective for every gradient of the model: the optimizer keeps them in one flat buffer."""
+    if is_distributed():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
 
 
 class ShardedForward:

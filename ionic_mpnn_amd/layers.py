@@ -349,16 +349,22 @@ class SliceParamA(Layer):
         return x[:, 0:1]
 
 
+def _softplus(x):
+    """tf.nn.softplus: log(1 + exp(x)) in the overflow-free form max(x,0) + log1p(exp(-|x|)) - same value,
+    and a finite gradient (sigmoid) for |x| > 88, where log1p(exp(x)) differentiates to inf/inf."""
+    return torch.clamp(x, min=0.0) + torch.log1p(torch.exp(-torch.abs(x)))
+
+
 @register_keras_serializable()
 class SliceParamB(Layer):
     def call(self, x):
-        return torch.clamp(torch.nn.functional.softplus(x[:, 1:2], beta=1.0, threshold=1e9), 0.0, 20.0)
+        return torch.clamp(_softplus(x[:, 1:2]), 0.0, 20.0)
 
 
 @register_keras_serializable()
 class SliceParamC(Layer):
     def call(self, x):
-        return torch.clamp(torch.nn.functional.softplus(x[:, 2:3], beta=1.0, threshold=1e9), 0.1, 50.0)
+        return torch.clamp(_softplus(x[:, 2:3]), 0.1, 50.0)
 
 
 @register_keras_serializable()

@@ -325,20 +325,17 @@ class MPNNModel:
         With torch.distributed initialised (or ``group`` given) every rank calls this with its shard of
         the global mini-batch: the gradients are averaged over ranks (weighted by shard size) with one
         all-reduce of the flat gradient buffer, then every rank applies the same step."""
-        import torch.distributed as dist
+        from . import dist as idist
         if getattr(self, "optimizer", None) is None:
             self.compile()
         opt = self.optimizer
         n_local = len(inputs["cat_atom"])
         loss = self._loss(inputs, y, training=True) if n_local else None
-        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        if world > 1:
-            cnt = torch.tensor([float(n_local)], dtype=torch.float32, device=opt.flat_grad.device)
-            dist.all_reduce(cnt, group=group)
-            scale = n_local / float(cnt.item())  # local mean -> this rank's share of the global mean
+        if idist.is_distributed():
+            weight, _ = idist.shard_loss_weight(n_local, opt.flat_grad.device, group)
             if loss is not None:
-                (loss * scale).backward()
-            dist.all_reduce(opt.flat_grad, group=group)  # one collective for every gradient
+                (loss * weight).backward()
+            idist.all_reduce_flat_gradients_(opt.flat_grad, group)
         elif loss is not None:
             loss.backward()
         opt.apply_gradients()   # clips, updates, and leaves the gradients in place ...

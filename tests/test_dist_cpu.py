@@ -81,3 +81,67 @@ def test_single_process_is_a_noop():
         assert idist.all_gather_fingerprints(x) is x
         s = idist.all_reduce_loss_stats(x[:, 0], torch.zeros(3))
         assert float(s[0]) == float((x[:, 0] ** 2).sum()) and int(s[1]) == 3
+
+
+def _grad_worker(rank, world, port, n_rows, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    from ionic_mpnn_amd import dist as idist
+    idist.init_distributed(backend="gloo")
+    g = torch.Generator().manual_seed(0)
+    X, y = torch.randn(n_rows, 5, generator=g, dtype=torch.float64), torch.randn(n_rows, generator=g, dtype=torch.float64)
+    w0 = torch.randn(5, generator=g, dtype=torch.float64)
+    lam = 0.3
+
+    def loss_of(w, Xs, ys):  # mean loss of a shard + a penalty every rank adds in full (like the l2 term)
+        return torch.mean((Xs @ w - ys) ** 2) + lam * (w * w).sum()
+
+    wf = w0.clone().requires_grad_(True)
+    loss_of(wf, X, y).backward()                      # full-batch gradient: the target
+    lo, hi = idist.shard_bounds(n_rows, world, rank)
+    wl = w0.clone().requires_grad_(True)
+    flat = torch.zeros(5, dtype=torch.float64)
+    wl.grad = flat.view_as(wl)                        # gradients accumulate into the flat buffer, as in train.Adam
+    weight, n_glob = idist.shard_loss_weight(hi - lo)
+    assert n_glob == n_rows
+    if hi > lo:
+        (loss_of(wl, X[lo:hi], y[lo:hi]) * weight).backward()
+    idist.all_reduce_flat_gradients_(flat)
+    assert torch.allclose(flat, wf.grad, rtol=1e-12, atol=1e-12), (flat, wf.grad)
+    Path(out_dir, f"gok_{rank}").write_text("ok")
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_rows", [8, 7, 1])         # even, uneven, and a rank with an empty shard
+def test_world2_gloo_gradient_average_matches_full_batch(tmp_path, n_rows):
+    world, port = 2, _free_port()
+    mp.spawn(_grad_worker, args=(world, port, n_rows, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"gok_{r}").exists() for r in range(world))
+
+
+def test_early_stopping_and_history_host_logic():
+    from ionic_mpnn_amd import train
+
+    class Fake:
+        def __init__(self):
+            self.w = 0
+        def state_dict(self):
+            return {"w": self.w}
+        def load_weights(self, d):
+            self.w = d["w"]
+
+    m, es, hist = Fake(), train.EarlyStopping(monitor="val_loss", patience=2, restore_best_weights=True), train.History()
+    es.on_train_begin(m)
+    stopped = None
+    for epoch, vl in enumerate([3.0, 2.0, 2.5, 2.2, 1.9, 5.0]):
+        m.w = epoch
+        hist._log(epoch, {"loss": vl + 1, "val_loss": vl})
+        if es.on_epoch_end(m, epoch, {"val_loss": vl}):
+            stopped = epoch
+            break
+    es.on_train_end(m)
+    assert stopped == 3 and es.best == 2.0 and m.w == 1          # two epochs without improvement after epoch 1
+    assert hist.history["val_loss"] == [3.0, 2.0, 2.5, 2.2] and hist.epoch == [0, 1, 2, 3]
+    a = train.Adam(1e-3, clipnorm=1.0)
+    assert a.get_config()["clipnorm"] == 1.0 and a.get_config()["epsilon"] == 1e-7

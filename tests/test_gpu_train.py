@@ -128,6 +128,20 @@ def test_whole_model_gradients_match_the_oracle():
         close(t.grad, wo[name].grad, 2e-4, f"grad {name}")
 
 
+def test_config5_shape_trains_without_nonfinite_gradients():
+    """D=128, S=6 (SURVEY config 5): untrained pre-activations of the viscosity head exceed 88, where a naive
+    log1p(exp(x)) differentiates to NaN."""
+    Va, Vb = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB
+    m = MM.build_model(Va, Vb, atom_dim=128, bond_dim=8, num_steps=6, device=DEV)
+    m.load_weights(weights.init_weights("viscosity", Va, Vb, atom_dim=128, bond_dim=8, num_steps=6, seed=1))
+    inp = synthetic.make_batch(48, seed=0)
+    y = np.random.default_rng(0).normal(4.0, 1.0, size=48).astype(np.float32)
+    m.compile(train.Adam(1e-3, clipnorm=1.0))
+    losses = [float(m.train_on_batch(m._to_device(inp), y)) for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert all(bool(torch.isfinite(t).all()) for _, t in m.trainable_variables())
+
+
 def test_adam_clipnorm_step_matches_the_oracle():
     rng = np.random.default_rng(0)
     shapes = [(7, 5), (33,), (4, 8, 8), (1,)]
