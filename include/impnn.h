@@ -216,8 +216,9 @@ int impnn_batch_assemble(int32_t n_ions, const int32_t* sample_idx, int32_t B, i
  *      then   dW[k] = sum_v Tb[v,k] dtype_mats[v];     dbond_table[v,k] = <dtype_mats[v], W[k]>
  *  GatedUpdate (a7, :142-156): dh, dagg (rows,D) and dparams in the canonical order
  *      Wz 2D*D | bz D | Wr | br | Wh | bh | gamma | beta  (impnn_gated_update_param_floats(D) floats, overwritten);
- *      intermediates are recomputed from (h, agg); the parameter sums go through per-workgroup partials in
- *      `workspace` (impnn_gated_update_bwd_workspace_floats) added in a fixed order: bitwise reproducible. */
+ *      intermediates are recomputed from (h, agg); the kernel gradients are split-K GEMMs over row chunks and
+ *      all parameter sums go through partials in `workspace` (impnn_gated_update_bwd_workspace_floats) that
+ *      are added in a fixed order: bitwise reproducible.  atom_dim must divide 256. */
 int impnn_embed_gather_bwd(const int32_t* ids, const float* dout, float* dtable, int64_t rows, int32_t vocab,
                            int32_t dim, impnn_stream_t stream);
 int impnn_reduce_scatter_bwd(const float* dagg, const int32_t* tgt, int32_t tgt_stride, float* dmessages, int32_t B,

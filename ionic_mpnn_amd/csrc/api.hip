@@ -377,14 +377,14 @@ int64_t impnn_gated_update_param_floats(int32_t D) { return D > 0 ? gated_update
 
 int64_t impnn_gated_update_bwd_workspace_floats(int64_t rows, int32_t D) {
   if (rows < 0 || D <= 0) return 0;
-  return (int64_t)gated_update_bwd_blocks(rows, D) * gated_update_param_floats(D);
+  return gated_update_bwd_workspace(rows, D);
 }
 
 int impnn_gated_update_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
                            const float* br, const float* Wh, const float* bh, const float* gamma, float ln_eps,
                            const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
                            int64_t workspace_floats, int64_t rows, int32_t D, impnn_stream_t stream) {
-  REQUIRE(rows >= 0 && D > 0 && D <= 256, "bad shape (D <= 256)");
+  REQUIRE(rows >= 0 && D > 0 && D <= 256 && 256 % D == 0, "atom_dim must divide 256");
   REQUIRE(h && agg && Wz && bz && Wr && br && Wh && bh && gamma && dout && dh && dagg && dparams && workspace,
           "null pointer");
   if (workspace_floats < impnn_gated_update_bwd_workspace_floats(rows, D))

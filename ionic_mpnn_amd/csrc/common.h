@@ -63,6 +63,7 @@ int launch_bond_type_matrices_bwd(const float* tb, const float* W, const float* 
                                   int K, int D, hipStream_t s);
 int gated_update_bwd_blocks(int64_t rows, int D);
 int64_t gated_update_param_floats(int D);
+int64_t gated_update_bwd_workspace(int64_t rows, int D);
 int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
                             const float* br, const float* Wh, const float* bh, const float* gamma, float eps,
                             const float* dout, float* dh, float* dagg, float* dparams, float* workspace,

@@ -14,11 +14,33 @@ constexpr int kBlock = 256;
 __device__ __forceinline__ float sigmoid_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // ---------------------------------------------------------------------------------------
-// a1/a2 backward: dtable[ids[r], :] += dout[r, :]   (float atomics: rows of one id meet in any order)
+// a1/a2 backward: dtable[ids[r], :] += dout[r, :]   (float atomics: rows of one id meet in any order).
+// Vocabularies are small (~10^2 rows), so thousands of rows collide on the same table row: when the table
+// fits LDS every workgroup first sums its rows there (LDS atomics) and touches HBM once per entry.
 // ---------------------------------------------------------------------------------------
 __global__ void embed_gather_bwd_kernel(const int32_t* __restrict__ ids, const float* __restrict__ dout,
-                                        float* __restrict__ dtable, int64_t rows, int vocab, int dim) {
+                                        float* __restrict__ dtable, int64_t rows, int vocab, int dim, int use_lds) {
+  extern __shared__ __align__(16) float smem[];
   const int64_t total = rows * dim;
+  if (use_lds) {
+    const int tsize = vocab * dim;
+    for (int t = threadIdx.x; t < tsize; t += blockDim.x) smem[t] = 0.f;
+    __syncthreads();
+    // contiguous slice of rows per workgroup
+    const int64_t per = (total + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < total ? lo + per : total;
+    for (int64_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
+      const int64_t r = t / dim;
+      const int id = ids[r];
+      if ((unsigned)id < (unsigned)vocab) atomicAdd(&smem[id * dim + (int)(t - r * dim)], dout[t]);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < tsize; t += blockDim.x) {
+      const float v = smem[t];
+      if (v != 0.f) atomicAdd(&dtable[t], v);
+    }
+    return;
+  }
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = t / dim;
     const int c = (int)(t - r * dim);
@@ -187,17 +209,21 @@ __global__ void bond_type_matrices_bwd_t_kernel(const float* __restrict__ W, con
 // a7 backward (models/layers.py:142-156).  Forward per row, c = [h|agg]:
 //   z = sig(c Wz + bz); r = sig(c Wr + br); t = tanh([r*h|agg] Wh + bh); n = (1-z) h + z t;
 //   x = (n - mean) * inv; out = gamma x + beta + h
-// Persistent workgroups walk tiles of R = kBlock/D rows; intermediates are recomputed from (h, agg);
-// every workgroup owns one slice of `partial` (P floats: dWz 2D*D | dbz | dWr | dbr | dWh | dbh | dgamma |
-// dbeta, the canonical order) that it updates with plain read-modify-writes, and
-// reduce_partials_kernel adds the slices in a fixed order: parameter gradients are bitwise reproducible.
+// Three launches:
+//   1. gated_update_bwd_kernel: tiles of R = kBlock/D rows, intermediates recomputed from (h, agg) ->
+//      dh, dagg, the pre-activation gradients dpre = [dzp|drp|dtp] (rows x 3D), r*h (rows x D), and per
+//      workgroup the column sums that give dbz, dbr, dbh, dgamma, dbeta (5D floats);
+//   2. tn_gemm_splitk_kernel: the three kernel gradients dW_g = in_g^T dpre_g (in_z = in_r = [h|agg],
+//      in_h = [r*h|agg]) as split-K GEMMs over row chunks (64x32 output tiles, 4x2 per thread);
+//   3. gated_update_reduce_kernel: adds the per-workgroup / per-chunk partials in a fixed order into dparams
+//      (Wz 2D*D | bz | Wr | br | Wh | bh | gamma | beta): parameter gradients are bitwise reproducible.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
     const float* __restrict__ h, const float* __restrict__ agg, const float* __restrict__ Wz,
     const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
     const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma, float eps,
-    const float* __restrict__ dout, float* __restrict__ dh, float* __restrict__ dagg,
-    float* __restrict__ partial, int64_t rows, int D, int R) {
+    const float* __restrict__ dout, float* __restrict__ dh, float* __restrict__ dagg, float* __restrict__ dpre,
+    float* __restrict__ rh_out, float* __restrict__ small, int64_t rows, int D, int R) {
   extern __shared__ __align__(16) float smem[];
   float* hs = smem;            // R*D each
   float* as = hs + R * D;
@@ -205,16 +231,13 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
   float* rs = zs + R * D;
   float* rhs = rs + R * D;     // r * h
   float* ts = rhs + R * D;     // tanh
-  float* xs = ts + R * D;      // n, then x-hat
+  float* xs = ts + R * D;      // n, then x-hat, then dh so far
   float* g1 = xs + R * D;      // dx-hat, then dzp
   float* g2 = g1 + R * D;      // dx-hat * x-hat, then drp
   float* g3 = g2 + R * D;      // dtp
   float* st = g3 + R * D;      // 4*R: mean, inv, m1, m2
   const int tid = threadIdx.x;
-  const int DD2 = 2 * D * D;
-  const int P = 3 * (DD2 + D) + 2 * D;
-  float* mine = partial + (int64_t)blockIdx.x * P;
-  for (int q = tid; q < P; q += kBlock) mine[q] = 0.f;
+  float s_bz = 0.f, s_br = 0.f, s_bh = 0.f, s_dg = 0.f, s_db = 0.f;  // this thread's (row slot, column) sums
   const int64_t ntile = (rows + R - 1) / R;
   for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int64_t row0 = tile * R;
@@ -241,7 +264,9 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
       const float z = sigmoid_exact(az), rr = sigmoid_exact(ar);
       zs[t] = z;
       rs[t] = rr;
-      rhs[t] = rr * hs[t];
+      const float rhv = rr * hs[t];
+      rhs[t] = rhv;
+      rh_out[row0 * D + t] = rhv;
     }
     __syncthreads();
     for (int t = tid; t < nr * D; t += kBlock) {
@@ -271,7 +296,8 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
       const int r = t / D, i = t - r * D;
       const float xh = (xs[t] - st[4 * r]) * st[4 * r + 1];
       xs[t] = xh;
-      const float dxh = dout[row0 * D + t] * gamma[i];
+      const float dy = dout[row0 * D + t];
+      const float dxh = dy * gamma[i];
       g1[t] = dxh;
       g2[t] = dxh * xh;
     }
@@ -285,26 +311,25 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
       st[4 * r + 2] = m1 / (float)D;
       st[4 * r + 3] = m2 / (float)D;
     }
-    // dgamma / dbeta of this tile (thread i < D owns column i)
-    for (int i = tid; i < D; i += kBlock) {
-      float dg = 0.f, db = 0.f;
-      for (int r = 0; r < nr; ++r) {
-        const float dy = dout[(row0 + r) * D + i];
-        dg = fmaf(dy, xs[r * D + i], dg);
-        db += dy;
-      }
-      mine[3 * (DD2 + D) + i] += dg;
-      mine[3 * (DD2 + D) + D + i] += db;
-    }
     __syncthreads();
-    // dn -> (dzp, dtp), first part of dh
+    // dn -> (dzp, dtp), first part of dh; column sums for dgamma / dbeta
     for (int t = tid; t < nr * D; t += kBlock) {
       const int r = t / D;
-      const float dn = st[4 * r + 1] * (g1[t] - st[4 * r + 2] - xs[t] * st[4 * r + 3]);
+      const float dy = dout[row0 * D + t];
+      const float xh = xs[t];
+      const float dn = st[4 * r + 1] * (g1[t] - st[4 * r + 2] - xh * st[4 * r + 3]);
       const float z = zs[t], tt = ts[t];
-      g1[t] = dn * (tt - hs[t]) * z * (1.0f - z);   // dzp
-      g3[t] = dn * z * (1.0f - tt * tt);            // dtp
-      xs[t] = dout[row0 * D + t] + dn * (1.0f - z);  // dh so far (x-hat is dead)
+      const float dzp = dn * (tt - hs[t]) * z * (1.0f - z);
+      const float dtp = dn * z * (1.0f - tt * tt);
+      g1[t] = dzp;
+      g3[t] = dtp;
+      xs[t] = dy + dn * (1.0f - z);  // dh so far (x-hat is dead)
+      if (t == tid) {                 // kBlock == R*D: one element per thread, fixed (slot, column)
+        s_dg = fmaf(dy, xh, s_dg);
+        s_db += dy;
+        s_bz += dzp;
+        s_bh += dtp;
+      }
     }
     __syncthreads();
     // dc2 = dtp Wh^T: lower half -> through r*h, upper half -> dagg
@@ -317,12 +342,14 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
         hi = fmaf(d, Wh[(int64_t)(D + i) * D + j], hi);
       }
       const float rr = rs[t];
-      g2[t] = lo * hs[t] * rr * (1.0f - rr);  // drp
+      const float drp = lo * hs[t] * rr * (1.0f - rr);
+      g2[t] = drp;
       xs[t] += lo * rr;
-      zs[t] = hi;                               // dagg so far (z is dead)
+      zs[t] = hi;  // dagg so far (z is dead)
+      if (t == tid) s_br += drp;
     }
     __syncthreads();
-    // dc = dzp Wz^T + drp Wr^T
+    // dc = dzp Wz^T + drp Wr^T; dpre leaves for the kernel-gradient GEMMs
     for (int t = tid; t < nr * D; t += kBlock) {
       const int r = t / D, i = t - r * D;
       float lo = 0.f, hi = 0.f;
@@ -335,41 +362,109 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
       }
       dh[row0 * D + t] = xs[t] + lo;
       dagg[row0 * D + t] = zs[t] + hi;
+      float* dp = dpre + (row0 + r) * 3 * D;
+      dp[i] = g1[t];
+      dp[D + i] = g2[t];
+      dp[2 * D + i] = g3[t];
     }
-    // parameter gradients of this tile: dW_g[i'][j] += sum_r in_g[r][i'] dpre_g[r][j]
-    for (int q = tid; q < DD2; q += kBlock) {
-      const int ip = q / D, j = q - ip * D;
-      float az = 0.f, ar = 0.f, ah = 0.f;
-      for (int r = 0; r < nr; ++r) {
-        const float c = ip < D ? hs[r * D + ip] : as[r * D + ip - D];
-        const float c2 = ip < D ? rhs[r * D + ip] : c;
-        az = fmaf(c, g1[r * D + j], az);
-        ar = fmaf(c, g2[r * D + j], ar);
-        ah = fmaf(c2, g3[r * D + j], ah);
-      }
-      mine[q] += az;
-      mine[(DD2 + D) + q] += ar;
-      mine[2 * (DD2 + D) + q] += ah;
-    }
-    for (int j = tid; j < D; j += kBlock) {
-      float sz = 0.f, sr = 0.f, sh = 0.f;
-      for (int r = 0; r < nr; ++r) {
-        sz += g1[r * D + j];
-        sr += g2[r * D + j];
-        sh += g3[r * D + j];
-      }
-      mine[DD2 + j] += sz;
-      mine[(DD2 + D) + DD2 + j] += sr;
-      mine[2 * (DD2 + D) + DD2 + j] += sh;
-    }
+  }
+  // column sums: thread tid holds (slot tid / D, column tid % D); add the slots in a fixed order
+  __syncthreads();
+  float* red = smem;  // 5 * kBlock
+  red[tid] = s_bz;
+  red[kBlock + tid] = s_br;
+  red[2 * kBlock + tid] = s_bh;
+  red[3 * kBlock + tid] = s_dg;
+  red[4 * kBlock + tid] = s_db;
+  __syncthreads();
+  float* mine = small + (int64_t)blockIdx.x * 5 * D;
+  for (int q = tid; q < 5 * D; q += kBlock) {
+    const int which = q / D, i = q - which * D;
+    float acc = 0.f;
+    for (int slot = 0; slot < R; ++slot) acc += red[which * kBlock + slot * D + i];
+    mine[q] = acc;
   }
 }
 
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out, int nblk, int P) {
+// C[M x N] (per chunk) = sum over the chunk's rows of A[row][m] * B[row][n];  A = [A1 | A2] (rows x Mh each),
+// B with leading dimension ldb.  blockIdx = (chunk, tile, gate); 64 x 32 tile, thread owns 4 x 2.
+struct TnGemmArgs {
+  const float* A1[3];
+  const float* A2[3];
+  const float* B[3];
+};
+constexpr int kGM = 64, kGN = 32, kGR = 32;  // output tile, rows staged per iteration
+
+__global__ __launch_bounds__(kBlock) void tn_gemm_splitk_kernel(TnGemmArgs ga, float* __restrict__ partial,
+                                                                int64_t rows, int Mh, int N, int ldb, int nchunk,
+                                                                int tilesN) {
+  __shared__ __align__(16) float As[kGR][kGM];
+  __shared__ __align__(16) float Bs[kGR][kGN];
+  const int chunk = blockIdx.x, tile = blockIdx.y, gate = blockIdx.z;
+  const int tm0 = (tile / tilesN) * kGM, tn0 = (tile % tilesN) * kGN;
+  const int M = 2 * Mh;
+  const float* A1 = ga.A1[gate];
+  const float* A2 = ga.A2[gate];
+  const float* B = ga.B[gate];
+  const int tid = threadIdx.x, tm = tid / 16, tn = tid % 16;
+  const int64_t per = (rows + nchunk - 1) / nchunk;
+  const int64_t r_lo = (int64_t)chunk * per, r_hi = r_lo + per < rows ? r_lo + per : rows;
+  float acc[4][2] = {};
+  for (int64_t r0 = r_lo; r0 < r_hi; r0 += kGR) {
+    const int nr = (int)((r_hi - r0) < kGR ? (r_hi - r0) : kGR);
+    __syncthreads();
+    for (int t = tid; t < kGR * kGM; t += kBlock) {
+      const int r = t / kGM, m = tm0 + t % kGM;
+      float v = 0.f;
+      if (r < nr && m < M) v = m < Mh ? A1[(r0 + r) * Mh + m] : A2[(r0 + r) * Mh + m - Mh];
+      As[r][t % kGM] = v;
+    }
+    for (int t = tid; t < kGR * kGN; t += kBlock) {
+      const int r = t / kGN, n = tn0 + t % kGN;
+      Bs[r][t % kGN] = (r < nr && n < N) ? B[(r0 + r) * ldb + n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < kGR; ++r) {
+      const float4 a = *reinterpret_cast<const float4*>(&As[r][tm * 4]);
+      const float2 b = *reinterpret_cast<const float2*>(&Bs[r][tn * 2]);
+      acc[0][0] = fmaf(a.x, b.x, acc[0][0]); acc[0][1] = fmaf(a.x, b.y, acc[0][1]);
+      acc[1][0] = fmaf(a.y, b.x, acc[1][0]); acc[1][1] = fmaf(a.y, b.y, acc[1][1]);
+      acc[2][0] = fmaf(a.z, b.x, acc[2][0]); acc[2][1] = fmaf(a.z, b.y, acc[2][1]);
+      acc[3][0] = fmaf(a.w, b.x, acc[3][0]); acc[3][1] = fmaf(a.w, b.y, acc[3][1]);
+    }
+  }
+  float* out = partial + ((int64_t)gate * nchunk + chunk) * M * N;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = tm0 + tm * 4 + i, n = tn0 + tn * 2 + j;
+      if (m < M && n < N) out[(int64_t)m * N + n] = acc[i][j];
+    }
+}
+
+// dparams = fixed-order sums of the partials (canonical layout, see above)
+__global__ void gated_update_reduce_kernel(const float* __restrict__ small, const float* __restrict__ gpart,
+                                           float* __restrict__ dparams, int nblk, int nchunk, int D) {
+  const int DD2 = 2 * D * D;
+  const int P = 3 * (DD2 + D) + 2 * D;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < P; q += gridDim.x * blockDim.x) {
     float acc = 0.f;
-    for (int b = 0; b < nblk; ++b) acc += partial[(int64_t)b * P + q];
-    out[q] = acc;
+    if (q < 3 * (DD2 + D)) {
+      const int gate = q / (DD2 + D), off = q - gate * (DD2 + D);
+      if (off < DD2) {
+        const float* src = gpart + (int64_t)gate * nchunk * DD2 + off;
+        for (int c = 0; c < nchunk; ++c) acc += src[(int64_t)c * DD2];
+      } else {
+        const int i = off - DD2;  // bias of gate: column sums of dpre_gate
+        for (int b = 0; b < nblk; ++b) acc += small[(int64_t)b * 5 * D + gate * D + i];
+      }
+    } else {
+      const int o = q - 3 * (DD2 + D);  // gamma (0..D), beta (D..2D)
+      for (int b = 0; b < nblk; ++b) acc += small[(int64_t)b * 5 * D + 3 * D + o];
+    }
+    dparams[q] = acc;
   }
 }
 
@@ -427,7 +522,12 @@ inline int grid_for(int64_t items, int cap = 256 * 8) {
 
 int launch_embed_gather_bwd(const int32_t* ids, const float* dout, float* dtable, int64_t rows, int vocab, int dim,
                             hipStream_t s) {
-  embed_gather_bwd_kernel<<<grid_for(rows * dim), kBlock, 0, s>>>(ids, dout, dtable, rows, vocab, dim);
+  const size_t lds = sizeof(float) * (size_t)vocab * dim;
+  const int use_lds = lds <= 64 * 1024 && rows * dim >= 8 * (int64_t)vocab * dim;
+  if (use_lds && lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)embed_gather_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  embed_gather_bwd_kernel<<<grid_for(rows * dim, use_lds ? 512 : 256 * 8), kBlock, use_lds ? lds : 0, s>>>(
+      ids, dout, dtable, rows, vocab, dim, use_lds);
   return check_launch("embed_gather_bwd");
 }
 
@@ -477,29 +577,61 @@ int launch_bond_type_matrices_bwd(const float* tb, const float* W, const float* 
   return check_launch("bond_type_matrices_bwd_t");
 }
 
-int gated_update_bwd_blocks(int64_t rows, int D) {
-  const int R = kBlock / D > 0 ? kBlock / D : 1;
+static int gu_main_blocks(int64_t rows, int D) {
+  const int R = kBlock / D;
   const int64_t ntile = (rows + R - 1) / R;
-  return (int)(ntile < 256 ? (ntile < 1 ? 1 : ntile) : 256);
+  return (int)(ntile < 2048 ? (ntile < 1 ? 1 : ntile) : 2048);
+}
+static int gu_tiles(int D, int* tiles_n) {
+  const int tn = (D + kGN - 1) / kGN, tm = (2 * D + kGM - 1) / kGM;
+  if (tiles_n) *tiles_n = tn;
+  return tm * tn;
+}
+static int gu_chunks(int64_t rows, int D) {
+  const int tiles = gu_tiles(D, nullptr);
+  int64_t want = (1024 + 3 * tiles - 1) / (3 * tiles);
+  const int64_t cap = (rows + 63) / 64;
+  if (want > cap) want = cap;
+  return (int)(want < 1 ? 1 : want);
 }
 
+int gated_update_bwd_blocks(int64_t rows, int D) { return gu_main_blocks(rows, D); }
+
 int64_t gated_update_param_floats(int D) { return 3 * ((int64_t)2 * D * D + D) + 2 * D; }
+
+// workspace (floats): dpre rows*3D | r*h rows*D | small nblk*5D | GEMM partials 3*nchunk*2D*D
+int64_t gated_update_bwd_workspace(int64_t rows, int D) {
+  return rows * 4 * D + (int64_t)gu_main_blocks(rows, D) * 5 * D + (int64_t)3 * gu_chunks(rows, D) * 2 * D * D;
+}
 
 int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
                             const float* br, const float* Wh, const float* bh, const float* gamma, float eps,
                             const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
                             int64_t rows, int D, hipStream_t s) {
-  const int R = kBlock / D > 0 ? kBlock / D : 1;
-  const int nblk = gated_update_bwd_blocks(rows, D);
-  const int P = (int)gated_update_param_floats(D);
-  const size_t lds = sizeof(float) * ((size_t)10 * R * D + 4 * R);
-  if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute((const void*)gated_update_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  gated_update_bwd_kernel<<<nblk, kBlock, lds, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, dagg,
-                                                    workspace, rows, D, R);
+  if (D > kBlock || kBlock % D != 0)
+    return fail(IMPNN_E_UNSUPPORTED, "gated_update_bwd: atom_dim %d must divide %d", D, kBlock);
+  const int R = kBlock / D;
+  const int nblk = gu_main_blocks(rows, D), nchunk = gu_chunks(rows, D);
+  float* dpre = workspace;
+  float* rh = dpre + rows * 3 * D;
+  float* small = rh + rows * D;
+  float* gpart = small + (int64_t)nblk * 5 * D;
+  size_t lds = sizeof(float) * ((size_t)10 * R * D + 4 * R);
+  if (lds < sizeof(float) * 5 * kBlock) lds = sizeof(float) * 5 * kBlock;
+  gated_update_bwd_kernel<<<nblk, kBlock, lds, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, dagg, dpre,
+                                                    rh, small, rows, D, R);
   if (int rc = check_launch("gated_update_bwd")) return rc;
-  reduce_partials_kernel<<<grid_for(P, 64), kBlock, 0, s>>>(workspace, dparams, nblk, P);
-  return check_launch("reduce_partials");
+  int tiles_n = 1;
+  const int tiles = gu_tiles(D, &tiles_n);
+  TnGemmArgs ga;
+  ga.A1[0] = h;  ga.A2[0] = agg; ga.B[0] = dpre;
+  ga.A1[1] = h;  ga.A2[1] = agg; ga.B[1] = dpre + D;
+  ga.A1[2] = rh; ga.A2[2] = agg; ga.B[2] = dpre + 2 * D;
+  tn_gemm_splitk_kernel<<<dim3(nchunk, tiles, 3), kBlock, 0, s>>>(ga, gpart, rows, D, D, 3 * D, nchunk, tiles_n);
+  if (int rc = check_launch("tn_gemm_splitk")) return rc;
+  const int P = (int)gated_update_param_floats(D);
+  gated_update_reduce_kernel<<<grid_for(P, 256), kBlock, 0, s>>>(small, gpart, dparams, nblk, nchunk, D);
+  return check_launch("gated_update_reduce");
 }
 
 int launch_adam_clipnorm(const void* table, const void* sizes, int n_vars, int64_t step, float lr, float b1, float b2,
