@@ -89,6 +89,7 @@ __global__ void global_sum_pool_bwd_kernel(const float* __restrict__ dp, const i
 constexpr int kMol = 32;
 constexpr int kMaxSlots = 4096;   // kMol * E edge slots per workgroup
 constexpr int kMaxTypes = 1024;
+constexpr int kRunRows = 64;      // edges of a type run staged in LDS at a time
 
 template <int ACC>  // ACC = ceil(D*D / kBlock) accumulators per thread
 __global__ __launch_bounds__(kBlock) void bmm_message_typed_bwd_kernel(
@@ -133,42 +134,49 @@ __global__ __launch_bounds__(kBlock) void bmm_message_typed_bwd_kernel(
   }
   __syncthreads();
   const int DD = D * D;
+  float* gm = As + DD;             // kRunRows x D: dm rows of the staged edges
+  float* xm = gm + kRunRows * D;   // kRunRows x D: their source rows of h
+  __shared__ int64_t srcrow[kRunRows];
+  const int lanes = kBlock / D > 0 ? kBlock / D : 1;
   int pos = 0;
   while (pos < total) {  // workgroup-uniform walk over the type runs
     const int s0 = order[pos];
     const int ty = bond_ids[(int64_t)b0 * E + s0];
     const int end = cnt[ty + 1];
-    for (int t = tid; t < DD; t += kBlock) As[t] = A[(int64_t)ty * DD + t];
     __syncthreads();
-    // dh: thread (edge lane, column j)
-    const int lanes = kBlock / D > 0 ? kBlock / D : 1;
-    if (tid < lanes * D) {
-      const int j = tid % D, el = tid / D;
-      for (int p = pos + el; p < end; p += lanes) {
-        const int s = order[p];
-        const int64_t be = (int64_t)b0 * E + s;
-        const int64_t b = be / E;
-        const int src = conn[be * 2];
-        const float* g = dm + be * D;
-        float u = 0.f;
-        for (int i = 0; i < D; ++i) u = fmaf(g[i], As[i * D + j], u);
-        atomicAdd(&dh[(b * N + src) * D + j], u);
-      }
-    }
-    // dA of this run
+    for (int t = tid; t < DD; t += kBlock) As[t] = A[(int64_t)ty * DD + t];
     float acc[ACC];
 #pragma unroll
     for (int a = 0; a < ACC; ++a) acc[a] = 0.f;
-    for (int p = pos; p < end; ++p) {
-      const int s = order[p];
-      const int64_t be = (int64_t)b0 * E + s;
-      const int64_t b = be / E;
-      const float* g = dm + be * D;
-      const float* x = h + (b * N + conn[be * 2]) * D;
+    for (int p0 = pos; p0 < end; p0 += kRunRows) {
+      const int n = min(kRunRows, end - p0);
+      __syncthreads();
+      for (int t = tid; t < n * D; t += kBlock) {
+        const int e = t / D, c = t - e * D;
+        const int64_t be = (int64_t)b0 * E + order[p0 + e];
+        const int64_t row = (be / E) * N + conn[be * 2];
+        gm[e * D + c] = dm[be * D + c];
+        xm[e * D + c] = h[row * D + c];
+        if (c == 0) srcrow[e] = row;
+      }
+      __syncthreads();
+      if (tid < lanes * D) {  // dh: thread (edge lane, column j)
+        const int j = tid % D, el = tid / D;
+        for (int e = el; e < n; e += lanes) {
+          float u = 0.f;
+          for (int i = 0; i < D; ++i) u = fmaf(gm[e * D + i], As[i * D + j], u);
+          atomicAdd(&dh[srcrow[e] * D + j], u);
+        }
+      }
 #pragma unroll
-      for (int a = 0; a < ACC; ++a) {
+      for (int a = 0; a < ACC; ++a) {  // dA of this run: entry q = (i, j)
         const int q = tid + a * kBlock;
-        if (q < DD) acc[a] = fmaf(g[q / D], x[q % D], acc[a]);
+        if (q < DD) {
+          const int i = q / D, j = q - i * D;
+          float v = acc[a];
+          for (int e = 0; e < n; ++e) v = fmaf(gm[e * D + i], xm[e * D + j], v);
+          acc[a] = v;
+        }
       }
     }
 #pragma unroll
@@ -176,7 +184,6 @@ __global__ __launch_bounds__(kBlock) void bmm_message_typed_bwd_kernel(
       const int q = tid + a * kBlock;
       if (q < DD) atomicAdd(&dA[(int64_t)ty * DD + q], acc[a]);
     }
-    __syncthreads();
     pos = end;
   }
 }
@@ -218,6 +225,7 @@ __global__ void bond_type_matrices_bwd_t_kernel(const float* __restrict__ W, con
 //   3. gated_update_reduce_kernel: adds the per-workgroup / per-chunk partials in a fixed order into dparams
 //      (Wz 2D*D | bz | Wr | br | Wh | bh | gamma | beta): parameter gradients are bitwise reproducible.
 // ---------------------------------------------------------------------------------------
+template <bool WLDS>  // the three gate kernels staged in LDS (row stride D+1: both access directions conflict-free)
 __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
     const float* __restrict__ h, const float* __restrict__ agg, const float* __restrict__ Wz,
     const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
@@ -236,8 +244,23 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
   float* g2 = g1 + R * D;      // dx-hat * x-hat, then drp
   float* g3 = g2 + R * D;      // dtp
   float* st = g3 + R * D;      // 4*R: mean, inv, m1, m2
+  const int LD = D + 1;
+  float* wz_s = st + 4 * R;    // 2D*LD each (WLDS only)
+  float* wr_s = wz_s + 2 * D * LD;
+  float* wh_s = wr_s + 2 * D * LD;
   const int tid = threadIdx.x;
+#define WZ(r_, c_) (WLDS ? wz_s[(r_) * LD + (c_)] : Wz[(int64_t)(r_) * D + (c_)])
+#define WR(r_, c_) (WLDS ? wr_s[(r_) * LD + (c_)] : Wr[(int64_t)(r_) * D + (c_)])
+#define WH(r_, c_) (WLDS ? wh_s[(r_) * LD + (c_)] : Wh[(int64_t)(r_) * D + (c_)])
   float s_bz = 0.f, s_br = 0.f, s_bh = 0.f, s_dg = 0.f, s_db = 0.f;  // this thread's (row slot, column) sums
+  if (WLDS) {
+    for (int t = threadIdx.x; t < 2 * D * D; t += kBlock) {
+      const int rw = t / D, c = t - rw * D;
+      wz_s[rw * LD + c] = Wz[t];
+      wr_s[rw * LD + c] = Wr[t];
+      wh_s[rw * LD + c] = Wh[t];
+    }
+  }
   const int64_t ntile = (rows + R - 1) / R;
   for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int64_t row0 = tile * R;
@@ -253,13 +276,13 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
       float az = bz[i], ar = br[i];
       for (int j = 0; j < D; ++j) {
         const float x = hs[r * D + j];
-        az = fmaf(x, Wz[(int64_t)j * D + i], az);
-        ar = fmaf(x, Wr[(int64_t)j * D + i], ar);
+        az = fmaf(x, WZ(j, i), az);
+        ar = fmaf(x, WR(j, i), ar);
       }
       for (int j = 0; j < D; ++j) {
         const float x = as[r * D + j];
-        az = fmaf(x, Wz[(int64_t)(D + j) * D + i], az);
-        ar = fmaf(x, Wr[(int64_t)(D + j) * D + i], ar);
+        az = fmaf(x, WZ(D + j, i), az);
+        ar = fmaf(x, WR(D + j, i), ar);
       }
       const float z = sigmoid_exact(az), rr = sigmoid_exact(ar);
       zs[t] = z;
@@ -272,8 +295,8 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
     for (int t = tid; t < nr * D; t += kBlock) {
       const int r = t / D, i = t - r * D;
       float ah = bh[i];
-      for (int j = 0; j < D; ++j) ah = fmaf(rhs[r * D + j], Wh[(int64_t)j * D + i], ah);
-      for (int j = 0; j < D; ++j) ah = fmaf(as[r * D + j], Wh[(int64_t)(D + j) * D + i], ah);
+      for (int j = 0; j < D; ++j) ah = fmaf(rhs[r * D + j], WH(j, i), ah);
+      for (int j = 0; j < D; ++j) ah = fmaf(as[r * D + j], WH(D + j, i), ah);
       const float tt = tanhf(ah);
       ts[t] = tt;
       xs[t] = (1.0f - zs[t]) * hs[t] + zs[t] * tt;
@@ -338,8 +361,8 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
       float lo = 0.f, hi = 0.f;
       for (int j = 0; j < D; ++j) {
         const float d = g3[r * D + j];
-        lo = fmaf(d, Wh[(int64_t)i * D + j], lo);
-        hi = fmaf(d, Wh[(int64_t)(D + i) * D + j], hi);
+        lo = fmaf(d, WH(i, j), lo);
+        hi = fmaf(d, WH(D + i, j), hi);
       }
       const float rr = rs[t];
       const float drp = lo * hs[t] * rr * (1.0f - rr);
@@ -355,10 +378,10 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
       float lo = 0.f, hi = 0.f;
       for (int j = 0; j < D; ++j) {
         const float dz = g1[r * D + j], dr = g2[r * D + j];
-        lo = fmaf(dz, Wz[(int64_t)i * D + j], lo);
-        lo = fmaf(dr, Wr[(int64_t)i * D + j], lo);
-        hi = fmaf(dz, Wz[(int64_t)(D + i) * D + j], hi);
-        hi = fmaf(dr, Wr[(int64_t)(D + i) * D + j], hi);
+        lo = fmaf(dz, WZ(i, j), lo);
+        lo = fmaf(dr, WR(i, j), lo);
+        hi = fmaf(dz, WZ(D + i, j), hi);
+        hi = fmaf(dr, WR(D + i, j), hi);
       }
       dh[row0 * D + t] = xs[t] + lo;
       dagg[row0 * D + t] = zs[t] + hi;
@@ -385,6 +408,9 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
     mine[q] = acc;
   }
 }
+#undef WZ
+#undef WR
+#undef WH
 
 // C[M x N] (per chunk) = sum over the chunk's rows of A[row][m] * B[row][n];  A = [A1 | A2] (rows x Mh each),
 // B with leading dimension ldb.  blockIdx = (chunk, tile, gate); 64 x 32 tile, thread owns 4 x 2.
@@ -444,28 +470,37 @@ __global__ __launch_bounds__(kBlock) void tn_gemm_splitk_kernel(TnGemmArgs ga, f
     }
 }
 
-// dparams = fixed-order sums of the partials (canonical layout, see above)
+// dparams = fixed-order sums of the partials (canonical layout, see above).  One wave per output: lane l adds
+// partials l, l+64, ... in order, then a fixed butterfly - the same association on every run.
 __global__ void gated_update_reduce_kernel(const float* __restrict__ small, const float* __restrict__ gpart,
                                            float* __restrict__ dparams, int nblk, int nchunk, int D) {
   const int DD2 = 2 * D * D;
   const int P = 3 * (DD2 + D) + 2 * D;
-  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < P; q += gridDim.x * blockDim.x) {
-    float acc = 0.f;
-    if (q < 3 * (DD2 + D)) {
-      const int gate = q / (DD2 + D), off = q - gate * (DD2 + D);
-      if (off < DD2) {
-        const float* src = gpart + (int64_t)gate * nchunk * DD2 + off;
-        for (int c = 0; c < nchunk; ++c) acc += src[(int64_t)c * DD2];
-      } else {
-        const int i = off - DD2;  // bias of gate: column sums of dpre_gate
-        for (int b = 0; b < nblk; ++b) acc += small[(int64_t)b * 5 * D + gate * D + i];
-      }
+  const int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (q >= P) return;
+  const float* src;
+  int64_t stride;
+  int n;
+  if (q < 3 * (DD2 + D)) {
+    const int gate = q / (DD2 + D), off = q - gate * (DD2 + D);
+    if (off < DD2) {
+      src = gpart + (int64_t)gate * nchunk * DD2 + off;
+      stride = DD2;
+      n = nchunk;
     } else {
-      const int o = q - 3 * (DD2 + D);  // gamma (0..D), beta (D..2D)
-      for (int b = 0; b < nblk; ++b) acc += small[(int64_t)b * 5 * D + 3 * D + o];
+      src = small + gate * D + (off - DD2);  // bias of the gate: column sums of dpre_gate
+      stride = 5 * D;
+      n = nblk;
     }
-    dparams[q] = acc;
+  } else {
+    src = small + 3 * D + (q - 3 * (DD2 + D));  // gamma (0..D), beta (D..2D)
+    stride = 5 * D;
+    n = nblk;
   }
+  float acc = 0.f;
+  for (int c = lane; c < n; c += 64) acc += src[(int64_t)c * stride];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) dparams[q] = acc;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -550,7 +585,7 @@ int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const 
   if (Vb > kMaxTypes) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed_bwd: Vb=%d too large", Vb);
   if (D > 128) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed_bwd: D=%d > 128", D);
   const int grid = (B + kMol - 1) / kMol;
-  const size_t lds = sizeof(float) * (size_t)D * D;
+  const size_t lds = sizeof(float) * ((size_t)D * D + 2 * (size_t)kRunRows * D);
   const int acc = (D * D + kBlock - 1) / kBlock;
 #define LAUNCH(ACC)                                                                                      \
   do {                                                                                                   \
@@ -580,7 +615,7 @@ int launch_bond_type_matrices_bwd(const float* tb, const float* W, const float* 
 static int gu_main_blocks(int64_t rows, int D) {
   const int R = kBlock / D;
   const int64_t ntile = (rows + R - 1) / R;
-  return (int)(ntile < 2048 ? (ntile < 1 ? 1 : ntile) : 2048);
+  return (int)(ntile < 1024 ? (ntile < 1 ? 1 : ntile) : 1024);
 }
 static int gu_tiles(int D, int* tiles_n) {
   const int tn = (D + kGN - 1) / kGN, tm = (2 * D + kGM - 1) / kGM;
@@ -618,8 +653,18 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   float* gpart = small + (int64_t)nblk * 5 * D;
   size_t lds = sizeof(float) * ((size_t)10 * R * D + 4 * R);
   if (lds < sizeof(float) * 5 * kBlock) lds = sizeof(float) * 5 * kBlock;
-  gated_update_bwd_kernel<<<nblk, kBlock, lds, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, dagg, dpre,
-                                                    rh, small, rows, D, R);
+  const size_t wlds = sizeof(float) * (size_t)3 * 2 * D * (D + 1);
+  if (lds + wlds <= 120 * 1024) {
+    lds += wlds;
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)gated_update_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+    gated_update_bwd_kernel<true><<<nblk, kBlock, lds, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh,
+                                                            dagg, dpre, rh, small, rows, D, R);
+  } else {
+    gated_update_bwd_kernel<false><<<nblk, kBlock, lds, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh,
+                                                             dagg, dpre, rh, small, rows, D, R);
+  }
   if (int rc = check_launch("gated_update_bwd")) return rc;
   int tiles_n = 1;
   const int tiles = gu_tiles(D, &tiles_n);
@@ -630,7 +675,7 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   tn_gemm_splitk_kernel<<<dim3(nchunk, tiles, 3), kBlock, 0, s>>>(ga, gpart, rows, D, D, 3 * D, nchunk, tiles_n);
   if (int rc = check_launch("tn_gemm_splitk")) return rc;
   const int P = (int)gated_update_param_floats(D);
-  gated_update_reduce_kernel<<<grid_for(P, 256), kBlock, 0, s>>>(small, gpart, dparams, nblk, nchunk, D);
+  gated_update_reduce_kernel<<<(P * 64 + kBlock - 1) / kBlock, kBlock, 0, s>>>(small, gpart, dparams, nblk, nchunk, D);
   return check_launch("gated_update_reduce");
 }
 
