@@ -245,6 +245,12 @@ int impnn_gated_update_bwd(const float* h, const float* agg, const float* Wz, co
  *  sizes: DEVICE array of n_vars element counts. */
 int impnn_adam_clipnorm_step(const void* var_table, const int64_t* sizes, int32_t n_vars, int64_t step, float lr,
                              float beta1, float beta2, float eps, float clipnorm, impnn_stream_t stream);
+/*  The same with the step number in DEVICE memory: *step_counter is incremented by one (on the stream) and the
+ *  new value is the `step` of this update.  A training step captured in a hipGraph (forward, backward and this
+ *  call) then advances its own counter on every replay. */
+int impnn_adam_clipnorm_step_counted(const void* var_table, const int64_t* sizes, int32_t n_vars,
+                                     int64_t* step_counter, float lr, float beta1, float beta2, float eps,
+                                     float clipnorm, impnn_stream_t stream);
 
 /* ---- measurement: HIP-event timing of the dominant kernel (encoder_fused_kernel), recorded on the
  *      stream the kernel is launched on.  After impnn_profile_enable(capacity) every

@@ -398,7 +398,17 @@ int impnn_adam_clipnorm_step(const void* var_table, const int64_t* sizes, int32_
   REQUIRE(n_vars >= 0 && step >= 1, "bad arguments (step counts from 1)");
   if (n_vars == 0) return IMPNN_OK;
   REQUIRE(var_table && sizes, "null pointer");
-  return launch_adam_clipnorm(var_table, sizes, n_vars, step, lr, beta1, beta2, eps, clipnorm, as_stream(stream));
+  return launch_adam_clipnorm(var_table, sizes, n_vars, step, nullptr, lr, beta1, beta2, eps, clipnorm,
+                              as_stream(stream));
+}
+
+int impnn_adam_clipnorm_step_counted(const void* var_table, const int64_t* sizes, int32_t n_vars, int64_t* step_counter,
+                                     float lr, float beta1, float beta2, float eps, float clipnorm,
+                                     impnn_stream_t stream) {
+  REQUIRE(n_vars >= 0, "bad arguments");
+  REQUIRE(var_table && sizes && step_counter, "null pointer");
+  return launch_adam_clipnorm(var_table, sizes, n_vars, 0, step_counter, lr, beta1, beta2, eps, clipnorm,
+                              as_stream(stream));
 }
 
 int impnn_batch_assemble(int32_t n_ions, const int32_t* sample_idx, int32_t B, int32_t M,

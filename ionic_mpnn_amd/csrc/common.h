@@ -68,8 +68,8 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
                             const float* br, const float* Wh, const float* bh, const float* gamma, float eps,
                             const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
                             int64_t rows, int D, hipStream_t s);
-int launch_adam_clipnorm(const void* table, const void* sizes, int n_vars, int64_t step, float lr, float b1, float b2,
-                         float eps, float clipnorm, hipStream_t s);
+int launch_adam_clipnorm(const void* table, const void* sizes, int n_vars, int64_t step, int64_t* step_dev, float lr,
+                         float b1, float b2, float eps, float clipnorm, hipStream_t s);
 
 // ---- batch assembly (loader_kernels.hip)
 int launch_batch_assemble(int n_ions, const int32_t* sample_idx, int B, int M, const int32_t* const* atom_flat,

@@ -511,10 +511,18 @@ __global__ void gated_update_reduce_kernel(const float* __restrict__ small, cons
 //   w <- w - lr * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)
 // The variable table holds device pointers: 4 per variable (w, g, m, v) and the element count.
 // ---------------------------------------------------------------------------------------
+__global__ void incr_step_kernel(long long* step) { *step += 1; }
+
 __global__ __launch_bounds__(1024) void adam_clipnorm_kernel(const unsigned long long* __restrict__ table,
                                                              const long long* __restrict__ sizes, float lr,
                                                              float b1, float b2, float eps, float clipnorm,
-                                                             float corr1, float corr2) {
+                                                             float corr1, float corr2,
+                                                             const long long* __restrict__ step_dev) {
+  if (step_dev) {  // step counter in device memory (a captured hipGraph replays with a new step every time)
+    const float t = (float)*step_dev;
+    corr1 = 1.0f - powf(b1, t);
+    corr2 = 1.0f - powf(b2, t);
+  }
   __shared__ float red[16];
   __shared__ float scale_s;
   const int var = blockIdx.x;
@@ -679,12 +687,19 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   return check_launch("gated_update_reduce");
 }
 
-int launch_adam_clipnorm(const void* table, const void* sizes, int n_vars, int64_t step, float lr, float b1, float b2,
-                         float eps, float clipnorm, hipStream_t s) {
-  const float corr1 = 1.0f - powf(b1, (float)step), corr2 = 1.0f - powf(b2, (float)step);
+int launch_adam_clipnorm(const void* table, const void* sizes, int n_vars, int64_t step, int64_t* step_dev, float lr,
+                         float b1, float b2, float eps, float clipnorm, hipStream_t s) {
+  float corr1 = 1.0f, corr2 = 1.0f;
+  if (step_dev) {
+    incr_step_kernel<<<1, 1, 0, s>>>(reinterpret_cast<long long*>(step_dev));
+    if (int rc = check_launch("incr_step")) return rc;
+  } else {
+    corr1 = 1.0f - powf(b1, (float)step);
+    corr2 = 1.0f - powf(b2, (float)step);
+  }
   adam_clipnorm_kernel<<<n_vars, 1024, 0, s>>>(static_cast<const unsigned long long*>(table),
                                                static_cast<const long long*>(sizes), lr, b1, b2, eps, clipnorm,
-                                               corr1, corr2);
+                                               corr1, corr2, reinterpret_cast<const long long*>(step_dev));
   return check_launch("adam_clipnorm");
 }
 

@@ -353,10 +353,12 @@ class MPNNModel:
         return tot / max(n, 1)
 
     def fit(self, x, y, validation_data=None, epochs=1, batch_size=32, callbacks=None, shuffle=True, verbose=0,
-            seed=None):
+            seed=None, graph=True):
         """model.fit as the trainers call it (train_viscosity.py:328-338): per epoch a fresh shuffle,
         mini-batches of ``batch_size``, `loss` = sample-weighted mean of the batch losses, `val_loss` from
-        evaluate(); callbacks see on_train_begin / on_epoch_end / on_train_end.  Returns a History."""
+        evaluate(); callbacks see on_train_begin / on_epoch_end / on_train_end.  Returns a History.
+        ``graph=True`` (single process): full-size mini-batches replay one captured hipGraph of the whole step
+        (train.GraphedTrainStep); the last, smaller batch of an epoch runs eagerly."""
         from . import train
         if getattr(self, "optimizer", None) is None:
             self.compile()
@@ -369,13 +371,22 @@ class MPNNModel:
         for cb in callbacks:
             if hasattr(cb, "on_train_begin"):
                 cb.on_train_begin(self)
+        from . import dist as idist
+        graphed = None
+        use_graph = bool(graph) and not idist.is_distributed() and n >= batch_size
         for epoch in range(int(epochs)):
             order = rng.permutation(n) if shuffle else np.arange(n)
             tot = torch.zeros((), dtype=torch.float64, device=self.device)
             for lo in range(0, n, batch_size):
                 idx = order[lo:lo + batch_size]
                 tidx = torch.from_numpy(idx).to(self.device)
-                loss = self.train_on_batch({k: v[tidx] for k, v in x.items()}, y[idx])
+                xb = {k: v[tidx] for k, v in x.items()}
+                if use_graph and len(idx) == batch_size:
+                    if graphed is None:
+                        graphed = train.GraphedTrainStep(self, xb, y[idx])
+                    loss = graphed(xb, y[idx])
+                else:
+                    loss = self.train_on_batch(xb, y[idx])
                 tot += loss.double() * len(idx)
             logs = {"loss": float(tot) / max(n, 1)}
             if validation_data is not None:

@@ -26,8 +26,13 @@ class Adam:
     def __init__(self, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, clipnorm=None):
         self.learning_rate, self.beta_1, self.beta_2 = float(learning_rate), float(beta_1), float(beta_2)
         self.epsilon, self.clipnorm = float(epsilon), (None if clipnorm is None else float(clipnorm))
-        self.iterations = 0
         self._vars = None
+        self._step_dev = None
+
+    @property
+    def iterations(self):
+        """Number of updates applied (the counter lives in device memory; reading it synchronises)."""
+        return int(self._step_dev.item()) if self._step_dev is not None else 0
 
     def get_config(self):
         return {"name": "Adam", "learning_rate": self.learning_rate, "beta_1": self.beta_1, "beta_2": self.beta_2,
@@ -36,7 +41,7 @@ class Adam:
     def build(self, variables):
         """variables: list of leaf tensors on one GPU.  Gradients live in ONE flat buffer (views become the
         variables' .grad), so the data-parallel average is a single collective and the kernel's pointer table
-        stays valid for the whole run."""
+        stays valid for the whole run (also inside a captured hipGraph)."""
         variables = list(variables)
         dev = variables[0].device
         sizes = [int(v.numel()) for v in variables]
@@ -44,6 +49,7 @@ class Adam:
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
         self.m = torch.zeros(total, dtype=torch.float32, device=dev)
         self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         table, off = [], 0
         for var, n in zip(variables, sizes):
             if var.dtype != torch.float32 or not var.is_contiguous():
@@ -60,22 +66,81 @@ class Adam:
     def zero_grad(self):
         self.flat_grad.zero_()
 
+    def state(self):
+        return {"m": self.m.clone(), "v": self.v.clone(), "step": self._step_dev.clone()}
+
+    def load_state(self, st):
+        self.m.copy_(st["m"]); self.v.copy_(st["v"]); self._step_dev.copy_(st["step"])
+
     def apply_gradients(self):
-        """One launch: clip, moments, update for every variable (gradients are read from the flat buffer)."""
+        """One launch: clip, moments, update for every variable (gradients are read from the flat buffer);
+        the step counter is advanced on the device, so the call can sit inside a captured graph."""
         if self._vars is None:
             raise RuntimeError("Adam.build(variables) has not been called")
-        for var in self._vars:  # autograd may have swapped .grad for a fresh tensor if it was reset to None
-            if var.grad is None or var.grad.data_ptr() < self.flat_grad.data_ptr() or \
-                    var.grad.data_ptr() >= self.flat_grad.data_ptr() + 4 * self.flat_grad.numel():
+        lo, hi = self.flat_grad.data_ptr(), self.flat_grad.data_ptr() + 4 * self.flat_grad.numel()
+        for var in self._vars:  # autograd swaps .grad for a fresh tensor if it was reset to None
+            if var.grad is None or not (lo <= var.grad.data_ptr() < hi):
                 raise RuntimeError("a variable's .grad no longer points into the optimizer's flat buffer; "
                                    "use optimizer.zero_grad() instead of setting .grad = None")
-        self.iterations += 1
         dev = self.flat_grad.device
         with torch.cuda.device(dev):
-            check(_lib.load().impnn_adam_clipnorm_step(
+            check(_lib.load().impnn_adam_clipnorm_step_counted(
                 C.c_void_p(self._table.data_ptr()), C.c_void_p(self._sizes.data_ptr()), len(self._vars),
-                self.iterations, self.learning_rate, self.beta_1, self.beta_2, self.epsilon,
+                C.c_void_p(self._step_dev.data_ptr()), self.learning_rate, self.beta_1, self.beta_2, self.epsilon,
                 self.clipnorm if self.clipnorm else 0.0, stream_ptr()))
+
+
+class GraphedTrainStep:
+    """One training step (forward, backward, optimizer) of a fixed batch shape captured in a hipGraph
+    (torch.cuda.CUDAGraph) and replayed per mini-batch: the reference trains with batches of 32
+    (train_viscosity.py:332), where a step is ~150 small launches and the host, not the GPU, sets the pace.
+    Inputs are copied into static buffers; every kernel argument that changes between steps lives in device
+    memory (the Adam step counter)."""
+
+    def __init__(self, model, inputs, y):
+        self.model = model
+        dev = model.device
+        self.static_in = {k: v.clone() for k, v in model._to_device(inputs).items()}
+        self.static_y = torch.as_tensor(np.asarray(y, np.float32)).to(dev).reshape(-1, 1).clone()
+        self.batch = int(self.static_y.shape[0])
+        opt = model.optimizer
+        saved_w = [t.detach().clone() for _, t in model.trainable_variables()]
+        saved_o = opt.state()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):  # warm-up off the default stream, as graph capture requires
+            for _ in range(3):
+                self._step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_loss = self._step()
+        with torch.no_grad():  # the warm-up steps were real updates: undo them
+            for (_, t), w0 in zip(model.trainable_variables(), saved_w):
+                t.copy_(w0)
+        opt.load_state(saved_o)
+        opt.zero_grad()
+        model.invalidate_packed_weights()
+
+    def _step(self):
+        m = self.model
+        pred = m(self.static_in, training=True)
+        loss = mse(self.static_y, pred) + m.regularization_loss()
+        loss.backward()
+        m.optimizer.apply_gradients()
+        m.optimizer.zero_grad()
+        return loss.detach()
+
+    def matches(self, inputs):
+        return all(tuple(inputs[k].shape) == tuple(v.shape) for k, v in self.static_in.items())
+
+    def __call__(self, inputs, y):
+        for k, v in self.static_in.items():
+            v.copy_(inputs[k], non_blocking=True)
+        self.static_y.copy_(torch.as_tensor(np.asarray(y, np.float32)).reshape(-1, 1), non_blocking=True)
+        self.graph.replay()
+        self.model.invalidate_packed_weights()
+        return self.static_loss
 
 
 class History:

@@ -175,3 +175,31 @@ def test_fit_reduces_the_loss_and_early_stopping_restores_the_best_weights():
     a = m.predict(inp)
     b = m.predict(inp, fused=False)
     close(a, b, 1e-5, "fused vs layered after training")
+
+
+def test_graphed_train_step_follows_the_eager_trajectory():
+    """The captured hipGraph of (forward, backward, Adam) must walk the same path as eager steps: same losses and
+    same weights after several different mini-batches (float atomics in the embedding / message backward allow
+    last-bit differences only)."""
+    ma, w, inp, y = _tiny_model(S=2, seed=11)
+    mb, _, _, _ = _tiny_model(S=2, seed=11)
+    for m in (ma, mb):
+        m.compile(train.Adam(1e-3, clipnorm=1.0))
+    d = ma._to_device(inp)
+    batches = [np.arange(0, 8), np.arange(8, 16), np.arange(16, 24), np.arange(4, 12)]
+    pick = lambda idx: ({k: v[torch.from_numpy(idx).to(DEV)] for k, v in d.items()}, y[idx])
+    g = train.GraphedTrainStep(mb, *pick(batches[0]))
+    for _, (ta, tb) in zip(range(99), zip(ma.trainable_variables(), mb.trainable_variables())):
+        assert torch.equal(ta[1], tb[1])                       # capture left the weights untouched
+    assert mb.optimizer.iterations == 0
+    for idx in batches:
+        la = ma.train_on_batch(*pick(idx))
+        lb = g(*pick(idx)).clone()
+        close(lb, la, 1e-5, "loss")
+    assert ma.optimizer.iterations == mb.optimizer.iterations == len(batches)
+    for (n, ta), (_, tb) in zip(ma.trainable_variables(), mb.trainable_variables()):
+        close(tb, ta, 1e-4, f"weights {n}")
+    # fit() uses the graph for full batches and eager steps for the remainder
+    h1 = ma.fit(inp, y, epochs=2, batch_size=10, seed=3, graph=False)
+    h2 = mb.fit(inp, y, epochs=2, batch_size=10, seed=3, graph=True)
+    close(np.array(h2.history["loss"]), np.array(h1.history["loss"]), 1e-4, "fit loss, graph vs eager")

@@ -18,6 +18,7 @@ ap.add_argument("--atom-dim", type=int, default=32)
 ap.add_argument("--bond-dim", type=int, default=8)
 ap.add_argument("--steps", type=int, default=3, help="message-passing steps")
 ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per step (train.GraphedTrainStep)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 D, K, S, B = a.atom_dim, a.bond_dim, a.steps, a.batch
@@ -29,15 +30,16 @@ m.load_weights(weights.init_weights("viscosity", synthetic.DEFAULT_VA, synthetic
 m.compile(train.Adam(1e-3, clipnorm=1.0))
 d = m._to_device(inp)
 losses = []
+step = train.GraphedTrainStep(m, d, y) if a.graph else m.train_on_batch
 for _ in range(5):
-    losses.append(float(m.train_on_batch(d, y)))
+    losses.append(float(step(d, y)))
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(a.iters):
-    loss = m.train_on_batch(d, y)
+    loss = step(d, y)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / a.iters * 1e3
 losses.append(float(loss))
-print(json.dumps({"batch": B, "atom_dim": D, "bond_dim": K, "mp_steps": S, "ms_per_train_step": ms,
+print(json.dumps({"graph": bool(a.graph), "batch": B, "atom_dim": D, "bond_dim": K, "mp_steps": S, "ms_per_train_step": ms,
                   "pairs_per_s": B / (ms * 1e-3), "loss_first": losses[0], "loss_last": losses[-1],
                   "params": int(sum(t.numel() for _, t in m.trainable_variables()))}))
