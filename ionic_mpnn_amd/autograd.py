@@ -72,8 +72,11 @@ class BmmMessageTyped(torch.autograd.Function):
         E, Vb = conn.shape[1], mats.shape[0]
         dm = f32c(dm)
         dh, dmats = torch.zeros_like(h), torch.zeros_like(mats)
-        _lib_call(h.device, _lib.load().impnn_bmm_message_typed_bwd, ptr(h), ptr(bond_ids), ptr(conn), ptr(mats),
-                  ptr(dm), ptr(dh), ptr(dmats), B, N, E, D, Vb)
+        lib = _lib.load()
+        wsb = int(lib.impnn_bmm_message_typed_bwd_workspace_bytes(B, E, Vb))
+        ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=h.device)
+        _lib_call(h.device, lib.impnn_bmm_message_typed_bwd, ptr(h), ptr(bond_ids), ptr(conn), ptr(mats),
+                  ptr(dm), ptr(dh), ptr(dmats), ptr(ws), wsb, B, N, E, D, Vb)
         return dh, None, None, dmats
 
 

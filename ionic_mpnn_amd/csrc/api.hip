@@ -356,14 +356,22 @@ int impnn_global_sum_pool_bwd(const float* dpooled, const int32_t* atom_ids, flo
   return launch_global_sum_pool_bwd(dpooled, atom_ids, dh, B, N, D, as_stream(stream));
 }
 
+int64_t impnn_bmm_message_typed_bwd_workspace_bytes(int32_t B, int32_t E, int32_t Vb) {
+  if (B < 0 || E < 0 || Vb <= 0) return 0;
+  return 4 * bmm_message_typed_bwd_workspace_ints(B, E, Vb);
+}
+
 int impnn_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn,
                                 const float* type_mats, const float* dmessages, float* dh, float* dtype_mats,
-                                int32_t B, int32_t N, int32_t E, int32_t D, int32_t Vb, impnn_stream_t stream) {
+                                void* workspace, int64_t workspace_bytes, int32_t B, int32_t N, int32_t E, int32_t D,
+                                int32_t Vb, impnn_stream_t stream) {
   REQUIRE(B >= 0 && N > 0 && E >= 0 && D > 0 && Vb > 0, "bad shape");
   if (B == 0 || E == 0) return IMPNN_OK;
-  REQUIRE(h && bond_ids && conn && type_mats && dmessages && dh && dtype_mats, "null pointer");
-  return launch_bmm_message_typed_bwd(h, bond_ids, conn, type_mats, dmessages, dh, dtype_mats, B, N, E, D, Vb,
-                                      as_stream(stream));
+  REQUIRE(h && bond_ids && conn && type_mats && dmessages && dh && dtype_mats && workspace, "null pointer");
+  if (workspace_bytes < impnn_bmm_message_typed_bwd_workspace_bytes(B, E, Vb))
+    return fail(IMPNN_E_WORKSPACE, "bmm_message_typed_bwd: workspace of %lld bytes is too small", (long long)workspace_bytes);
+  return launch_bmm_message_typed_bwd(h, bond_ids, conn, type_mats, dmessages, dh, dtype_mats,
+                                      static_cast<int32_t*>(workspace), B, N, E, D, Vb, as_stream(stream));
 }
 
 int impnn_bond_type_matrices_bwd(const float* bond_table, const float* W, const float* dtype_mats, float* dW,

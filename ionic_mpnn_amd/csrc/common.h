@@ -56,9 +56,10 @@ int launch_embed_gather_bwd(const int32_t* ids, const float* dout, float* dtable
 int launch_reduce_scatter_bwd(const float* dagg, const int32_t* tgt, int tgt_stride, float* dm, int B, int N, int E,
                               int D, hipStream_t s);
 int launch_global_sum_pool_bwd(const float* dp, const int32_t* ids, float* dh, int B, int N, int D, hipStream_t s);
+int64_t bmm_message_typed_bwd_workspace_ints(int B, int E, int Vb);
 int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn, const float* A,
-                                 const float* dm, float* dh, float* dA, int B, int N, int E, int D, int Vb,
-                                 hipStream_t s);
+                                 const float* dm, float* dh, float* dA, int32_t* workspace, int B, int N, int E,
+                                 int D, int Vb, hipStream_t s);
 int launch_bond_type_matrices_bwd(const float* tb, const float* W, const float* dA, float* dW, float* dtb, int Vb,
                                   int K, int D, hipStream_t s);
 int gated_update_bwd_blocks(int64_t rows, int D);

@@ -81,110 +81,113 @@ __global__ void global_sum_pool_bwd_kernel(const float* __restrict__ dp, const i
 // a4 backward in the per-bond-type schedule.  Forward: m[b,e,:] = A[type_e] h[b,src_e,:] on valid edges.
 //   dh[b,src,:]  += A[type]^T dm[b,e,:]
 //   dA[type,i,j] += dm[b,e,i] h[b,src,j]
-// A workgroup takes kMol molecules, counting-sorts their valid edges by type in LDS, and walks the type
-// runs: A[type] is staged in LDS once per run; dA of the run is summed in registers ((i,j) entries dealt
-// over the threads) and leaves with one atomicAdd per entry and run; dh goes out with float atomics
-// (several edges share a source row).  dh and dA must be zeroed by the caller.
+// The valid edges of the WHOLE batch are counting-sorted by bond type (histogram, prefix, scatter - three
+// small launches), and every workgroup of the main kernel takes one segment of <= kSeg edges of one type:
+// A[type] and the segment's dm / h rows are staged in LDS, dA of the segment is summed in registers ((i,j)
+// entries dealt over the threads) and leaves with one atomicAdd per entry, dh goes out with float atomics
+// (several edges share a source row).  Parallelism is edges/kSeg workgroups at any batch size (a batch of
+// 32 molecules still gives ~100).  dh and dA must be zeroed by the caller.
+// workspace (int32): cnt Vb+1 | start Vb+1 | cursor Vb | segbase Vb+1 | order B*E
 // ---------------------------------------------------------------------------------------
-constexpr int kMol = 32;
-constexpr int kMaxSlots = 4096;   // kMol * E edge slots per workgroup
-constexpr int kMaxTypes = 1024;
-constexpr int kRunRows = 64;      // edges of a type run staged in LDS at a time
+constexpr int kSeg = 64;
+constexpr int kMaxTypes = 4096;
+
+__device__ __forceinline__ int edge_type_or_neg(const int32_t* conn, const int32_t* bond_ids, int64_t be, int N, int Vb) {
+  const int src = conn[be * 2], tgt = conn[be * 2 + 1], ty = bond_ids[be];
+  return (src > 0 && tgt > 0 && src < N && tgt < N && (unsigned)ty < (unsigned)Vb) ? ty : -1;
+}
+
+__global__ void zero_ints_kernel(int32_t* __restrict__ p, int n) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) p[t] = 0;
+}
+
+__global__ void edge_type_hist_kernel(const int32_t* __restrict__ conn, const int32_t* __restrict__ bond_ids,
+                                      int32_t* __restrict__ cnt, int64_t BE, int N, int Vb) {
+  for (int64_t be = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; be < BE; be += (int64_t)gridDim.x * blockDim.x) {
+    const int ty = edge_type_or_neg(conn, bond_ids, be, N, Vb);
+    if (ty >= 0) atomicAdd(&cnt[ty], 1);
+  }
+}
+
+// one workgroup: start[t] = exclusive prefix of cnt, cursor = start, segbase[t] = exclusive prefix of
+// ceil(cnt[t] / kSeg); start[Vb] = valid edges, segbase[Vb] = segments
+__global__ void edge_type_prefix_kernel(const int32_t* __restrict__ cnt, int32_t* __restrict__ start,
+                                        int32_t* __restrict__ cursor, int32_t* __restrict__ segbase, int Vb) {
+  if (threadIdx.x == 0) {
+    int run = 0, segs = 0;
+    for (int t = 0; t < Vb; ++t) {
+      const int c = cnt[t];
+      start[t] = run;
+      cursor[t] = run;
+      segbase[t] = segs;
+      run += c;
+      segs += (c + kSeg - 1) / kSeg;
+    }
+    start[Vb] = run;
+    segbase[Vb] = segs;
+  }
+}
+
+__global__ void edge_type_scatter_kernel(const int32_t* __restrict__ conn, const int32_t* __restrict__ bond_ids,
+                                         int32_t* __restrict__ cursor, int32_t* __restrict__ order, int64_t BE, int N,
+                                         int Vb) {
+  for (int64_t be = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; be < BE; be += (int64_t)gridDim.x * blockDim.x) {
+    const int ty = edge_type_or_neg(conn, bond_ids, be, N, Vb);
+    if (ty >= 0) order[atomicAdd(&cursor[ty], 1)] = (int32_t)be;
+  }
+}
 
 template <int ACC>  // ACC = ceil(D*D / kBlock) accumulators per thread
 __global__ __launch_bounds__(kBlock) void bmm_message_typed_bwd_kernel(
-    const float* __restrict__ h, const int32_t* __restrict__ bond_ids, const int32_t* __restrict__ conn,
-    const float* __restrict__ A, const float* __restrict__ dm, float* __restrict__ dh, float* __restrict__ dA,
-    int B, int N, int E, int D, int Vb) {
+    const float* __restrict__ h, const int32_t* __restrict__ conn, const float* __restrict__ A,
+    const float* __restrict__ dm, float* __restrict__ dh, float* __restrict__ dA, const int32_t* __restrict__ start,
+    const int32_t* __restrict__ segbase, const int32_t* __restrict__ order, int N, int E, int D, int Vb) {
   extern __shared__ __align__(16) float smem[];
-  __shared__ int cnt[kMaxTypes + 1];
-  __shared__ int order[kMaxSlots];
-  float* As = smem;  // D*D
+  __shared__ int64_t srcrow[kSeg];
+  const int seg = blockIdx.x;
+  if (seg >= segbase[Vb]) return;  // the grid is an upper bound on the number of segments
+  int lo = 0, hi = Vb - 1;          // type of this segment: largest t with segbase[t] <= seg
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (segbase[mid] <= seg) lo = mid; else hi = mid - 1;
+  }
+  const int ty = lo;
+  const int p0 = start[ty] + (seg - segbase[ty]) * kSeg;
+  const int n = min(kSeg, start[ty + 1] - p0);
+  if (n <= 0) return;
   const int tid = threadIdx.x;
-  const int b0 = blockIdx.x * kMol;
-  const int nb = min(kMol, B - b0);
-  const int slots = nb * E;
-  for (int t = tid; t <= Vb; t += kBlock) cnt[t] = 0;
-  __syncthreads();
-  auto valid_type = [&](int slot) -> int {
-    const int64_t be = (int64_t)b0 * E + slot;
-    const int src = conn[be * 2], tgt = conn[be * 2 + 1], ty = bond_ids[be];
-    return (src > 0 && tgt > 0 && src < N && tgt < N && (unsigned)ty < (unsigned)Vb) ? ty : -1;
-  };
-  for (int s = tid; s < slots; s += kBlock) {
-    const int ty = valid_type(s);
-    if (ty >= 0) atomicAdd(&cnt[ty + 1], 1);
-  }
-  __syncthreads();
-  if (tid == 0) {  // exclusive prefix over <= Vb+1 counters (Vb is small next to the edge work)
-    int run = 0;
-    for (int t = 1; t <= Vb; ++t) {
-      const int c = cnt[t];
-      cnt[t] = run;
-      run += c;
-    }
-    cnt[0] = run;  // total valid edges
-  }
-  __syncthreads();
-  const int total = cnt[0];
-  __syncthreads();
-  for (int s = tid; s < slots; s += kBlock) {
-    const int ty = valid_type(s);
-    if (ty >= 0) order[atomicAdd(&cnt[ty + 1], 1)] = s;  // cnt[ty+1] ends as the END of type ty's run
-  }
-  __syncthreads();
   const int DD = D * D;
-  float* gm = As + DD;             // kRunRows x D: dm rows of the staged edges
-  float* xm = gm + kRunRows * D;   // kRunRows x D: their source rows of h
-  __shared__ int64_t srcrow[kRunRows];
+  float* As = smem;            // D*D
+  float* gm = As + DD;         // kSeg x D: dm rows of the segment's edges
+  float* xm = gm + kSeg * D;   // kSeg x D: their source rows of h
+  for (int t = tid; t < DD; t += kBlock) As[t] = A[(int64_t)ty * DD + t];
+  for (int t = tid; t < n * D; t += kBlock) {
+    const int e = t / D, c = t - e * D;
+    const int64_t be = order[p0 + e];
+    const int64_t row = (be / E) * N + conn[be * 2];
+    gm[e * D + c] = dm[be * D + c];
+    xm[e * D + c] = h[row * D + c];
+    if (c == 0) srcrow[e] = row;
+  }
+  __syncthreads();
   const int lanes = kBlock / D > 0 ? kBlock / D : 1;
-  int pos = 0;
-  while (pos < total) {  // workgroup-uniform walk over the type runs
-    const int s0 = order[pos];
-    const int ty = bond_ids[(int64_t)b0 * E + s0];
-    const int end = cnt[ty + 1];
-    __syncthreads();
-    for (int t = tid; t < DD; t += kBlock) As[t] = A[(int64_t)ty * DD + t];
-    float acc[ACC];
-#pragma unroll
-    for (int a = 0; a < ACC; ++a) acc[a] = 0.f;
-    for (int p0 = pos; p0 < end; p0 += kRunRows) {
-      const int n = min(kRunRows, end - p0);
-      __syncthreads();
-      for (int t = tid; t < n * D; t += kBlock) {
-        const int e = t / D, c = t - e * D;
-        const int64_t be = (int64_t)b0 * E + order[p0 + e];
-        const int64_t row = (be / E) * N + conn[be * 2];
-        gm[e * D + c] = dm[be * D + c];
-        xm[e * D + c] = h[row * D + c];
-        if (c == 0) srcrow[e] = row;
-      }
-      __syncthreads();
-      if (tid < lanes * D) {  // dh: thread (edge lane, column j)
-        const int j = tid % D, el = tid / D;
-        for (int e = el; e < n; e += lanes) {
-          float u = 0.f;
-          for (int i = 0; i < D; ++i) u = fmaf(gm[e * D + i], As[i * D + j], u);
-          atomicAdd(&dh[srcrow[e] * D + j], u);
-        }
-      }
-#pragma unroll
-      for (int a = 0; a < ACC; ++a) {  // dA of this run: entry q = (i, j)
-        const int q = tid + a * kBlock;
-        if (q < DD) {
-          const int i = q / D, j = q - i * D;
-          float v = acc[a];
-          for (int e = 0; e < n; ++e) v = fmaf(gm[e * D + i], xm[e * D + j], v);
-          acc[a] = v;
-        }
-      }
+  if (tid < lanes * D) {  // dh: thread (edge lane, column j)
+    const int j = tid % D, el = tid / D;
+    for (int e = el; e < n; e += lanes) {
+      float u = 0.f;
+      for (int i = 0; i < D; ++i) u = fmaf(gm[e * D + i], As[i * D + j], u);
+      atomicAdd(&dh[srcrow[e] * D + j], u);
     }
+  }
 #pragma unroll
-    for (int a = 0; a < ACC; ++a) {
-      const int q = tid + a * kBlock;
-      if (q < DD) atomicAdd(&dA[(int64_t)ty * DD + q], acc[a]);
+  for (int a = 0; a < ACC; ++a) {  // dA of this segment: entry q = (i, j)
+    const int q = tid + a * kBlock;
+    if (q < DD) {
+      const int i = q / D, j = q - i * D;
+      float v = 0.f;
+      for (int e = 0; e < n; ++e) v = fmaf(gm[e * D + i], xm[e * D + j], v);
+      atomicAdd(&dA[(int64_t)ty * DD + q], v);
     }
-    pos = end;
   }
 }
 
@@ -586,21 +589,38 @@ int launch_global_sum_pool_bwd(const float* dp, const int32_t* ids, float* dh, i
   return check_launch("global_sum_pool_bwd");
 }
 
+int64_t bmm_message_typed_bwd_workspace_ints(int B, int E, int Vb) { return (int64_t)4 * (Vb + 1) + (int64_t)B * E; }
+
 int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn, const float* A,
-                                 const float* dm, float* dh, float* dA, int B, int N, int E, int D, int Vb,
-                                 hipStream_t s) {
-  if ((int64_t)kMol * E > kMaxSlots) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed_bwd: E=%d too large", E);
+                                 const float* dm, float* dh, float* dA, int32_t* workspace, int B, int N, int E,
+                                 int D, int Vb, hipStream_t s) {
   if (Vb > kMaxTypes) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed_bwd: Vb=%d too large", Vb);
   if (D > 128) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed_bwd: D=%d > 128", D);
-  const int grid = (B + kMol - 1) / kMol;
-  const size_t lds = sizeof(float) * ((size_t)D * D + 2 * (size_t)kRunRows * D);
+  const int64_t BE = (int64_t)B * E;
+  int32_t* cnt = workspace;
+  int32_t* start = cnt + (Vb + 1);
+  int32_t* cursor = start + (Vb + 1);
+  int32_t* segbase = cursor + (Vb + 1);
+  int32_t* order = segbase + (Vb + 1);
+  // (a kernel, not hipMemsetAsync: the call must behave the same inside a captured hipGraph)
+  zero_ints_kernel<<<grid_for(Vb + 1), kBlock, 0, s>>>(cnt, Vb + 1);
+  if (int rc = check_launch("zero_ints")) return rc;
+  edge_type_hist_kernel<<<grid_for(BE), kBlock, 0, s>>>(conn, bond_ids, cnt, BE, N, Vb);
+  if (int rc = check_launch("edge_type_hist")) return rc;
+  edge_type_prefix_kernel<<<1, 64, 0, s>>>(cnt, start, cursor, segbase, Vb);
+  if (int rc = check_launch("edge_type_prefix")) return rc;
+  edge_type_scatter_kernel<<<grid_for(BE), kBlock, 0, s>>>(conn, bond_ids, cursor, order, BE, N, Vb);
+  if (int rc = check_launch("edge_type_scatter")) return rc;
+  const int64_t max_segs = (BE + kSeg - 1) / kSeg + Vb;
+  const size_t lds = sizeof(float) * ((size_t)D * D + 2 * (size_t)kSeg * D);
   const int acc = (D * D + kBlock - 1) / kBlock;
-#define LAUNCH(ACC)                                                                                      \
-  do {                                                                                                   \
-    if (lds > 48 * 1024)                                                                                 \
-      (void)hipFuncSetAttribute((const void*)bmm_message_typed_bwd_kernel<ACC>,                          \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
-    bmm_message_typed_bwd_kernel<ACC><<<grid, kBlock, lds, s>>>(h, bond_ids, conn, A, dm, dh, dA, B, N, E, D, Vb); \
+#define LAUNCH(ACC)                                                                                          \
+  do {                                                                                                       \
+    if (lds > 48 * 1024)                                                                                     \
+      (void)hipFuncSetAttribute((const void*)bmm_message_typed_bwd_kernel<ACC>,                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+    bmm_message_typed_bwd_kernel<ACC><<<(int)max_segs, kBlock, lds, s>>>(h, conn, A, dm, dh, dA, start, segbase, \
+                                                                          order, N, E, D, Vb);              \
   } while (0)
   if (acc <= 1) LAUNCH(1);
   else if (acc <= 4) LAUNCH(4);
