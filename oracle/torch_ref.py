@@ -91,6 +91,16 @@ def viscosity_forward(w, inputs, dtype=torch.float32):
     return A + Bp / (T + Cp + 1e-6)
 
 
+def melting_point_forward(w, inputs, dtype=torch.float32):
+    """train_melting_point.py:146-208: K = D*D bond states, Add() mixing, Dense(relu) -> Dense(1)."""
+    fc = encode(w, "cat", inputs["cat_atom"], inputs["cat_bond"], inputs["cat_connectivity"], dtype)
+    fa = encode(w, "an", inputs["an_atom"], inputs["an_bond"], inputs["an_connectivity"], dtype)
+    cp = torch.relu(fc @ _t(w["cat_proj/kernel"], dtype) + _t(w["cat_proj/bias"], dtype))     # :192
+    ap = torch.relu(fa @ _t(w["an_proj/kernel"], dtype) + _t(w["an_proj/bias"], dtype))       # :193
+    x = torch.relu((cp + ap) @ _t(w["mp_hidden/kernel"], dtype) + _t(w["mp_hidden/bias"], dtype))  # :197
+    return x @ _t(w["mp_out/kernel"], dtype) + _t(w["mp_out/bias"], dtype)                    # :198
+
+
 def pooled_pair(w, inputs, dtype=torch.float32):
     """The hot path only: both ions' GlobalSumPool outputs."""
     return (encode(w, "cat", inputs["cat_atom"], inputs["cat_bond"], inputs["cat_connectivity"], dtype, True),

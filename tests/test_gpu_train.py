@@ -128,6 +128,30 @@ def test_whole_model_gradients_match_the_oracle():
         close(t.grad, wo[name].grad, 2e-4, f"grad {name}")
 
 
+def test_melting_point_model_gradients_match_the_oracle():
+    """train_melting_point.py: bond_dim = atom_dim^2 (the per-bond-type schedule is mandatory), l2(1e-5) on the
+    fingerprint and hidden Dense kernels."""
+    Va, Vb, D = 9, 5, 8
+    w = weights.init_weights("melting_point", Va, Vb, atom_dim=D, bond_dim=D * D, fp_size=12, mixing_size=10,
+                             num_steps=2, seed=4, perturb=True)
+    m = MM.build_melting_point_model(Va, Vb, atom_dim=D, fp_size=12, mixing_size=10, num_steps=2, device=DEV)
+    m.load_weights(w)
+    inp = synthetic.make_batch(12, max_atoms=9, max_edges=14, atom_vocab_size=Va, bond_vocab_size=Vb, min_atoms=3,
+                               seed=4, with_temperature=False)
+    y = np.random.default_rng(4).normal(0.0, 1.0, size=12).astype(np.float32)
+    m.compile()
+    loss = m._loss(m._to_device(inp), y, training=True)
+    loss.backward()
+    wo = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w.items()}
+    pred = TR.melting_point_forward(wo, inp, torch.float64)
+    lo = torch.mean((pred.reshape(-1) - torch.tensor(y, dtype=torch.float64)) ** 2) + 1e-5 * (
+        (wo["cat_fp/kernel"] ** 2).sum() + (wo["an_fp/kernel"] ** 2).sum() + (wo["mp_hidden/kernel"] ** 2).sum())
+    lo.backward()
+    close(loss, lo, 1e-5, "loss")
+    for name, t in m.trainable_variables():
+        close(t.grad, wo[name].grad, 2e-4, f"grad {name}")
+
+
 def test_config5_shape_trains_without_nonfinite_gradients():
     """D=128, S=6 (SURVEY config 5): untrained pre-activations of the viscosity head exceed 88, where a naive
     log1p(exp(x)) differentiates to NaN."""
