@@ -132,7 +132,9 @@ class MPNNModel:
         return {k: v.detach().cpu().numpy().copy() for k, v in self._named_tensors().items()}
 
     def load_weights(self, weights):
-        """weights: dict name -> array in the naming of ionic_mpnn_amd.weights."""
+        """weights: dict name -> array in the naming of ionic_mpnn_amd.weights, or the path of a save_weights file."""
+        if isinstance(weights, (str, bytes)) or hasattr(weights, "__fspath__"):
+            weights = self.load_weight_file(weights)[1]
         named = self._named_tensors()
         missing = sorted(set(named) - set(weights))
         if missing:
@@ -144,6 +146,37 @@ class MPNNModel:
             with torch.no_grad():
                 t.copy_(torch.from_numpy(a))
         self.invalidate_packed_weights()
+
+    # ---- f3: configuration and weight files (the .keras archive itself needs an HDF5 reader: not here)
+    def get_config(self):
+        """Constructor arguments + per-layer configs (keras Model.get_config analogue, models/layers.py:119-125)."""
+        return {"name": self.name, "kind": self.kind, "atom_vocab_size": self.atom_vocab_size,
+                "bond_vocab_size": self.bond_vocab_size, "atom_dim": self.atom_dim, "bond_dim": self.bond_dim,
+                "fp_size": self.fp_size, "mixing_size": self.mixing_size, "num_steps": self.num_steps,
+                "fp_l2": self.fp_l2,
+                "layers": [{"class_name": type(l).__name__, "config": l.get_config()} for l in self.layers]}
+
+    @classmethod
+    def from_config(cls, config, device=None):
+        L.reset_uids()  # keras auto-names (gated_update_3, ...) restart with a new model graph
+        return cls(config["kind"], config["atom_vocab_size"], config["bond_vocab_size"], config["atom_dim"],
+                   config["bond_dim"], config["fp_size"], config["mixing_size"], config["num_steps"],
+                   config.get("fp_l2", 1e-4), device=device, name=config.get("name"))
+
+    def save_weights(self, path):
+        """All variables under their Keras-style names (ionic_mpnn_amd.weights) plus the config, as one .npz."""
+        import json
+        arrays = self.state_dict()
+        cfg = {k: v for k, v in self.get_config().items() if k != "layers"}
+        np.savez(path, __config__=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), **arrays)
+
+    @staticmethod
+    def load_weight_file(path):
+        """-> (config dict, weights dict) from a file written by save_weights (no pickle is involved)."""
+        import json
+        with np.load(path, allow_pickle=False) as z:
+            cfg = json.loads(bytes(z["__config__"].tobytes()).decode())
+            return cfg, {k: z[k] for k in z.files if k != "__config__"}
 
     def invalidate_packed_weights(self):
         """Call after mutating layer weights in place; the fused encoder caches a packed copy."""

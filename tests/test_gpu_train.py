@@ -227,3 +227,18 @@ def test_graphed_train_step_follows_the_eager_trajectory():
     h1 = ma.fit(inp, y, epochs=2, batch_size=10, seed=3, graph=False)
     h2 = mb.fit(inp, y, epochs=2, batch_size=10, seed=3, graph=True)
     close(np.array(h2.history["loss"]), np.array(h1.history["loss"]), 1e-4, "fit loss, graph vs eager")
+
+
+def test_weight_file_round_trip(tmp_path):
+    """f3: config + variables under their Keras-style names survive save_weights -> from_config + load_weights."""
+    m, _, inp, _ = _tiny_model(S=2, seed=9)
+    path = tmp_path / "viscosity_final.npz"
+    m.save_weights(path)
+    cfg, w = MM.MPNNModel.load_weight_file(path)
+    assert cfg["atom_dim"] == 16 and cfg["num_steps"] == 2 and "cat_gu_1/dense_z/kernel" in w
+    m2 = MM.MPNNModel.from_config(cfg, device=DEV)
+    m2.load_weights(path)
+    assert [l.name for l in m2.layers] == [l.name for l in m.layers]
+    assert np.array_equal(m.predict(inp), m2.predict(inp))
+    lc = m.get_config()["layers"]
+    assert {"atom_dim": 16, "bond_dim": 4}.items() <= next(c["config"] for c in lc if c["class_name"] == "BondMatrixMessage").items()
