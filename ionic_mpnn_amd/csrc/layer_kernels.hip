@@ -695,6 +695,8 @@ int launch_bmm_message(const float* h, const float* bs, const int32_t* conn, con
 int launch_bond_type_matrices(const float* tb, const float* W, float* out, int Vb, int K, int D,
                               hipStream_t s) {
   const int DD = D * D;
+  if (K >= 64)  // K = D*D (train_melting_point.py:146): a real GEMM, out (Vb x DD) = Tb (Vb x K) W (K x DD)
+    return launch_strided_gemm(tb, W, out, K, Vb, DD, 1, K, DD, 1, s);
   dim3 grid((DD + kBlock - 1) / kBlock, Vb);
   bond_type_matrices_kernel<<<grid, kBlock, 0, s>>>(tb, W, out, Vb, K, DD);
   return check_launch("bond_type_matrices");

@@ -415,26 +415,28 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
 #undef WR
 #undef WH
 
-// C[M x N] (per chunk) = sum over the chunk's rows of A[row][m] * B[row][n];  A = [A1 | A2] (rows x Mh each),
-// B with leading dimension ldb.  blockIdx = (chunk, tile, gate); 64 x 32 tile, thread owns 4 x 2.
-struct TnGemmArgs {
+// C[M x N] (per chunk) = sum over the chunk's rows r of A(r,m) * B(r,n), every operand addressed with a row and
+// a column stride; the M axis may be the concatenation [A1 | A2] of two operands (split at Mh).
+// blockIdx = (chunk, tile, problem); 64 x 32 output tile, thread owns 4 x 2, 32 rows staged in LDS per iteration.
+// Output of chunk c of problem p: out + (p * nchunk + c) * M * N, row-major.
+struct GemmProblems {
   const float* A1[3];
   const float* A2[3];
   const float* B[3];
 };
 constexpr int kGM = 64, kGN = 32, kGR = 32;  // output tile, rows staged per iteration
 
-__global__ __launch_bounds__(kBlock) void tn_gemm_splitk_kernel(TnGemmArgs ga, float* __restrict__ partial,
-                                                                int64_t rows, int Mh, int N, int ldb, int nchunk,
-                                                                int tilesN) {
+__global__ __launch_bounds__(kBlock) void strided_gemm_splitk_kernel(GemmProblems ga, float* __restrict__ out,
+                                                                     int64_t rows, int M, int Mh, int N,
+                                                                     int64_t a_rs, int64_t a_cs, int64_t b_rs,
+                                                                     int64_t b_cs, int nchunk, int tilesN) {
   __shared__ __align__(16) float As[kGR][kGM];
   __shared__ __align__(16) float Bs[kGR][kGN];
-  const int chunk = blockIdx.x, tile = blockIdx.y, gate = blockIdx.z;
+  const int chunk = blockIdx.x, tile = blockIdx.y, prob = blockIdx.z;
   const int tm0 = (tile / tilesN) * kGM, tn0 = (tile % tilesN) * kGN;
-  const int M = 2 * Mh;
-  const float* A1 = ga.A1[gate];
-  const float* A2 = ga.A2[gate];
-  const float* B = ga.B[gate];
+  const float* A1 = ga.A1[prob];
+  const float* A2 = ga.A2[prob];
+  const float* B = ga.B[prob];
   const int tid = threadIdx.x, tm = tid / 16, tn = tid % 16;
   const int64_t per = (rows + nchunk - 1) / nchunk;
   const int64_t r_lo = (int64_t)chunk * per, r_hi = r_lo + per < rows ? r_lo + per : rows;
@@ -442,15 +444,31 @@ __global__ __launch_bounds__(kBlock) void tn_gemm_splitk_kernel(TnGemmArgs ga, f
   for (int64_t r0 = r_lo; r0 < r_hi; r0 += kGR) {
     const int nr = (int)((r_hi - r0) < kGR ? (r_hi - r0) : kGR);
     __syncthreads();
-    for (int t = tid; t < kGR * kGM; t += kBlock) {
-      const int r = t / kGM, m = tm0 + t % kGM;
-      float v = 0.f;
-      if (r < nr && m < M) v = m < Mh ? A1[(r0 + r) * Mh + m] : A2[(r0 + r) * Mh + m - Mh];
-      As[r][t % kGM] = v;
+    if (a_cs == 1) {  // columns contiguous: lanes walk m
+      for (int t = tid; t < kGR * kGM; t += kBlock) {
+        const int r = t / kGM, mm = t % kGM, m = tm0 + mm;
+        float v = 0.f;
+        if (r < nr && m < M) v = m < Mh ? A1[(r0 + r) * a_rs + m] : A2[(r0 + r) * a_rs + (m - Mh)];
+        As[r][mm] = v;
+      }
+    } else {          // rows contiguous (a transposed operand): lanes walk r
+      for (int t = tid; t < kGR * kGM; t += kBlock) {
+        const int mm = t / kGR, r = t % kGR, m = tm0 + mm;
+        float v = 0.f;
+        if (r < nr && m < M) v = m < Mh ? A1[(r0 + r) * a_rs + m * a_cs] : A2[(r0 + r) * a_rs + (m - Mh) * a_cs];
+        As[r][mm] = v;
+      }
     }
-    for (int t = tid; t < kGR * kGN; t += kBlock) {
-      const int r = t / kGN, n = tn0 + t % kGN;
-      Bs[r][t % kGN] = (r < nr && n < N) ? B[(r0 + r) * ldb + n] : 0.f;
+    if (b_cs == 1) {
+      for (int t = tid; t < kGR * kGN; t += kBlock) {
+        const int r = t / kGN, nn = t % kGN, n = tn0 + nn;
+        Bs[r][nn] = (r < nr && n < N) ? B[(r0 + r) * b_rs + n] : 0.f;
+      }
+    } else {
+      for (int t = tid; t < kGR * kGN; t += kBlock) {
+        const int nn = t / kGR, r = t % kGR, n = tn0 + nn;
+        Bs[r][nn] = (r < nr && n < N) ? B[(r0 + r) * b_rs + n * b_cs] : 0.f;
+      }
     }
     __syncthreads();
 #pragma unroll 8
@@ -463,13 +481,13 @@ __global__ __launch_bounds__(kBlock) void tn_gemm_splitk_kernel(TnGemmArgs ga, f
       acc[3][0] = fmaf(a.w, b.x, acc[3][0]); acc[3][1] = fmaf(a.w, b.y, acc[3][1]);
     }
   }
-  float* out = partial + ((int64_t)gate * nchunk + chunk) * M * N;
+  float* o = out + ((int64_t)prob * nchunk + chunk) * M * N;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int m = tm0 + tm * 4 + i, n = tn0 + tn * 2 + j;
-      if (m < M && n < N) out[(int64_t)m * N + n] = acc[i][j];
+      if (m < M && n < N) o[(int64_t)m * N + n] = acc[i][j];
     }
 }
 
@@ -630,9 +648,24 @@ int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const 
   return check_launch("bmm_message_typed_bwd");
 }
 
+// out[M x N] = sum_r A(r,m) B(r,n) in one pass (no split: deterministic, no workspace)
+int launch_strided_gemm(const float* A, const float* B, float* out, int64_t rows, int M, int N, int64_t a_rs,
+                        int64_t a_cs, int64_t b_rs, int64_t b_cs, hipStream_t s) {
+  GemmProblems ga{};
+  ga.A1[0] = A; ga.A2[0] = A; ga.B[0] = B;
+  const int tiles_n = (N + kGN - 1) / kGN, tiles_m = (M + kGM - 1) / kGM;
+  strided_gemm_splitk_kernel<<<dim3(1, tiles_m * tiles_n, 1), kBlock, 0, s>>>(ga, out, rows, M, M, N, a_rs, a_cs, b_rs,
+                                                                              b_cs, 1, tiles_n);
+  return check_launch("strided_gemm");
+}
+
 int launch_bond_type_matrices_bwd(const float* tb, const float* W, const float* dA, float* dW, float* dtb, int Vb,
                                   int K, int D, hipStream_t s) {
   const int DD = D * D;
+  if (K >= 64) {  // GEMM-shaped: dW (K x DD) = Tb^T dA over Vb rows; dTb (Vb x K) = dA W^T over DD rows
+    if (int rc = launch_strided_gemm(tb, dA, dW, Vb, K, DD, K, 1, DD, 1, s)) return rc;
+    return launch_strided_gemm(dA, W, dtb, DD, Vb, K, 1, DD, 1, DD, s);
+  }
   bond_type_matrices_bwd_w_kernel<<<dim3((DD + kBlock - 1) / kBlock, K), kBlock, 0, s>>>(tb, dA, dW, Vb, K, DD);
   if (int rc = check_launch("bond_type_matrices_bwd_w")) return rc;
   const int64_t waves = (int64_t)Vb * K;
@@ -696,12 +729,13 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   if (int rc = check_launch("gated_update_bwd")) return rc;
   int tiles_n = 1;
   const int tiles = gu_tiles(D, &tiles_n);
-  TnGemmArgs ga;
+  GemmProblems ga;
   ga.A1[0] = h;  ga.A2[0] = agg; ga.B[0] = dpre;
   ga.A1[1] = h;  ga.A2[1] = agg; ga.B[1] = dpre + D;
   ga.A1[2] = rh; ga.A2[2] = agg; ga.B[2] = dpre + 2 * D;
-  tn_gemm_splitk_kernel<<<dim3(nchunk, tiles, 3), kBlock, 0, s>>>(ga, gpart, rows, D, D, 3 * D, nchunk, tiles_n);
-  if (int rc = check_launch("tn_gemm_splitk")) return rc;
+  strided_gemm_splitk_kernel<<<dim3(nchunk, tiles, 3), kBlock, 0, s>>>(ga, gpart, rows, 2 * D, D, D, D, 1, 3 * D, 1,
+                                                                       nchunk, tiles_n);
+  if (int rc = check_launch("strided_gemm_splitk")) return rc;
   const int P = (int)gated_update_param_floats(D);
   gated_update_reduce_kernel<<<(P * 64 + kBlock - 1) / kBlock, kBlock, 0, s>>>(small, gpart, dparams, nblk, nchunk, D);
   return check_launch("gated_update_reduce");

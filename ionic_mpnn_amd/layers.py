@@ -233,13 +233,30 @@ class BondMatrixMessage(Layer):
             if self.fused:
                 bond_state = bond_state.dense()
             else:
-                mats = ops.bond_type_matrices(bond_state.table, self.bond_transform)
-                return ops.bmm_message_typed(atom_state, bond_state.ids, connectivity, mats)
+                return ops.bmm_message_typed(atom_state, bond_state.ids, connectivity,
+                                             self._type_matrices(bond_state.table))
         if bond_state.shape[-1] != self.bond_dim:
             raise ValueError(f"bond_state last dim {bond_state.shape[-1]} != bond_dim {self.bond_dim}")
         if self.fused:
             return ops.bmm_fused(atom_state, bond_state, connectivity, self.bond_transform)
         return ops.bmm_message(atom_state, bond_state, connectivity, self.bond_transform)
+
+    def _type_matrices(self, table):
+        """A[v] = sum_k table[v,k] W[k] depends on the weights only: without grad it is kept until either
+        tensor changes (torch version counters; ``invalidate_cache()`` for writers that bypass torch, i.e. the
+        optimizer kernel).  With bond_dim = atom_dim**2 this GEMM is most of a layer-at-a-time step."""
+        W = self.bond_transform
+        if torch.is_grad_enabled() and (W.requires_grad or table.requires_grad):
+            return ops.bond_type_matrices(table, W)
+        key = (table.data_ptr(), table._version, W.data_ptr(), W._version)
+        c = getattr(self, "_mats_cache", None)
+        if c is None or c[0] != key:
+            c = (key, ops.bond_type_matrices(table, W))
+            self._mats_cache = c
+        return c[1]
+
+    def invalidate_cache(self):
+        self._mats_cache = None
 
     def get_config(self):
         cfg = super().get_config()

@@ -184,6 +184,9 @@ class MPNNModel:
         self._prepared = {}
         self._split_deg_limit = None
         self._head_packed = None
+        for p in ("cat", "an"):
+            for lyr in self.branches[p]["bmm"]:
+                lyr.invalidate_cache()
 
     def _packed_head(self):
         """Head weights in the layout of impnn_model_head (include/impnn.h), cached per weight version."""

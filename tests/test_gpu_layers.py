@@ -136,6 +136,27 @@ def test_layer_objects_chain_like_encode():
     assert_close(pooled.cpu().numpy(), outs["cat/pooled"], what="pooled")
 
 
+def test_type_matrix_cache_follows_weight_changes():
+    """Embedding(lazy=True) -> BondMatrixMessage keeps A[v] = sum_k Tb[v,k] W[k] between calls; any in-place change of
+    the bond table or of bond_transform must be seen by the next call."""
+    _, inp, w, outs = load_case("tiny_viscosity")
+    d = torch.device(DEV)
+    h, conn, bond_ids = dev(f32(outs["cat/h0"])), dev(inp["cat_connectivity"]), dev(inp["cat_bond"])
+    emb = L.Embedding(w["bond_embedding"].shape[0], 4, lazy=True, device=d)
+    emb(bond_ids)
+    bmm = L.BondMatrixMessage(8, 4, name="cat_bmm_0", device=d)
+    first = bmm([h, emb(bond_ids), conn]).clone()          # random initial weights
+    emb.set_weights([w["bond_embedding"]])
+    bmm.set_weights([w["cat_bmm_0/bond_transform"]])
+    m = bmm([h, emb(bond_ids), conn])
+    assert not torch.equal(m, first)
+    assert_close(m.cpu().numpy(), outs["cat/m0"], what="m0 after set_weights")
+    assert torch.equal(bmm([h, emb(bond_ids), conn]), m)   # served from the cache
+    with torch.no_grad():
+        bmm.bond_transform.mul_(2.0)
+    assert_close(bmm([h, emb(bond_ids), conn]).cpu().numpy(), 2.0 * outs["cat/m0"], what="m0 after in-place scale")
+
+
 # ------------------------------------------------------------------ edge cases
 def test_empty_and_degenerate_shapes():
     assert ops.embed_gather(torch.zeros(0, 5, dtype=torch.int32, device=DEV), dev(np.ones((3, 4), np.float32))).shape == (0, 5, 4)

@@ -231,6 +231,8 @@ def test_graphed_train_step_follows_the_eager_trajectory():
 
 def test_weight_file_round_trip(tmp_path):
     """f3: config + variables under their Keras-style names survive save_weights -> from_config + load_weights."""
+    from ionic_mpnn_amd import layers as LL
+    LL.reset_uids()  # keras auto-names (gated_update_3, ...) count from the start of a session
     m, _, inp, _ = _tiny_model(S=2, seed=9)
     path = tmp_path / "viscosity_final.npz"
     m.save_weights(path)
