@@ -244,3 +244,19 @@ def test_weight_file_round_trip(tmp_path):
     assert np.array_equal(m.predict(inp), m2.predict(inp))
     lc = m.get_config()["layers"]
     assert {"atom_dim": 16, "bond_dim": 4}.items() <= next(c["config"] for c in lc if c["class_name"] == "BondMatrixMessage").items()
+
+
+def test_trainer_flow_end_to_end(monkeypatch):
+    """records -> resident dataset (GPU batch assembly) -> fit (graphed steps) -> predict: the flow of
+    train_viscosity.py main() (tools/example_train_viscosity.py)."""
+    import importlib.util
+    import sys
+    from pathlib import Path
+    path = Path(__file__).resolve().parents[1] / "tools" / "example_train_viscosity.py"
+    spec = importlib.util.spec_from_file_location("example_train_viscosity", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["example", "--records", "160", "--epochs", "6"])
+    out = mod.main()
+    assert out["epochs_run"] == 6 and np.isfinite(out["last_loss"]) and out["last_loss"] < out["first_loss"]
+    assert all(np.isfinite(out[k]) for k in ("train_r2", "dev_mae", "test_mae"))
