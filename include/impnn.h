@@ -171,7 +171,7 @@ int impnn_model_head(int32_t kind, const float* pooled_cat, const float* pooled_
  *      impnn_encoder_fused_prepared(...) == impnn_encoder_plan(...) then impnn_encoder_run(...). */
 int impnn_encoder_plan(int32_t n_ions, const int32_t* const* atom_ids, const int32_t* const* bond_ids,
                        const int32_t* const* conn, int32_t B, int32_t N, int32_t E, int32_t D,
-                       int32_t K, int32_t S, int32_t Vb, void* workspace, size_t workspace_bytes,
+                       int32_t K, int32_t S, int32_t Va, int32_t Vb, void* workspace, size_t workspace_bytes,
                        impnn_stream_t stream);
 int impnn_encoder_run(int32_t n_ions, const int32_t* const* atom_ids, const float* atom_table,
                       int32_t Va, const float* bond_table, int32_t Vb, const void* const* prepared,

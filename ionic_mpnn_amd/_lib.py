@@ -38,7 +38,7 @@ SIGNATURES = {
                                                C.POINTER(vp), i32, C.POINTER(vp), i32, i32, i32, i32, i32, i32, f32,
                                                vp, sz, vp]),
     "impnn_encoder_plan": (C.c_int, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i32, i32,
-                                     i32, vp, sz, vp]),
+                                     i32, i32, vp, sz, vp]),
     "impnn_encoder_run": (C.c_int, [i32, C.POINTER(vp), vp, i32, vp, i32, C.POINTER(vp), i32, C.POINTER(vp), i32, i32,
                                     i32, i32, i32, i32, f32, vp, sz, vp]),
     "impnn_model_head_floats": (i64, [i32, i32, i32, i32]),

@@ -219,8 +219,8 @@ int impnn_encoder_fused(int32_t n_ions, const int32_t* const* atom_ids, const in
 
 int impnn_encoder_plan(int32_t n_ions, const int32_t* const* atom_ids, const int32_t* const* bond_ids,
                        const int32_t* const* conn, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K, int32_t S,
-                       int32_t Vb, void* workspace, size_t workspace_bytes, impnn_stream_t stream) {
-  return encoder_common(__func__, n_ions, atom_ids, bond_ids, conn, nullptr, 1, nullptr, Vb, nullptr, nullptr, 0,
+                       int32_t Va, int32_t Vb, void* workspace, size_t workspace_bytes, impnn_stream_t stream) {
+  return encoder_common(__func__, n_ions, atom_ids, bond_ids, conn, nullptr, Va, nullptr, Vb, nullptr, nullptr, 0,
                         nullptr, B, N, E, D, K, S, 0.f, workspace, workspace_bytes, stream, 1);
 }
 

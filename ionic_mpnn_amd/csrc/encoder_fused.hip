@@ -143,9 +143,9 @@ __device__ __forceinline__ void mma3(f32x4& acc, const _Float16* blk, int lane, 
   acc = mfma16(al, b.hi, acc);
 }
 
-// image | h (2 buffers) | chunk record | bond table (Vb*8 floats, sized at launch so that the plan
+// image | h | chunk record | bond table (Vb*8 floats, sized at launch so that the plan
 // kernels of the next batch still find LDS on the same CU)
-constexpr size_t kLdsFixedBytes = sizeof(float) * ((size_t)kImgSlot + 2 * kRCap * kHS) + kRecBytes;
+constexpr size_t kLdsFixedBytes = sizeof(float) * ((size_t)kImgSlot + kRCap * kHS) + kRecBytes;
 static_assert(kLdsFixedBytes + sizeof(float) * kTbCapFloats <= 160 * 1024, "LDS budget");
 
 // KT = compile-time bond_dim (0: run-time K <= 8); SPLIT: mode 1 (fp16 hi/lo products)
@@ -154,9 +154,8 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
   extern __shared__ __align__(16) float smem[];
   const int K = KT ? KT : p.K;
   float* const wimg = smem;
-  float* const hbuf0 = wimg + kImgSlot;
-  float* const hbuf1 = hbuf0 + kRCap * kHS;
-  unsigned char* const recl = reinterpret_cast<unsigned char*>(hbuf1 + kRCap * kHS);
+  float* const hbuf = wimg + kImgSlot;  // node state, updated in place (see the step loop)
+  unsigned char* const recl = reinterpret_cast<unsigned char*>(hbuf + kRCap * kHS);
   float* const tbl = reinterpret_cast<float*>(recl + kRecBytes);
   const uint16_t* const r_rowptr = reinterpret_cast<const uint16_t*>(recl + kRecRowptr);
   const unsigned char* const r_tilemax = recl + kRecTilemax;
@@ -179,6 +178,13 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
     const int v = t >> 3, k = t & 7;
     tbl[t] = k < K ? p.bond_table[v * K + k] * (SPLIT ? kSX : 1.0f) : 0.f;
   }
+  // atom table copy: a chunk prologue then fills h0 from LDS instead of waiting for a global round trip
+  float* const atab = tbl + ((p.Vb * kKMax + 127) & ~127);  // Va rows + one zero row (slack / out-of-range ids)
+  if (p.atab_lds)  // rows at the h buffer's stride (kHS floats: random rows spread over the LDS banks)
+    for (int t = tid; t < (p.Va + 1) * (kD / 4); t += kThreads) {
+      const int r = t >> 3, c = t & 7;
+      st4(atab + r * kHS + 4 * c, r < p.Va ? ld4(p.atom_table + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
   const float* wmsg = wimg;
   const float* wupd = wimg + img_msg_floats(K);
   const float* wvec = SPLIT ? wimg + img16_vec_float_off(K) : wupd + img_upd_floats();
@@ -217,18 +223,23 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
       for (int i = 0; i < kPf; ++i) pf[i] = ld4(img_g + 4 * (tid + i * kThreads));
     }
     lds_barrier();
-    {  // h0 (train_viscosity.py:171) for the placed row: 4 threads per row, 2 x 16 B each; slack rows: zeros
+    // h0 (train_viscosity.py:171).  With the atom table in LDS, step 0 reads atom_table[id] directly (the in-edge
+    // entries carry the source's atom id) and writes h1 into the buffer: nothing to fill here.
+    if (!p.atab_lds || p.S == 0) {  // 4 threads per placed row, 2 x 16 B each; slack rows: zeros
       const int row = tid >> 2, sub = tid & 3;
       const int id = r_rowatom[row];
       f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
       if ((unsigned)id < (unsigned)p.Va) {
-        v0 = ld4(p.atom_table + (int64_t)id * kD + 8 * sub);
-        v1 = ld4(p.atom_table + (int64_t)id * kD + 8 * sub + 4);
+        if (p.atab_lds) {  // (two branches: one pointer for both would turn the loads into flat_load)
+          v0 = ld4(atab + id * kHS + 8 * sub);
+          v1 = ld4(atab + id * kHS + 8 * sub + 4);
+        } else {
+          v0 = ld4(p.atom_table + (int64_t)id * kD + 8 * sub);
+          v1 = ld4(p.atom_table + (int64_t)id * kD + 8 * sub + 4);
+        }
       }
-      st4(hbuf0 + row * kHS + 8 * sub, v0);
-      st4(hbuf0 + row * kHS + 8 * sub + 4, v1);
-      st4(hbuf1 + row * kHS + 8 * sub, v0);
-      st4(hbuf1 + row * kHS + 8 * sub + 4, v1);
+      st4(hbuf + row * kHS + 8 * sub, v0);
+      st4(hbuf + row * kHS + 8 * sub + 4, v1);
     }
     if (need_image) {
 #pragma unroll
@@ -244,8 +255,15 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
 
     // ---- message-passing steps: one 16-atom tile per wave (16 waves, 4 per SIMD)
     for (int s = 0; s < p.S; ++s) {
-      const float* hcur = (s & 1) ? hbuf1 : hbuf0;
-      float* hnext = (s & 1) ? hbuf0 : hbuf1;
+      // One h buffer: every wave gathers (reads other rows) BEFORE the mid-step barrier and writes its own rows
+      // AFTER it, and the end-of-step barrier orders those writes before the next step's gathers.  Rows that are
+      // skipped (no tile work) simply keep their value.
+      const float* hcur = hbuf;
+      float* hnext = hbuf;
+      const bool g0 = p.atab_lds && s == 0;             // step 0 gathers from the atom table
+      // in-edge entries carry ready float4 offsets: [31:20] into the atom table, [19:8] into the h buffer
+      const int src_shift = g0 ? 20 : 8;
+      const int src_base = (g0 ? (int)(atab - smem) : (int)(hbuf - smem)) + 4 * q;
       const int sn = (s + 1) < p.S ? (s + 1) : 0;  // the last step fetches the step-0 image for the next chunk
       const float* nxt = img_g + (int64_t)sn * kImgSlot;
       bool pf_issued = false;
@@ -282,9 +300,10 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
         {
           // first in-edge initialises G (rows without in-edges use a zero coefficient vector)
           const uint32_t ent = r_ent[deg > 0 ? p0 : 0];
-          const int src = ent & 0xffu, bid = (ent >> 8) & 0xffu;
-          const f32x4 x0 = ld4(hcur + src * kHS + 4 * q);
-          const f32x4 x1 = ld4(hcur + src * kHS + 16 + 4 * q);
+          const int bid = ent & 0xffu;
+          const int soff = (int)(__builtin_amdgcn_ubfe(ent, src_shift, 12) * 4u) + src_base;
+          const f32x4 x0 = ld4(smem + soff);
+          const f32x4 x1 = ld4(smem + soff + 16);
           f32x4 c0 = ld4(tbl + bid * kKMax);
           f32x4 c1 = ld4(tbl + bid * kKMax + 4);
           if (deg <= 0) {
@@ -304,9 +323,10 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
         for (int d = 1; d < maxdeg; ++d) {
           if (d < deg) {
             const uint32_t ent = r_ent[p0 + d];
-            const int src = ent & 0xffu, bid = (ent >> 8) & 0xffu;
-            const f32x4 x0 = ld4(hcur + src * kHS + 4 * q);
-            const f32x4 x1 = ld4(hcur + src * kHS + 16 + 4 * q);
+            const int bid = ent & 0xffu;
+            const int soff = (int)(__builtin_amdgcn_ubfe(ent, src_shift, 12) * 4u) + src_base;
+            const f32x4 x0 = ld4(smem + soff);
+            const f32x4 x1 = ld4(smem + soff + 16);
             const f32x4 c0 = ld4(tbl + bid * kKMax);
             const f32x4 c1 = ld4(tbl + bid * kKMax + 4);
   #pragma unroll
@@ -322,12 +342,19 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
         }
         if (tstamp && lane == 0) stamp[9] = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_setprio(2);
-        // The image of this step was stored after the previous step's barrier, without a barrier of its own:
-        // the gather above needs no weights, so those LDS stores ran under it.  From here on they are needed.
+        // Mid-step barrier.  (1) h is updated in place: all gathers are done before anybody writes.  (2) The image
+        // of this step was stored after the previous step's barrier, without a barrier of its own: the gather
+        // above needs no weights, so those LDS stores ran under it.  From here on they are needed.
         // (Waves without a tile meet this barrier in the else branch below: whole waves take either path.)
-        if (s > 0) lds_barrier();
-        const f32x4 h0 = ld4(hcur + row * kHS + 4 * q);  // the row's own state
-        const f32x4 h1 = ld4(hcur + row * kHS + 16 + 4 * q);
+        if (!g0) lds_barrier();  // (step 0 from the atom table: nobody reads the buffer, the image is in place)
+        int own = row;            // the row's own state
+        if (g0) {
+          const int id = r_rowatom[row];
+          own = (unsigned)id < (unsigned)p.Va ? id : p.Va;
+        }
+        own = own * kHS + src_base;
+        const f32x4 h0 = ld4(smem + own);
+        const f32x4 h1 = ld4(smem + own + 16);
 
         // ---- agg^T = sum_k W_k * G_k   (models/layers.py:108-112 + 78-82, reassociated)
         f32x4 agg0 = {0.f, 0.f, 0.f, 0.f}, agg1 = {0.f, 0.f, 0.f, 0.f};
@@ -464,7 +491,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
 
       }
       if (!pf_issued) {  // waves without a tile in this chunk still carry their share of the image
-        if (s > 0) lds_barrier();
+        if (!g0) lds_barrier();
 #pragma unroll
         for (int i = 0; i < kPf; ++i) pf[i] = ld4(nxt + 4 * (tid + i * kThreads));
       }
@@ -485,7 +512,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
     // ---- GlobalSumPool (models/layers.py:161-164): rows whose atom id > 0.  Eight lanes share one
     //      (molecule, 4 features): each sums every 8th row in ascending order, then a fixed 3-step
     //      butterfly on the DPP network - a wavefront segmented reduction with a run-to-run fixed order.
-    const float* hfin = (p.S & 1) ? hbuf1 : hbuf0;
+    const float* hfin = hbuf;
     float* out_g = p.pooled[g];
     for (int t0 = 0; t0 < M * 64; t0 += kThreads) {
       const int t = t0 + tid;
@@ -619,7 +646,7 @@ int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
   pp.nsub = reinterpret_cast<int32_t*>(base + w.nsub_off);
   pp.desc = reinterpret_cast<int32_t*>(base + w.desc_off);
   pp.rec = reinterpret_cast<unsigned char*>(base + w.rec_off);
-  pp.n_ions = a.n_ions; pp.B = a.B; pp.N = a.N; pp.E = a.E; pp.Vb = a.Vb;
+  pp.n_ions = a.n_ions; pp.B = a.B; pp.N = a.N; pp.E = a.E; pp.Va = a.Va; pp.Vb = a.Vb;
   pp.nwg = w.nwg;
   pp.max_sub = w.max_sub;
   pp.nblk = w.nblk;
@@ -655,7 +682,10 @@ int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
     attr_set[variant] = true;
   }
   profile_record_start(s);
-  const size_t lds = kLdsFixedBytes + align_up((size_t)a.Vb * kKMax * sizeof(float), 512);
+  size_t lds = kLdsFixedBytes + align_up((size_t)a.Vb * kKMax * sizeof(float), 512);
+  const size_t atab_bytes = ((size_t)a.Va + 1) * kHS * sizeof(float);
+  ep.atab_lds = a.Va <= kEntMaxAtom && lds + atab_bytes <= 156 * 1024;
+  if (ep.atab_lds) lds += atab_bytes;
   kern<<<w.nwg, kThreads, lds, s>>>(ep);
   profile_record_stop(s);
   return check_launch("encoder_fused");

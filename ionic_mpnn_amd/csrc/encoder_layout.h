@@ -56,6 +56,7 @@ constexpr int kRecMoloff = 544;    // u16[kRCap + 2]: first logical row of every
 constexpr int kRecMolrows = 1072;  // u16[kRCap]    : kept rows r_b of every molecule
 constexpr int kRecPoolrow = 1584;  // u16[kRCap]    : logical row -> placed row, | 0x8000 if atom id > 0 (pooled)
 constexpr int kRecRowatom = 2096;  // i32[kRCap]    : atom id of the PLACED row, -1 for a slack row
+constexpr int kEntMaxAtom = 454;   // 12-bit field of atom id * kHS/4 in an in-edge entry (atom table in LDS)
 constexpr int kRecEnt = 3136;      // u32[kECap]    : in-edge lists in edge-slot order: slot<<16 | bond id<<8 | placed src row
 constexpr int kRecBytes = 8192;
 static_assert(kRecEnt + 4 * kECap <= kRecBytes && kRecEnt % 16 == 0, "record layout");
@@ -123,7 +124,7 @@ struct PlanParams {
   int32_t* nsub;      // [nwg]           chunks of every encoder workgroup
   int32_t* desc;      // [nwg][max_sub][4]
   unsigned char* rec; // [nwg][max_sub][kRecBytes]
-  int n_ions, B, N, E, Vb, nwg, max_sub, nblk;
+  int n_ions, B, N, E, Va, Vb, nwg, max_sub, nblk;
   unsigned long long* stamps;  // diagnostics only: 16 words written by plan_chunks workgroup 0
 };
 
@@ -144,6 +145,7 @@ struct EncParams {
   const int32_t* desc;
   const unsigned char* rec;
   int n_ions, B, N, K, S, Va, Vb, max_sub;
+  int atab_lds;  // atom table copied to LDS (Va*32 floats after the bond table copy); 0: read from HBM/L2
   float ln_eps;
   unsigned long long* stamps;  // diagnostics only (impnn_debug_set_stamp_buffer): 32 words per workgroup
 };

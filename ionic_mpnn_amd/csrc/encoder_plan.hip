@@ -294,6 +294,7 @@ constexpr int kShareCap = kECap;  // molecules of one share resolved in LDS (ali
 __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
   __shared__ int32_t moloff[kRCap + 2], molrows[kRCap], cnt[kRCap], place[kRCap], cursor[kRCap], rowptr[kRCap + 2];
   __shared__ int32_t bins[48], tilemax[16], scratch[8];
+  __shared__ uint16_t atomof[kRCap];  // placed row -> atom id clamped to [0, Va] (Va = the zero row)
   __shared__ uint32_t ent2[kECap + 1];
   int32_t* const shst = reinterpret_cast<int32_t*>(ent2);  // virtual-row prefix of the share's molecules (+ end),
                                                            // dead before ent2 is filled (moloff keeps what is needed)
@@ -484,6 +485,7 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
   cursor[pos] = my_deg;  // in-degree per placed row (scanned below)
   if (my_deg > 0) atomicMax(&tilemax[pos >> 4], my_deg > 255 ? 255 : my_deg);
   r_rowatom[pos] = my_real ? my_id : -1;  // out-of-range ids (incl. negative) read as a zero row in the encoder
+  atomof[pos] = (uint16_t)((my_real && (unsigned)my_id < (unsigned)p.Va) ? my_id : p.Va);
   r_poolrow[tid] = (uint16_t)(pos | ((my_real && my_id > 0) ? 0x8000 : 0));
   lds_barrier();
   CSTAMP(6);
@@ -551,7 +553,13 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
       const uint32_t v = ent2[i];
       int rank = 0;
       for (int jx = b0; jx < b1; ++jx) rank += ent2[jx] < v;
-      r_ent[b0 + rank] = v;
+      // the edge slot has done its job (order); the encoder gets the source row's atom id in its place, so that
+      // step 0 can read h0 = atom_table[id] directly (no h0 fill in the chunk prologue)
+      // entry for the encoder: [31:20] atom id of the source * kHS/4, [19:8] placed source row * kHS/4 (both
+      // are float4 offsets into the atom table / the h buffer), [7:0] bond id
+      const uint32_t srow = v & 0xffu, bid = (v >> 8) & 0xffu;
+      const uint32_t aid = atomof[srow] < kEntMaxAtom ? atomof[srow] : kEntMaxAtom;
+      r_ent[b0 + rank] = ((aid * (kHS / 4)) << 20) | ((srow * (kHS / 4)) << 8) | bid;
     }
   }
   CSTAMP(15);

@@ -267,7 +267,8 @@ class MPNNModel:
             self._pipeline = ops.EncoderPipeline(self.device)
         ions = [(inputs["cat_atom"], inputs["cat_bond"], inputs["cat_connectivity"]),
                 (inputs["an_atom"], inputs["an_bond"], inputs["an_connectivity"])]
-        return self._pipeline.plan(ions, self.atom_dim, self.bond_dim, self.num_steps, self.bond_vocab_size)
+        return self._pipeline.plan(ions, self.atom_dim, self.bond_dim, self.num_steps, self.atom_vocab_size,
+                                   self.bond_vocab_size)
 
     def encode_pooled(self, inputs, fused=None, trace=None, plan=None):
         """Both ions' GlobalSumPool outputs: the hot path."""

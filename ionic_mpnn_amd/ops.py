@@ -402,7 +402,7 @@ class EncoderPipeline:
         self.slots = [{"ws": None, "done": None} for _ in range(depth)]
         self.next = 0
 
-    def plan(self, ions, D, K, S, Vb):
+    def plan(self, ions, D, K, S, Va, Vb):
         n = len(ions)
         prep = []
         for (a, b, c) in ions:
@@ -428,7 +428,7 @@ class EncoderPipeline:
             self.side.wait_event(slot["done"])  # the encoder that last read this workspace
         with torch.cuda.device(self.device), torch.cuda.stream(self.side):
             check(lib.impnn_encoder_plan(n, mk([p[0] for p in prep]), mk([p[1] for p in prep]), mk([p[2] for p in prep]),
-                                         B, N, E, D, K, S, Vb, ptr(slot["ws"]), slot["ws"].numel(),
+                                         B, N, E, D, K, S, Va, Vb, ptr(slot["ws"]), slot["ws"].numel(),
                                          C.c_void_p(self.side.cuda_stream)))
             ready = torch.cuda.Event()
             ready.record(self.side)
