@@ -299,7 +299,8 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
         const int maxdeg = __builtin_amdgcn_readfirstlane(r_tilemax[tile]);
         {
           // first in-edge initialises G (rows without in-edges use a zero coefficient vector)
-          const uint32_t ent = r_ent[deg > 0 ? p0 : 0];
+          // (a row without in-edges must still read FINITE h values: 0 * NaN would poison G; entry 0 -> row 0)
+          const uint32_t ent = deg > 0 ? r_ent[p0] : 0u;
           const int bid = ent & 0xffu;
           const int soff = (int)(__builtin_amdgcn_ubfe(ent, src_shift, 12) * 4u) + src_base;
           const f32x4 x0 = ld4(smem + soff);

@@ -289,3 +289,20 @@ def test_config1_dataset_plumbing_batch32():
     assert_close(m(x, fused=True).cpu().numpy(), ref, what="log_eta fused")
     assert_close(m(x, fused=False).cpu().numpy(), ref, what="log_eta layered")
     assert_close(m.predict(x, batch_size=32), ref, what="predict")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_rows_without_in_edges_never_read_stale_workspace(mode):
+    """A chunk whose rows have no in-edge leaves the record's entry area unwritten; the gather of such rows must not
+    depend on it (0 * NaN).  The workspace is poisoned with NaN bit patterns first."""
+    Va, Vb = 30, 11
+    inp = synthetic.make_batch(9, max_atoms=1, max_edges=0, atom_vocab_size=Va, bond_vocab_size=Vb, min_atoms=1, seed=7)
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=32, bond_dim=8, num_steps=2, seed=107, perturb=True)
+    m = make_model(w, Va, Vb, K=8, mode=mode)
+    from ionic_mpnn_amd import ops
+    ws = ops._workspace(torch.device(DEV), 64 << 20)
+    ws.view(torch.int32).fill_(0x7FC00000 | 0x3FF)      # quiet NaNs everywhere, offsets fields all ones
+    pc, pa = m.encode_pooled(to_dev(inp), fused=True)
+    rc = O.encode(w, "cat", inp["cat_atom"], inp["cat_bond"], inp["cat_connectivity"], pooled_only=True)
+    assert torch.isfinite(pc).all() and torch.isfinite(pa).all()
+    assert_close(pc.cpu().numpy(), rc, what="cat pooled")
