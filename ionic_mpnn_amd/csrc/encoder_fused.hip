@@ -258,8 +258,6 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
       // One h buffer: every wave gathers (reads other rows) BEFORE the mid-step barrier and writes its own rows
       // AFTER it, and the end-of-step barrier orders those writes before the next step's gathers.  Rows that are
       // skipped (no tile work) simply keep their value.
-      const float* hcur = hbuf;
-      float* hnext = hbuf;
       const bool g0 = p.atab_lds && s == 0;             // step 0 gathers from the atom table
       // in-edge entries carry ready float4 offsets: [31:20] into the atom table, [19:8] into the h buffer
       const int src_shift = g0 ? 20 : 8;
@@ -285,7 +283,6 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
       const bool has_tile = my_tile >= 0 && my_tile < ntiles;
       const int tile = has_tile ? my_tile : 0;
       const int row = tile * 16 + a;
-      const bool tstamp = false;
       float G[kKMax][8];
       if (has_tile) {
         // A wave's issue priority falls as it advances through its tile (gather 3, message 2, gates 1, rest 0): the SIMD
@@ -341,7 +338,6 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
             }
           }
         }
-        if (tstamp && lane == 0) stamp[9] = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_setprio(2);
         // Mid-step barrier.  (1) h is updated in place: all gathers are done before anybody writes.  (2) The image
         // of this step was stored after the previous step's barrier, without a barrier of its own: the gather
@@ -388,7 +384,6 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
             }
           }
         }
-        if (tstamp && lane == 0) stamp[10] = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_setprio(1);
         // next step's weight image starts its flight now (G is dead: registers are free)
         if (!pf_issued) {
@@ -415,7 +410,6 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
           mma3(z1, hupd + ((0 * 2 + 1) * 2 + 1) * 1024, lane, sa);
           mma3(r0, hupd + ((1 * 2 + 0) * 2 + 1) * 1024, lane, sa);
           mma3(r1, hupd + ((1 * 2 + 1) * 2 + 1) * 1024, lane, sa);
-          if (tstamp && lane == 0) stamp[11] = __builtin_amdgcn_s_memtime();
           z0 = sigmoid4<true>(z0);  // accumulators carry kAcc: folded into the exp2 constant
           z1 = sigmoid4<true>(z1);
           const f32x4 rs0 = sigmoid4<true>(r0) * hs0, rs1 = sigmoid4<true>(r1) * hs1;  // :149, times kSX
@@ -444,7 +438,6 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
               }
             }
           }
-          if (tstamp && lane == 0) stamp[11] = __builtin_amdgcn_s_memtime();
           z0 = sigmoid4<false>(z0);
           z1 = sigmoid4<false>(z1);
           rh0 = sigmoid4<false>(r0) * h0;  // :149
@@ -465,7 +458,6 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
             }
           }
         }
-        if (tstamp && lane == 0) stamp[12] = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_setprio(0);
         // ---- blend, LayerNorm, residual  (models/layers.py:153-155)
         // (1-z) h + z t == h + z (t - h); vector arithmetic throughout (packed f32 instructions)
@@ -487,8 +479,8 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
         const f32x4 b0 = ld4(wvec + 4 * kD + 4 * q), b1 = ld4(wvec + 4 * kD + 16 + 4 * q);
         const f32x4 o0 = n0 * (g0 * inv) + (b0 + h0);
         const f32x4 o1 = n1 * (g1 * inv) + (b1 + h1);
-        st4(hnext + row * kHS + 4 * q, o0);
-        st4(hnext + row * kHS + 16 + 4 * q, o1);
+        st4(hbuf + row * kHS + 4 * q, o0);
+        st4(hbuf + row * kHS + 16 + 4 * q, o1);
 
       }
       if (!pf_issued) {  // waves without a tile in this chunk still carry their share of the image
@@ -643,11 +635,11 @@ int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
   pp.rows = reinterpret_cast<int32_t*>(base + w.rows_off);
   pp.vr = reinterpret_cast<int32_t*>(base + w.vr_off);
   pp.partial = reinterpret_cast<int32_t*>(base + w.partial_off);
-  pp.share = reinterpret_cast<int32_t*>(base + w.share_off);
   pp.nsub = reinterpret_cast<int32_t*>(base + w.nsub_off);
   pp.desc = reinterpret_cast<int32_t*>(base + w.desc_off);
   pp.rec = reinterpret_cast<unsigned char*>(base + w.rec_off);
   pp.n_ions = a.n_ions; pp.B = a.B; pp.N = a.N; pp.E = a.E; pp.Va = a.Va; pp.Vb = a.Vb;
+  pp.grid_sub = w.max_sub < 6 ? w.max_sub : 6;  // 6 x 256 workgroups of 256 threads are resident at once on 256 CUs
   pp.nwg = w.nwg;
   pp.max_sub = w.max_sub;
   pp.nblk = w.nblk;

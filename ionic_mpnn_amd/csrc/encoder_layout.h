@@ -62,8 +62,6 @@ constexpr int kRecBytes = 8192;
 static_assert(kRecEnt + 4 * kECap <= kRecBytes && kRecEnt % 16 == 0, "record layout");
 
 // chunk descriptor (int4): {first molecule, molecules, 0, rows | ion << 16}
-// share (int4), one per persistent encoder workgroup: {ion | first 16-molecule block << 1,
-//   virtual-row prefix at that block, first virtual row of the share, one past its last virtual row}
 constexpr int kPB = 16;  // molecules per plan_stats workgroup (= partial-sum granularity)
 
 // ---- workspace layout (bytes, all 256-aligned sections)
@@ -120,11 +118,11 @@ struct PlanParams {
   int32_t* rows;      // [n_ions][B]     kept rows r_b
   int32_t* vr;        // [n_ions][B]     virtual rows max(1, r_b, ceil(v_b/4))
   int32_t* partial;   // [n_ions][nblk]  sum of vr over 16 molecules
-  int32_t* share;     // [nwg][4]
   int32_t* nsub;      // [nwg]           chunks of every encoder workgroup
   int32_t* desc;      // [nwg][max_sub][4]
   unsigned char* rec; // [nwg][max_sub][kRecBytes]
   int n_ions, B, N, E, Va, Vb, nwg, max_sub, nblk;
+  int grid_sub;  // plan_chunks workgroups launched per share (<= max_sub)
   unsigned long long* stamps;  // diagnostics only: 16 words written by plan_chunks workgroup 0
 };
 

@@ -289,20 +289,24 @@ __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int la
 // plan_chunks: 256 threads (= kRCap: one per row) per chunk.
 // -----------------------------------------------------------------------------------------
 constexpr int kDegBins = 18;    // in-degree 0..15, ">= 16", and "row beyond the chunk" (placed last)
-constexpr int kShareCap = kECap;  // molecules of one share resolved in LDS (aliases the entry buffer)
+constexpr int kShareCap = kECap;  // molecules of one share resolved in LDS
+constexpr int kMaxHops = 128;     // chunks of one share (launch_plan checks max_sub against it)
 
 __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
   __shared__ int32_t moloff[kRCap + 2], molrows[kRCap], cnt[kRCap], place[kRCap], cursor[kRCap], rowptr[kRCap + 2];
   __shared__ int32_t bins[48], tilemax[16], scratch[8];
   __shared__ uint16_t atomof[kRCap];  // placed row -> atom id clamped to [0, Va] (Va = the zero row)
   __shared__ uint32_t ent2[kECap + 1];
-  int32_t* const shst = reinterpret_cast<int32_t*>(ent2);  // virtual-row prefix of the share's molecules (+ end),
-                                                           // dead before ent2 is filled (moloff keeps what is needed)
-  __shared__ int chunk_s[5];              // first molecule, molecules, rows, share-local first molecule, ion
+  __shared__ int32_t shst[kShareCap + 1];  // virtual-row prefix of the share's molecules (+ end)
+  __shared__ int32_t cb[kMaxHops + 1];     // next-fit chain: share-local first molecule of every chunk (+ end)
+  __shared__ int chunk_s[3];               // first molecule of the share, chunks of the share, ion
   __builtin_amdgcn_s_setprio(3);
 #define CSTAMP(i) do { if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
   CSTAMP(0);
-  const int j = blockIdx.x / p.max_sub, slot_i = blockIdx.x - j * p.max_sub;
+  // grid = nwg x grid_sub: workgroup (j, slot_i) builds chunks slot_i, slot_i + grid_sub, ... of share j.  grid_sub
+  // covers the usual chunk count, so that every workgroup is resident at once (slots beyond a share's chunks only
+  // resolve and leave); shares with more chunks take another turn of the loop below.
+  const int j = blockIdx.x / p.grid_sub, slot_i = blockIdx.x - j * p.grid_sub;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // ---- resolve the share: molecules whose first virtual row lies in [t_lo, t_hi), their prefix, and
   //      the next-fit chain of chunks; wave 0 does it, everybody else waits at the barrier.
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
     const bool have = resolve_share(p, j, lane, g, k0, bp0, t_lo, t_hi);
     if (!have) {
       if (lane == 0) {
-        chunk_s[0] = -1; chunk_s[1] = 0; chunk_s[2] = 0; chunk_s[3] = 0; chunk_s[4] = 0;
+        chunk_s[0] = -1; chunk_s[1] = 0; chunk_s[2] = 0;
         if (slot_i == 0) p.nsub[j] = 0;
       }
     } else {
@@ -346,8 +350,8 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
     nsh = nsh < kShareCap ? nsh : kShareCap;  // a share holds ~B/nwg molecules; launch_plan checks the cap
     if (lane == 0) shst[nsh] = end_row;
     __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): sst is read back by this wave below
-    int mb = 0, hop = 0, my_mb = -1, my_e = -1;
-    while (mb < nsh) {  // next-fit: chunk [mb, e), e = largest index with shst[e] - shst[mb] <= 256
+    int mb = 0, hop = 0;
+    while (mb < nsh && hop < kMaxHops) {  // next-fit: chunk [mb, e), e = largest index with shst[e] - shst[mb] <= 256
       const int lim = shst[mb] + kRCap;
       int e = mb + 1;
       for (int c0 = mb + 1; c0 <= nsh; c0 += 64) {
@@ -358,29 +362,26 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
         e = c0 + 63 - __builtin_clzll(okb);
         if (okb != ~0ull) break;
       }
-      if (hop == slot_i) {
-        my_mb = mb;
-        my_e = e;
-      }
+      if (lane == 0) cb[hop] = mb;
       ++hop;
       mb = e;
-      if (slot_i != 0 && my_mb >= 0) break;  // only slot 0 needs the total count
     }
     if (lane == 0) {
-      chunk_s[0] = my_mb >= 0 ? first + my_mb : -1;
-      chunk_s[1] = my_mb >= 0 ? my_e - my_mb : 0;
-      chunk_s[2] = my_mb >= 0 ? shst[my_e] - shst[my_mb] : 0;
-      chunk_s[3] = my_mb;
-      chunk_s[4] = g;
+      cb[hop] = nsh;
+      chunk_s[0] = first;
+      chunk_s[1] = hop;
+      chunk_s[2] = g;
       if (slot_i == 0) p.nsub[j] = hop;
     }
     }
   }
   lds_barrier();
   CSTAMP(1);
-  const int m0 = chunk_s[0], M = chunk_s[1], R = chunk_s[2], mb_local = chunk_s[3], g = chunk_s[4];
-  if (M <= 0) return;
-  const int idx = blockIdx.x;
+  const int first_mol = chunk_s[0], nhop = chunk_s[1], g = chunk_s[2];
+  for (int sl = slot_i; sl < nhop; sl += p.grid_sub) {
+  const int mb_local = cb[sl], M = cb[sl + 1] - mb_local, m0 = first_mol + mb_local;
+  const int R = shst[mb_local + M] - shst[mb_local];
+  const int idx = j * p.max_sub + sl;
   if (tid == 0) reinterpret_cast<int4*>(p.desc)[idx] = make_int4(m0, M, 0, R | (g << 16));
   const int N = p.N, E = p.E;
   const int32_t* ids_g = p.atom_ids[g];
@@ -563,6 +564,8 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
     }
   }
   CSTAMP(15);
+  lds_barrier();  // the LDS tables are rebuilt by the next chunk of this workgroup (rare: see above)
+  }
 #undef CSTAMP
 }
 
@@ -579,7 +582,9 @@ int launch_plan(const PlanParams& pp, hipStream_t s) {
   if (int rc = check_launch("plan_stats")) return rc;
   if ((int64_t)2 * pp.n_ions * pp.B / pp.nwg + 64 > kShareCap)
     return fail(IMPNN_E_UNSUPPORTED, "encoder plan: batch of %d molecules per ion is too large", pp.B);
-  plan_chunks_kernel<<<pp.nwg * pp.max_sub, kRCap, 0, s>>>(pp);
+  if (pp.max_sub > kMaxHops)
+    return fail(IMPNN_E_UNSUPPORTED, "encoder plan: %d chunk slots per workgroup", pp.max_sub);
+  plan_chunks_kernel<<<pp.nwg * pp.grid_sub, kRCap, 0, s>>>(pp);
   return check_launch("plan_chunks");
 }
 
