@@ -306,3 +306,19 @@ def test_rows_without_in_edges_never_read_stale_workspace(mode):
     rc = O.encode(w, "cat", inp["cat_atom"], inp["cat_bond"], inp["cat_connectivity"], pooled_only=True)
     assert torch.isfinite(pc).all() and torch.isfinite(pa).all()
     assert_close(pc.cpu().numpy(), rc, what="cat pooled")
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("Va,S", [(600, 3), (455, 1), (454, 2), (600, 0)])
+def test_large_atom_vocabularies_take_the_global_table_path(Va, S, mode):
+    """Up to 454 atom types the embedding table is copied to LDS and step 0 gathers from it; above that the chunk
+    prologue fills h0 from HBM and step 0 gathers from the h buffer (with the mid-step barrier).  Both must match."""
+    Vb = 9
+    inp = synthetic.make_batch(70, max_atoms=30, max_edges=50, atom_vocab_size=Va, bond_vocab_size=Vb, min_atoms=4, seed=Va + S)
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=32, bond_dim=8, num_steps=S, seed=Va, perturb=True)
+    m = make_model(w, Va, Vb, K=8, mode=mode)
+    pc, pa = m.encode_pooled(to_dev(inp), fused=True)
+    rc = O.encode(w, "cat", inp["cat_atom"], inp["cat_bond"], inp["cat_connectivity"], pooled_only=True)
+    ra = O.encode(w, "an", inp["an_atom"], inp["an_bond"], inp["an_connectivity"], pooled_only=True)
+    assert_close(pc.cpu().numpy(), rc, what="cat pooled")
+    assert_close(pa.cpu().numpy(), ra, what="an pooled")
