@@ -219,7 +219,10 @@ int impnn_batch_assemble(int32_t n_ions, const int32_t* sample_idx, int32_t B, i
  *      Wz 2D*D | bz D | Wr | br | Wh | bh | gamma | beta  (impnn_gated_update_param_floats(D) floats, overwritten);
  *      intermediates are recomputed from (h, agg); the kernel gradients are split-K GEMMs over row chunks and
  *      all parameter sums go through partials in `workspace` (impnn_gated_update_bwd_workspace_floats) that
- *      are added in a fixed order: bitwise reproducible.  atom_dim must divide 256. */
+ *      are added in a fixed order: bitwise reproducible.  atom_dim must divide 256.
+ *  `accumulate` != 0 (GatedUpdate dparams; dW and dbond_table of impnn_bond_type_matrices_bwd with K < 64): the
+ *      results are ADDED to the output buffers - the caller points them at the optimizer's gradient buffer and
+ *      saves one add per parameter tensor. */
 int impnn_embed_gather_bwd(const int32_t* ids, const float* dout, float* dtable, int64_t rows, int32_t vocab,
                            int32_t dim, impnn_stream_t stream);
 int impnn_reduce_scatter_bwd(const float* dagg, const int32_t* tgt, int32_t tgt_stride, float* dmessages, int32_t B,
@@ -232,13 +235,15 @@ int impnn_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const i
                                 void* workspace, int64_t workspace_bytes, int32_t B, int32_t N, int32_t E, int32_t D,
                                 int32_t Vb, impnn_stream_t stream);
 int impnn_bond_type_matrices_bwd(const float* bond_table, const float* W, const float* dtype_mats, float* dW,
-                                 float* dbond_table, int32_t Vb, int32_t K, int32_t D, impnn_stream_t stream);
+                                 float* dbond_table, int32_t Vb, int32_t K, int32_t D, int32_t accumulate,
+                                 impnn_stream_t stream);
 int64_t impnn_gated_update_param_floats(int32_t D);
 int64_t impnn_gated_update_bwd_workspace_floats(int64_t rows, int32_t D);
 int impnn_gated_update_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
                            const float* br, const float* Wh, const float* bh, const float* gamma, float ln_eps,
                            const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
-                           int64_t workspace_floats, int64_t rows, int32_t D, impnn_stream_t stream);
+                           int64_t workspace_floats, int64_t rows, int32_t D, int32_t accumulate,
+                           impnn_stream_t stream);
 
 /*  Optimizer step, one launch for all variables (train_viscosity.py:227-230):
  *      g <- g * clipnorm / max(||g||_2, clipnorm)      per variable (tf.clip_by_norm); clipnorm <= 0: off

@@ -10,6 +10,16 @@ from . import _lib, ops
 from ._lib import check, f32c, i32c, ptr, stream_ptr
 
 
+def _sink(param):
+    """The existing gradient buffer of a leaf parameter, when a backward kernel may add into it directly
+    (float32, contiguous, same device): ionic_mpnn_amd.train.Adam keeps every .grad as a view of one flat buffer.
+    Returning None for that input afterwards tells autograd there is nothing left to accumulate."""
+    g = getattr(param, "grad", None)
+    if g is None or not param.is_leaf or g.dtype != torch.float32 or not g.is_contiguous() or g.device != param.device:
+        return None
+    return g
+
+
 def _lib_call(device, fn, *args):
     with torch.cuda.device(device):
         check(fn(*args, stream_ptr()))
@@ -21,18 +31,18 @@ class EmbedGather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, ids, table):
         ids = i32c(ids)
-        ctx.save_for_backward(ids)
-        ctx.table_shape = tuple(table.shape)
+        ctx.save_for_backward(ids, table)
         return ops.embed_gather(ids, table)
 
     @staticmethod
     def backward(ctx, dout):
-        (ids,) = ctx.saved_tensors
-        V, dim = ctx.table_shape
-        dtable = torch.zeros(V, dim, dtype=torch.float32, device=dout.device)
+        ids, table = ctx.saved_tensors
+        V, dim = table.shape
+        sink = _sink(table)  # the kernel accumulates (atomics): add straight into the gradient buffer
+        dtable = sink if sink is not None else torch.zeros(V, dim, dtype=torch.float32, device=dout.device)
         dout = f32c(dout)
         _lib_call(dout.device, _lib.load().impnn_embed_gather_bwd, ptr(ids), ptr(dout), ptr(dtable), ids.numel(), V, dim)
-        return None, dtable
+        return None, (None if sink is not None else dtable)
 
 
 class BondTypeMatrices(torch.autograd.Function):
@@ -50,9 +60,14 @@ class BondTypeMatrices(torch.autograd.Function):
         Vb, K = bond_table.shape
         D = W.shape[-1]
         dmats = f32c(dmats)
+        sw, st = _sink(W), _sink(bond_table)
+        if sw is not None and st is not None and K < 64:
+            _lib_call(W.device, _lib.load().impnn_bond_type_matrices_bwd, ptr(bond_table), ptr(W), ptr(dmats), ptr(sw),
+                      ptr(st), Vb, K, D, 1)
+            return None, None
         dW, dtb = torch.empty_like(W), torch.empty_like(bond_table)
         _lib_call(W.device, _lib.load().impnn_bond_type_matrices_bwd, ptr(bond_table), ptr(W), ptr(dmats), ptr(dW),
-                  ptr(dtb), Vb, K, D)
+                  ptr(dtb), Vb, K, D, 0)
         return dtb, dW
 
 
@@ -107,13 +122,13 @@ class GatedUpdate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps):
         ts = [f32c(t) for t in (h, agg, Wz, bz, Wr, br, Wh, bh, gamma)]
-        ctx.save_for_backward(*ts)
+        ctx.save_for_backward(*ts, beta)
         ctx.eps = float(eps)
         return ops.gated_update(*ts, beta, eps)
 
     @staticmethod
     def backward(ctx, dout):
-        h, agg, Wz, bz, Wr, br, Wh, bh, gamma = ctx.saved_tensors
+        h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta = ctx.saved_tensors
         D = h.shape[-1]
         rows = h.numel() // D
         lib = _lib.load()
@@ -121,10 +136,25 @@ class GatedUpdate(torch.autograd.Function):
         dh, dagg = torch.empty_like(h), torch.empty_like(agg)
         P = int(lib.impnn_gated_update_param_floats(D))
         wsn = int(lib.impnn_gated_update_bwd_workspace_floats(rows, D))
-        dparams = torch.empty(P, dtype=torch.float32, device=h.device)
         ws = torch.empty(max(wsn, 1), dtype=torch.float32, device=h.device)
+        # the eight parameter gradients leave the kernel as one block in the canonical order; when the existing
+        # .grad buffers form exactly that block (train.Adam's flat buffer does), the kernel adds into it directly
+        params = (Wz, bz, Wr, br, Wh, bh, gamma, beta)
+        sinks = [_sink(t) for t in params]
+        direct = all(g is not None for g in sinks)
+        if direct:
+            base, off = sinks[0].data_ptr(), 0
+            for t, g in zip(params, sinks):
+                direct = direct and g.data_ptr() == base + 4 * off and g.numel() == t.numel()
+                off += t.numel()
+        if direct:
+            _lib_call(h.device, lib.impnn_gated_update_bwd, ptr(h), ptr(agg), ptr(Wz), ptr(bz), ptr(Wr), ptr(br),
+                      ptr(Wh), ptr(bh), ptr(gamma), ctx.eps, ptr(dout), ptr(dh), ptr(dagg), ptr(sinks[0]), ptr(ws), wsn,
+                      rows, D, 1)
+            return (dh, dagg, *([None] * 8), None)
+        dparams = torch.empty(P, dtype=torch.float32, device=h.device)
         _lib_call(h.device, lib.impnn_gated_update_bwd, ptr(h), ptr(agg), ptr(Wz), ptr(bz), ptr(Wr), ptr(br), ptr(Wh),
-                  ptr(bh), ptr(gamma), ctx.eps, ptr(dout), ptr(dh), ptr(dagg), ptr(dparams), ptr(ws), wsn, rows, D)
+                  ptr(bh), ptr(gamma), ctx.eps, ptr(dout), ptr(dh), ptr(dagg), ptr(dparams), ptr(ws), wsn, rows, D, 0)
         n_w, o = 2 * D * D, 0
         grads = []
         for _ in range(3):

@@ -375,10 +375,12 @@ int impnn_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const i
 }
 
 int impnn_bond_type_matrices_bwd(const float* bond_table, const float* W, const float* dtype_mats, float* dW,
-                                 float* dbond_table, int32_t Vb, int32_t K, int32_t D, impnn_stream_t stream) {
+                                 float* dbond_table, int32_t Vb, int32_t K, int32_t D, int32_t accumulate,
+                                 impnn_stream_t stream) {
   REQUIRE(Vb > 0 && K > 0 && D > 0, "bad shape");
   REQUIRE(bond_table && W && dtype_mats && dW && dbond_table, "null pointer");
-  return launch_bond_type_matrices_bwd(bond_table, W, dtype_mats, dW, dbond_table, Vb, K, D, as_stream(stream));
+  return launch_bond_type_matrices_bwd(bond_table, W, dtype_mats, dW, dbond_table, Vb, K, D, accumulate != 0,
+                                       as_stream(stream));
 }
 
 int64_t impnn_gated_update_param_floats(int32_t D) { return D > 0 ? gated_update_param_floats(D) : 0; }
@@ -391,14 +393,15 @@ int64_t impnn_gated_update_bwd_workspace_floats(int64_t rows, int32_t D) {
 int impnn_gated_update_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
                            const float* br, const float* Wh, const float* bh, const float* gamma, float ln_eps,
                            const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
-                           int64_t workspace_floats, int64_t rows, int32_t D, impnn_stream_t stream) {
+                           int64_t workspace_floats, int64_t rows, int32_t D, int32_t accumulate,
+                           impnn_stream_t stream) {
   REQUIRE(rows >= 0 && D > 0 && D <= 256 && 256 % D == 0, "atom_dim must divide 256");
   REQUIRE(h && agg && Wz && bz && Wr && br && Wh && bh && gamma && dout && dh && dagg && dparams && workspace,
           "null pointer");
   if (workspace_floats < impnn_gated_update_bwd_workspace_floats(rows, D))
     return fail(IMPNN_E_WORKSPACE, "gated_update_bwd: workspace of %lld floats is too small", (long long)workspace_floats);
   return launch_gated_update_bwd(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, ln_eps, dout, dh, dagg, dparams, workspace,
-                                 rows, D, as_stream(stream));
+                                 rows, D, accumulate != 0, as_stream(stream));
 }
 
 int impnn_adam_clipnorm_step(const void* var_table, const int64_t* sizes, int32_t n_vars, int64_t step, float lr,

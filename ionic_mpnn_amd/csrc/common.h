@@ -63,14 +63,14 @@ int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const 
 int launch_strided_gemm(const float* A, const float* B, float* out, int64_t rows, int M, int N, int64_t a_rs,
                         int64_t a_cs, int64_t b_rs, int64_t b_cs, hipStream_t s);
 int launch_bond_type_matrices_bwd(const float* tb, const float* W, const float* dA, float* dW, float* dtb, int Vb,
-                                  int K, int D, hipStream_t s);
+                                  int K, int D, int accumulate, hipStream_t s);
 int gated_update_bwd_blocks(int64_t rows, int D);
 int64_t gated_update_param_floats(int D);
 int64_t gated_update_bwd_workspace(int64_t rows, int D);
 int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
                             const float* br, const float* Wh, const float* bh, const float* gamma, float eps,
                             const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
-                            int64_t rows, int D, hipStream_t s);
+                            int64_t rows, int D, int accumulate, hipStream_t s);
 int launch_adam_clipnorm(const void* table, const void* sizes, int n_vars, int64_t step, int64_t* step_dev, float lr,
                          float b1, float b2, float eps, float clipnorm, hipStream_t s);
 

@@ -195,16 +195,16 @@ __global__ __launch_bounds__(kBlock) void bmm_message_typed_bwd_kernel(
 // schedule A backward: A[v] = sum_k Tb[v,k] W[k]  =>  dW[k] = sum_v Tb[v,k] dA[v];  dTb[v,k] = <dA[v], W[k]>
 // ---------------------------------------------------------------------------------------
 __global__ void bond_type_matrices_bwd_w_kernel(const float* __restrict__ tb, const float* __restrict__ dA,
-                                                float* __restrict__ dW, int Vb, int K, int DD) {
+                                                float* __restrict__ dW, int Vb, int K, int DD, int accumulate) {
   const int k = blockIdx.y;
   for (int ij = blockIdx.x * blockDim.x + threadIdx.x; ij < DD; ij += gridDim.x * blockDim.x) {
     float acc = 0.f;
     for (int v = 0; v < Vb; ++v) acc = fmaf(tb[(int64_t)v * K + k], dA[(int64_t)v * DD + ij], acc);
-    dW[(int64_t)k * DD + ij] = acc;
+    dW[(int64_t)k * DD + ij] = accumulate ? dW[(int64_t)k * DD + ij] + acc : acc;
   }
 }
 __global__ void bond_type_matrices_bwd_t_kernel(const float* __restrict__ W, const float* __restrict__ dA,
-                                                float* __restrict__ dtb, int Vb, int K, int DD) {
+                                                float* __restrict__ dtb, int Vb, int K, int DD, int accumulate) {
   // one wave per (v,k)
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   if (wave >= Vb * K) return;
@@ -212,7 +212,7 @@ __global__ void bond_type_matrices_bwd_t_kernel(const float* __restrict__ W, con
   float acc = 0.f;
   for (int ij = lane; ij < DD; ij += 64) acc = fmaf(dA[(int64_t)v * DD + ij], W[(int64_t)k * DD + ij], acc);
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-  if (lane == 0) dtb[(int64_t)v * K + k] = acc;
+  if (lane == 0) dtb[(int64_t)v * K + k] = accumulate ? dtb[(int64_t)v * K + k] + acc : acc;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(kBlock) void strided_gemm_splitk_kernel(GemmProblem
 // dparams = fixed-order sums of the partials (canonical layout, see above).  One wave per output: lane l adds
 // partials l, l+64, ... in order, then a fixed butterfly - the same association on every run.
 __global__ void gated_update_reduce_kernel(const float* __restrict__ small, const float* __restrict__ gpart,
-                                           float* __restrict__ dparams, int nblk, int nchunk, int D) {
+                                           float* __restrict__ dparams, int nblk, int nchunk, int D, int accumulate) {
   const int DD2 = 2 * D * D;
   const int P = 3 * (DD2 + D) + 2 * D;
   const int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -521,7 +521,7 @@ __global__ void gated_update_reduce_kernel(const float* __restrict__ small, cons
   float acc = 0.f;
   for (int c = lane; c < n; c += 64) acc += src[(int64_t)c * stride];
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-  if (lane == 0) dparams[q] = acc;
+  if (lane == 0) dparams[q] = accumulate ? dparams[q] + acc : acc;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -660,16 +660,18 @@ int launch_strided_gemm(const float* A, const float* B, float* out, int64_t rows
 }
 
 int launch_bond_type_matrices_bwd(const float* tb, const float* W, const float* dA, float* dW, float* dtb, int Vb,
-                                  int K, int D, hipStream_t s) {
+                                  int K, int D, int accumulate, hipStream_t s) {
   const int DD = D * D;
-  if (K >= 64) {  // GEMM-shaped: dW (K x DD) = Tb^T dA over Vb rows; dTb (Vb x K) = dA W^T over DD rows
+  if (K >= 64) {
+    if (accumulate) return fail(IMPNN_E_UNSUPPORTED, "bond_type_matrices_bwd: accumulate needs K < 64");  // GEMM-shaped: dW (K x DD) = Tb^T dA over Vb rows; dTb (Vb x K) = dA W^T over DD rows
     if (int rc = launch_strided_gemm(tb, dA, dW, Vb, K, DD, K, 1, DD, 1, s)) return rc;
     return launch_strided_gemm(dA, W, dtb, DD, Vb, K, 1, DD, 1, DD, s);
   }
-  bond_type_matrices_bwd_w_kernel<<<dim3((DD + kBlock - 1) / kBlock, K), kBlock, 0, s>>>(tb, dA, dW, Vb, K, DD);
+  bond_type_matrices_bwd_w_kernel<<<dim3((DD + kBlock - 1) / kBlock, K), kBlock, 0, s>>>(tb, dA, dW, Vb, K, DD, accumulate);
   if (int rc = check_launch("bond_type_matrices_bwd_w")) return rc;
   const int64_t waves = (int64_t)Vb * K;
-  bond_type_matrices_bwd_t_kernel<<<(int)((waves * 64 + kBlock - 1) / kBlock), kBlock, 0, s>>>(W, dA, dtb, Vb, K, DD);
+  bond_type_matrices_bwd_t_kernel<<<(int)((waves * 64 + kBlock - 1) / kBlock), kBlock, 0, s>>>(W, dA, dtb, Vb, K, DD,
+                                                                                               accumulate);
   return check_launch("bond_type_matrices_bwd_t");
 }
 
@@ -703,7 +705,7 @@ int64_t gated_update_bwd_workspace(int64_t rows, int D) {
 int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
                             const float* br, const float* Wh, const float* bh, const float* gamma, float eps,
                             const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
-                            int64_t rows, int D, hipStream_t s) {
+                            int64_t rows, int D, int accumulate, hipStream_t s) {
   if (D > kBlock || kBlock % D != 0)
     return fail(IMPNN_E_UNSUPPORTED, "gated_update_bwd: atom_dim %d must divide %d", D, kBlock);
   const int R = kBlock / D;
@@ -737,7 +739,8 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
                                                                        nchunk, tiles_n);
   if (int rc = check_launch("strided_gemm_splitk")) return rc;
   const int P = (int)gated_update_param_floats(D);
-  gated_update_reduce_kernel<<<(P * 64 + kBlock - 1) / kBlock, kBlock, 0, s>>>(small, gpart, dparams, nblk, nchunk, D);
+  gated_update_reduce_kernel<<<(P * 64 + kBlock - 1) / kBlock, kBlock, 0, s>>>(small, gpart, dparams, nblk, nchunk, D,
+                                                                            accumulate);
   return check_launch("gated_update_reduce");
 }
 
