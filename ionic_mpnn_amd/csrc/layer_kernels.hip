@@ -158,15 +158,15 @@ constexpr int kTVb = 1024;       // bond types handled by the LDS histogram
 
 __global__ __launch_bounds__(512) void bmm_message_typed_d32_kernel(
     const float* __restrict__ h, const int32_t* __restrict__ bond_ids, const int32_t* __restrict__ conn,
-    const float* __restrict__ A, float* __restrict__ m_out, int B, int N, int E, int Vb) {
+    const float* __restrict__ A, float* __restrict__ m_out, int B, int N, int E, int Vb, int tm) {
   constexpr int D = 32;
   __shared__ int32_t hist[kTVb + 1], cursor[kTVb], tbase[kTVb + 1];
   __shared__ uint32_t sorted[kTSlots];
   __shared__ uint16_t tile_type[kTSlots / 16 + kTVb];
   __shared__ int32_t wtot[8], carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b0 = blockIdx.x * kTM;
-  const int nm = (B - b0) < kTM ? (B - b0) : kTM;
+  const int b0 = blockIdx.x * tm;  // tm <= kTM molecules per workgroup (fewer for small batches: more workgroups)
+  const int nm = (B - b0) < tm ? (B - b0) : tm;
   const int n_slots = nm * E;
   for (int t = tid; t <= Vb; t += blockDim.x) hist[t] = 0;
   __syncthreads();
@@ -299,8 +299,8 @@ __global__ void reduce_scatter_kernel(const float* __restrict__ m, const int32_t
       for (int i = c0; i < D; i += cols) acc[(size_t)n * D + i] = 0.f;
     const float* mb = m + (int64_t)b * E * D;
     const int32_t* tb = tgt + (int64_t)b * E * tgt_stride;
-    if (cols == D) {  // one column per thread: keep 8 edge rows in flight; adds stay in edge-slot order
-      constexpr int kU = 8;
+    if (cols == D) {  // one column per thread: keep 16 edge rows in flight; adds stay in edge-slot order
+      constexpr int kU = 16;
       int e = 0;
       for (; e + kU <= E; e += kU) {
         float v[kU];
@@ -708,7 +708,9 @@ int launch_bmm_message_typed(const float* h, const int32_t* bond_ids, const int3
   if (B == 0) return IMPNN_OK;
   if (D == 32 && Vb <= kTVb && (int64_t)kTM * E <= kTSlots && E < (1 << 15) && N < (1 << 12) && aligned16(h) &&
       aligned16(type_mats) && aligned16(m) && (reinterpret_cast<uintptr_t>(conn) & 7u) == 0) {
-    bmm_message_typed_d32_kernel<<<(B + kTM - 1) / kTM, 512, 0, s>>>(h, bond_ids, conn, type_mats, m, B, N, E, Vb);
+    int tm = B / 512;  // small batches (training with 32): fewer molecules per workgroup, more workgroups
+    tm = tm < 1 ? 1 : (tm > kTM ? kTM : tm);
+    bmm_message_typed_d32_kernel<<<(B + tm - 1) / tm, 512, 0, s>>>(h, bond_ids, conn, type_mats, m, B, N, E, Vb, tm);
     return check_launch("bmm_message_typed_d32");
   }
   size_t lds = (size_t)N * D * sizeof(float);
