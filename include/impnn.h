@@ -213,7 +213,8 @@ int impnn_batch_assemble(int32_t n_ions, const int32_t* sample_idx, int32_t B, i
  *  GlobalSumPool (a8):       dh[b,n,:] = atom_ids[b,n] > 0 ? dpooled[b,:] : 0
  *  BondMatrixMessage (a4) in the per-bond-type schedule (impnn_bond_type_matrices + impnn_bmm_message_typed):
  *      dh[b,src,:] (+=) A[type]^T dmessages[b,e,:];   dtype_mats[type] (+=) dmessages[b,e,:] (x) h[b,src,:]
- *      (the batch's valid edges are counting-sorted by type in `workspace`, one workgroup per <=64 edges of a type)
+ *      (the batch's valid edges are counting-sorted by type in `workspace`, one workgroup per <=64 edges of a type;
+ *      sorted_ready != 0: `workspace` still holds the sort of the same (conn, bond_ids) from an earlier call)
  *      then   dW[k] = sum_v Tb[v,k] dtype_mats[v];     dbond_table[v,k] = <dtype_mats[v], W[k]>
  *  GatedUpdate (a7, :142-156): dh, dagg (rows,D) and dparams in the canonical order
  *      Wz 2D*D | bz D | Wr | br | Wh | bh | gamma | beta  (impnn_gated_update_param_floats(D) floats, overwritten);
@@ -233,7 +234,7 @@ int64_t impnn_bmm_message_typed_bwd_workspace_bytes(int32_t B, int32_t E, int32_
 int impnn_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn,
                                 const float* type_mats, const float* dmessages, float* dh, float* dtype_mats,
                                 void* workspace, int64_t workspace_bytes, int32_t B, int32_t N, int32_t E, int32_t D,
-                                int32_t Vb, impnn_stream_t stream);
+                                int32_t Vb, int32_t sorted_ready, impnn_stream_t stream);
 int impnn_bond_type_matrices_bwd(const float* bond_table, const float* W, const float* dtype_mats, float* dW,
                                  float* dbond_table, int32_t Vb, int32_t K, int32_t D, int32_t accumulate,
                                  impnn_stream_t stream);

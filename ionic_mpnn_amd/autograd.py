@@ -10,6 +10,26 @@ from . import _lib, ops
 from ._lib import check, f32c, i32c, ptr, stream_ptr
 
 
+_pass = {"id": None, "next": 1}
+
+
+class training_pass:
+    """Scope of ONE differentiable forward pass (MPNNModel.__call__(training=True) opens it).  Work that depends on
+    the batch's graph tensors only - the edge sort by bond type of the message backward - is shared by the nodes
+    created inside one scope and never across scopes (the tensors may be refilled in place by kernels that torch's
+    version counters do not see)."""
+
+    def __enter__(self):
+        self.prev = _pass["id"]
+        _pass["id"] = _pass["next"]
+        _pass["next"] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _pass["id"] = self.prev
+        return False
+
+
 def _sink(param):
     """The existing gradient buffer of a leaf parameter, when a backward kernel may add into it directly
     (float32, contiguous, same device): ionic_mpnn_amd.train.Adam keeps every .grad as a view of one flat buffer.
@@ -78,6 +98,7 @@ class BmmMessageTyped(torch.autograd.Function):
     def forward(ctx, h, bond_ids, conn, type_mats):
         h, type_mats, bond_ids, conn = f32c(h), f32c(type_mats), i32c(bond_ids), i32c(conn)
         ctx.save_for_backward(h, bond_ids, conn, type_mats)
+        ctx.graph_key = (conn, bond_ids, _pass["id"])  # the tensor OBJECTS (the S layers of one ion share them)
         return ops.bmm_message_typed(h, bond_ids, conn, type_mats)
 
     @staticmethod
@@ -89,9 +110,18 @@ class BmmMessageTyped(torch.autograd.Function):
         dh, dmats = torch.zeros_like(h), torch.zeros_like(mats)
         lib = _lib.load()
         wsb = int(lib.impnn_bmm_message_typed_bwd_workspace_bytes(B, E, Vb))
-        ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=h.device)
+        # The edge sort by bond type depends on (conn, bond_ids) only.  It is kept on the connectivity tensor
+        # object, keyed by the in-place version counters of both tensors, so the other layers of this ion in the
+        # same backward pass (and nobody else) reuse it.
+        holder, bond_obj, pass_id = ctx.graph_key  # the objects the forward saw (saved tensors may be re-wrapped)
+        key = (pass_id, holder._version, bond_obj.data_ptr(), bond_obj._version, Vb, wsb)
+        cached = getattr(holder, "_impnn_edge_sort", None)
+        ready = pass_id is not None and cached is not None and cached[0] == key
+        ws = cached[1] if ready else torch.empty(max(wsb, 4), dtype=torch.uint8, device=h.device)
         _lib_call(h.device, lib.impnn_bmm_message_typed_bwd, ptr(h), ptr(bond_ids), ptr(conn), ptr(mats),
-                  ptr(dm), ptr(dh), ptr(dmats), ptr(ws), wsb, B, N, E, D, Vb)
+                  ptr(dm), ptr(dh), ptr(dmats), ptr(ws), wsb, B, N, E, D, Vb, 1 if ready else 0)
+        if not ready and pass_id is not None:
+            holder._impnn_edge_sort = (key, ws)
         return dh, None, None, dmats
 
 

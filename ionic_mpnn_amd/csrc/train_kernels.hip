@@ -611,7 +611,7 @@ int64_t bmm_message_typed_bwd_workspace_ints(int B, int E, int Vb) { return (int
 
 int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn, const float* A,
                                  const float* dm, float* dh, float* dA, int32_t* workspace, int B, int N, int E,
-                                 int D, int Vb, hipStream_t s) {
+                                 int D, int Vb, int sorted_ready, hipStream_t s) {
   if (Vb > kMaxTypes) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed_bwd: Vb=%d too large", Vb);
   if (D > 128) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed_bwd: D=%d > 128", D);
   const int64_t BE = (int64_t)B * E;
@@ -620,15 +620,17 @@ int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const 
   int32_t* cursor = start + (Vb + 1);
   int32_t* segbase = cursor + (Vb + 1);
   int32_t* order = segbase + (Vb + 1);
-  // (a kernel, not hipMemsetAsync: the call must behave the same inside a captured hipGraph)
-  zero_ints_kernel<<<grid_for(Vb + 1), kBlock, 0, s>>>(cnt, Vb + 1);
-  if (int rc = check_launch("zero_ints")) return rc;
-  edge_type_hist_kernel<<<grid_for(BE), kBlock, 0, s>>>(conn, bond_ids, cnt, BE, N, Vb);
-  if (int rc = check_launch("edge_type_hist")) return rc;
-  edge_type_prefix_kernel<<<1, 64, 0, s>>>(cnt, start, cursor, segbase, Vb);
-  if (int rc = check_launch("edge_type_prefix")) return rc;
-  edge_type_scatter_kernel<<<grid_for(BE), kBlock, 0, s>>>(conn, bond_ids, cursor, order, BE, N, Vb);
-  if (int rc = check_launch("edge_type_scatter")) return rc;
+  if (!sorted_ready) {  // the sort depends on (conn, bond_ids) only: the S layers of one ion share it
+    // (a kernel, not hipMemsetAsync: the call must behave the same inside a captured hipGraph)
+    zero_ints_kernel<<<grid_for(Vb + 1), kBlock, 0, s>>>(cnt, Vb + 1);
+    if (int rc = check_launch("zero_ints")) return rc;
+    edge_type_hist_kernel<<<grid_for(BE), kBlock, 0, s>>>(conn, bond_ids, cnt, BE, N, Vb);
+    if (int rc = check_launch("edge_type_hist")) return rc;
+    edge_type_prefix_kernel<<<1, 64, 0, s>>>(cnt, start, cursor, segbase, Vb);
+    if (int rc = check_launch("edge_type_prefix")) return rc;
+    edge_type_scatter_kernel<<<grid_for(BE), kBlock, 0, s>>>(conn, bond_ids, cursor, order, BE, N, Vb);
+    if (int rc = check_launch("edge_type_scatter")) return rc;
+  }
   const int64_t max_segs = (BE + kSeg - 1) / kSeg + Vb;
   const size_t lds = sizeof(float) * ((size_t)D * D + 2 * (size_t)kSeg * D);
   const int acc = (D * D + kBlock - 1) / kBlock;

@@ -318,8 +318,10 @@ class MPNNModel:
         head in torch ops."""
         inputs = self._to_device(inputs)
         if training:
-            pc, pa = self.encode_pooled(inputs, fused=False)
-            return self.head(pc, pa, inputs.get("temperature"), differentiable=True)
+            from . import autograd
+            with autograd.training_pass():
+                pc, pa = self.encode_pooled(inputs, fused=False)
+                return self.head(pc, pa, inputs.get("temperature"), differentiable=True)
         with torch.no_grad():
             pc, pa = self.encode_pooled(inputs, fused=fused, trace=trace)
             return self.head(pc, pa, inputs.get("temperature"), trace=trace)
