@@ -228,13 +228,16 @@ __global__ void bond_type_matrices_bwd_t_kernel(const float* __restrict__ W, con
 //   3. gated_update_reduce_kernel: adds the per-workgroup / per-chunk partials in a fixed order into dparams
 //      (Wz 2D*D | bz | Wr | br | Wh | bh | gamma | beta): parameter gradients are bitwise reproducible.
 // ---------------------------------------------------------------------------------------
-template <bool WLDS>  // the three gate kernels staged in LDS (row stride D+1: both access directions conflict-free)
-__global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
+// WLDS: the three gate kernels staged in LDS (row stride D+1: both access directions conflict-free).
+// BS: workgroup size = rows per tile x D; large D uses 1024 threads so that one pass over the (L2-resident)
+// kernels serves 4x more rows.
+template <bool WLDS, int BS>
+__global__ __launch_bounds__(BS) void gated_update_bwd_kernel(
     const float* __restrict__ h, const float* __restrict__ agg, const float* __restrict__ Wz,
     const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
     const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma, float eps,
     const float* __restrict__ dout, float* __restrict__ dh, float* __restrict__ dagg, float* __restrict__ dpre,
-    float* __restrict__ rh_out, float* __restrict__ small, int64_t rows, int D, int R) {
+    float* __restrict__ rh_out, float* __restrict__ small, const float* __restrict__ WT, int64_t rows, int D, int R) {
   extern __shared__ __align__(16) float smem[];
   float* hs = smem;            // R*D each
   float* as = hs + R * D;
@@ -255,9 +258,15 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
 #define WZ(r_, c_) (WLDS ? wz_s[(r_) * LD + (c_)] : Wz[(int64_t)(r_) * D + (c_)])
 #define WR(r_, c_) (WLDS ? wr_s[(r_) * LD + (c_)] : Wr[(int64_t)(r_) * D + (c_)])
 #define WH(r_, c_) (WLDS ? wh_s[(r_) * LD + (c_)] : Wh[(int64_t)(r_) * D + (c_)])
+  // element (r_, c_) for loops whose LANES walk r_: from LDS (padded stride) or from the transposed copies
+  // WT = [Wz^T | Wr^T | Wh^T], each D x 2D, so that consecutive lanes read consecutive addresses
+  const int D2 = 2 * D;
+#define WZ_T(r_, c_) (WLDS ? wz_s[(r_) * LD + (c_)] : WT[(int64_t)(c_) * D2 + (r_)])
+#define WR_T(r_, c_) (WLDS ? wr_s[(r_) * LD + (c_)] : WT[(int64_t)D * D2 + (int64_t)(c_) * D2 + (r_)])
+#define WH_T(r_, c_) (WLDS ? wh_s[(r_) * LD + (c_)] : WT[(int64_t)2 * D * D2 + (int64_t)(c_) * D2 + (r_)])
   float s_bz = 0.f, s_br = 0.f, s_bh = 0.f, s_dg = 0.f, s_db = 0.f;  // this thread's (row slot, column) sums
   if (WLDS) {
-    for (int t = threadIdx.x; t < 2 * D * D; t += kBlock) {
+    for (int t = threadIdx.x; t < 2 * D * D; t += BS) {
       const int rw = t / D, c = t - rw * D;
       wz_s[rw * LD + c] = Wz[t];
       wr_s[rw * LD + c] = Wr[t];
@@ -269,12 +278,12 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
     const int64_t row0 = tile * R;
     const int nr = (int)((rows - row0) < R ? (rows - row0) : R);
     __syncthreads();
-    for (int t = tid; t < nr * D; t += kBlock) {
+    for (int t = tid; t < nr * D; t += BS) {
       hs[t] = h[row0 * D + t];
       as[t] = agg[row0 * D + t];
     }
     __syncthreads();
-    for (int t = tid; t < nr * D; t += kBlock) {
+    for (int t = tid; t < nr * D; t += BS) {
       const int r = t / D, i = t - r * D;
       float az = bz[i], ar = br[i];
       for (int j = 0; j < D; ++j) {
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
       rh_out[row0 * D + t] = rhv;
     }
     __syncthreads();
-    for (int t = tid; t < nr * D; t += kBlock) {
+    for (int t = tid; t < nr * D; t += BS) {
       const int r = t / D, i = t - r * D;
       float ah = bh[i];
       for (int j = 0; j < D; ++j) ah = fmaf(rhs[r * D + j], WH(j, i), ah);
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
       xs[t] = (1.0f - zs[t]) * hs[t] + zs[t] * tt;
     }
     __syncthreads();
-    for (int r = tid; r < nr; r += kBlock) {
+    for (int r = tid; r < nr; r += BS) {
       float mean = 0.f;
       for (int j = 0; j < D; ++j) mean += xs[r * D + j];
       mean /= (float)D;
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
       st[4 * r + 1] = 1.0f / sqrtf(var / (float)D + eps);
     }
     __syncthreads();
-    for (int t = tid; t < nr * D; t += kBlock) {
+    for (int t = tid; t < nr * D; t += BS) {
       const int r = t / D, i = t - r * D;
       const float xh = (xs[t] - st[4 * r]) * st[4 * r + 1];
       xs[t] = xh;
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
       g2[t] = dxh * xh;
     }
     __syncthreads();
-    for (int r = tid; r < nr; r += kBlock) {
+    for (int r = tid; r < nr; r += BS) {
       float m1 = 0.f, m2 = 0.f;
       for (int j = 0; j < D; ++j) {
         m1 += g1[r * D + j];
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
     }
     __syncthreads();
     // dn -> (dzp, dtp), first part of dh; column sums for dgamma / dbeta
-    for (int t = tid; t < nr * D; t += kBlock) {
+    for (int t = tid; t < nr * D; t += BS) {
       const int r = t / D;
       const float dy = dout[row0 * D + t];
       const float xh = xs[t];
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
       g1[t] = dzp;
       g3[t] = dtp;
       xs[t] = dy + dn * (1.0f - z);  // dh so far (x-hat is dead)
-      if (t == tid) {                 // kBlock == R*D: one element per thread, fixed (slot, column)
+      if (t == tid) {                 // BS == R*D: one element per thread, fixed (slot, column)
         s_dg = fmaf(dy, xh, s_dg);
         s_db += dy;
         s_bz += dzp;
@@ -359,13 +368,13 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
     }
     __syncthreads();
     // dc2 = dtp Wh^T: lower half -> through r*h, upper half -> dagg
-    for (int t = tid; t < nr * D; t += kBlock) {
+    for (int t = tid; t < nr * D; t += BS) {
       const int r = t / D, i = t - r * D;
       float lo = 0.f, hi = 0.f;
       for (int j = 0; j < D; ++j) {
         const float d = g3[r * D + j];
-        lo = fmaf(d, WH(i, j), lo);
-        hi = fmaf(d, WH(D + i, j), hi);
+        lo = fmaf(d, WH_T(i, j), lo);
+        hi = fmaf(d, WH_T(D + i, j), hi);
       }
       const float rr = rs[t];
       const float drp = lo * hs[t] * rr * (1.0f - rr);
@@ -376,15 +385,15 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
     }
     __syncthreads();
     // dc = dzp Wz^T + drp Wr^T; dpre leaves for the kernel-gradient GEMMs
-    for (int t = tid; t < nr * D; t += kBlock) {
+    for (int t = tid; t < nr * D; t += BS) {
       const int r = t / D, i = t - r * D;
       float lo = 0.f, hi = 0.f;
       for (int j = 0; j < D; ++j) {
         const float dz = g1[r * D + j], dr = g2[r * D + j];
-        lo = fmaf(dz, WZ(i, j), lo);
-        lo = fmaf(dr, WR(i, j), lo);
-        hi = fmaf(dz, WZ(D + i, j), hi);
-        hi = fmaf(dr, WR(D + i, j), hi);
+        lo = fmaf(dz, WZ_T(i, j), lo);
+        lo = fmaf(dr, WR_T(i, j), lo);
+        hi = fmaf(dz, WZ_T(D + i, j), hi);
+        hi = fmaf(dr, WR_T(D + i, j), hi);
       }
       dh[row0 * D + t] = xs[t] + lo;
       dagg[row0 * D + t] = zs[t] + hi;
@@ -396,24 +405,45 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_kernel(
   }
   // column sums: thread tid holds (slot tid / D, column tid % D); add the slots in a fixed order
   __syncthreads();
-  float* red = smem;  // 5 * kBlock
+  float* red = smem;  // 5 * BS
   red[tid] = s_bz;
-  red[kBlock + tid] = s_br;
-  red[2 * kBlock + tid] = s_bh;
-  red[3 * kBlock + tid] = s_dg;
-  red[4 * kBlock + tid] = s_db;
+  red[BS + tid] = s_br;
+  red[2 * BS + tid] = s_bh;
+  red[3 * BS + tid] = s_dg;
+  red[4 * BS + tid] = s_db;
   __syncthreads();
   float* mine = small + (int64_t)blockIdx.x * 5 * D;
-  for (int q = tid; q < 5 * D; q += kBlock) {
+  for (int q = tid; q < 5 * D; q += BS) {
     const int which = q / D, i = q - which * D;
     float acc = 0.f;
-    for (int slot = 0; slot < R; ++slot) acc += red[which * kBlock + slot * D + i];
+    for (int slot = 0; slot < R; ++slot) acc += red[which * BS + slot * D + i];
     mine[q] = acc;
   }
 }
 #undef WZ
 #undef WR
 #undef WH
+#undef WZ_T
+#undef WR_T
+#undef WH_T
+
+// WT = [Wz^T | Wr^T | Wh^T] (each D x 2D) for the large-D variant above (32x32 LDS tiles)
+__global__ void transpose3_kernel(const float* __restrict__ Wz, const float* __restrict__ Wr,
+                                  const float* __restrict__ Wh, float* __restrict__ WT, int D) {
+  __shared__ float tile[32][33];
+  const float* W = blockIdx.z == 0 ? Wz : (blockIdx.z == 1 ? Wr : Wh);
+  float* T = WT + (int64_t)blockIdx.z * 2 * D * D;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;  // W is (2D x D): rows r, cols c
+  for (int y = threadIdx.y; y < 32; y += blockDim.y) {
+    const int r = r0 + y, c = c0 + threadIdx.x;
+    tile[y][threadIdx.x] = (r < 2 * D && c < D) ? W[(int64_t)r * D + c] : 0.f;
+  }
+  __syncthreads();
+  for (int y = threadIdx.y; y < 32; y += blockDim.y) {
+    const int c = c0 + y, r = r0 + threadIdx.x;       // T is (D x 2D): T[c][r]
+    if (c < D && r < 2 * D) T[(int64_t)c * 2 * D + r] = tile[threadIdx.x][y];
+  }
+}
 
 // C[M x N] (per chunk) = sum over the chunk's rows r of A(r,m) * B(r,n), every operand addressed with a row and
 // a column stride; the M axis may be the concatenation [A1 | A2] of two operands (split at Mh).
@@ -699,9 +729,10 @@ int gated_update_bwd_blocks(int64_t rows, int D) { return gu_main_blocks(rows, D
 
 int64_t gated_update_param_floats(int D) { return 3 * ((int64_t)2 * D * D + D) + 2 * D; }
 
-// workspace (floats): dpre rows*3D | r*h rows*D | small nblk*5D | GEMM partials 3*nchunk*2D*D
+// workspace (floats): dpre rows*3D | r*h rows*D | small nblk*5D | GEMM partials 3*nchunk*2D*D | W^T 3*2D*D
 int64_t gated_update_bwd_workspace(int64_t rows, int D) {
-  return rows * 4 * D + (int64_t)gu_main_blocks(rows, D) * 5 * D + (int64_t)3 * gu_chunks(rows, D) * 2 * D * D;
+  return rows * 4 * D + (int64_t)gu_main_blocks(rows, D) * 5 * D + (int64_t)3 * gu_chunks(rows, D) * 2 * D * D +
+         (int64_t)3 * 2 * D * D;
 }
 
 int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
@@ -716,19 +747,29 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   float* rh = dpre + rows * 3 * D;
   float* small = rh + rows * D;
   float* gpart = small + (int64_t)nblk * 5 * D;
+  float* wt = gpart + (int64_t)3 * nchunk * 2 * D * D;
   size_t lds = sizeof(float) * ((size_t)10 * R * D + 4 * R);
   if (lds < sizeof(float) * 5 * kBlock) lds = sizeof(float) * 5 * kBlock;
   const size_t wlds = sizeof(float) * (size_t)3 * 2 * D * (D + 1);
   if (lds + wlds <= 120 * 1024) {
     lds += wlds;
     if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)gated_update_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
-    gated_update_bwd_kernel<true><<<nblk, kBlock, lds, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh,
-                                                            dagg, dpre, rh, small, rows, D, R);
+      (void)hipFuncSetAttribute((const void*)gated_update_bwd_kernel<true, kBlock>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    gated_update_bwd_kernel<true, kBlock><<<nblk, kBlock, lds, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh,
+                                                                    dagg, dpre, rh, small, nullptr, rows, D, R);
   } else {
-    gated_update_bwd_kernel<false><<<nblk, kBlock, lds, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh,
-                                                             dagg, dpre, rh, small, rows, D, R);
+    constexpr int kBig = 1024;
+    const int Rb = kBig / D;
+    size_t lb = sizeof(float) * ((size_t)10 * Rb * D + 4 * Rb);
+    if (lb < sizeof(float) * 5 * kBig) lb = sizeof(float) * 5 * kBig;
+    if (lb > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)gated_update_bwd_kernel<false, kBig>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+    transpose3_kernel<<<dim3((D + 31) / 32, (2 * D + 31) / 32, 3), dim3(32, 8), 0, s>>>(Wz, Wr, Wh, wt, D);
+    if (int rc = check_launch("transpose3")) return rc;
+    gated_update_bwd_kernel<false, kBig><<<nblk, kBig, lb, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh,
+                                                                dagg, dpre, rh, small, wt, rows, D, Rb);
   }
   if (int rc = check_launch("gated_update_bwd")) return rc;
   int tiles_n = 1;
