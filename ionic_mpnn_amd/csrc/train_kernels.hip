@@ -210,7 +210,20 @@ __global__ void bond_type_matrices_bwd_t_kernel(const float* __restrict__ W, con
   if (wave >= Vb * K) return;
   const int v = wave / K, k = wave - v * K;
   float acc = 0.f;
-  for (int ij = lane; ij < DD; ij += 64) acc = fmaf(dA[(int64_t)v * DD + ij], W[(int64_t)k * DD + ij], acc);
+  const float* da = dA + (int64_t)v * DD;
+  const float* w = W + (int64_t)k * DD;
+  int ij = lane;
+  for (; ij + 7 * 64 < DD; ij += 8 * 64) {  // 16 independent loads in flight per lane
+    float x[8], y[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      x[u] = da[ij + 64 * u];
+      y[u] = w[ij + 64 * u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = fmaf(x[u], y[u], acc);
+  }
+  for (; ij < DD; ij += 64) acc = fmaf(da[ij], w[ij], acc);
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
   if (lane == 0) dtb[(int64_t)v * K + k] = accumulate ? dtb[(int64_t)v * K + k] + acc : acc;
 }
