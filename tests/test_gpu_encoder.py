@@ -322,3 +322,37 @@ def test_large_atom_vocabularies_take_the_global_table_path(Va, S, mode):
     ra = O.encode(w, "an", inp["an_atom"], inp["an_bond"], inp["an_connectivity"], pooled_only=True)
     assert_close(pc.cpu().numpy(), rc, what="cat pooled")
     assert_close(pa.cpu().numpy(), ra, what="an pooled")
+
+
+def _random_dense_case(rng):
+    N = int(rng.integers(1, 97))
+    E = int(rng.integers(0, 4 * N + 1))
+    E = min(E, 300)
+    K = int(rng.integers(1, 9))
+    S = int(rng.integers(0, 5))
+    B = int(rng.integers(1, 400))
+    Va, Vb = int(rng.integers(2, 500)), int(rng.integers(1, 200))
+    ids = rng.integers(0, Va, size=(2, B, N)).astype(np.int32)
+    ids[rng.random(size=ids.shape) < 0.2] = 0                      # padding holes anywhere
+    conn = rng.integers(0, N, size=(2, B, E, 2)).astype(np.int32)   # arbitrary multigraph incl. self loops
+    bond = rng.integers(0, Vb, size=(2, B, E)).astype(np.int32)
+    inp = {"cat_atom": ids[0], "cat_bond": bond[0], "cat_connectivity": conn[0],
+           "an_atom": ids[1], "an_bond": bond[1], "an_connectivity": conn[1]}
+    return N, E, K, S, B, Va, Vb, inp
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fused_encoder_fuzz_against_the_oracle(seed):
+    """Random shapes and arbitrary multigraphs (not just trees): every placement / chunking / entry-packing path of
+    the plan and both table paths of the encoder, in the mode the model would pick."""
+    rng = np.random.default_rng(1000 + seed)
+    N, E, K, S, B, Va, Vb, inp = _random_dense_case(rng)
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=32, bond_dim=K, num_steps=S, seed=seed, perturb=True)
+    m = make_model(w, Va, Vb, K=K, mode="auto")
+    if not m.fused_supported(N, E):
+        pytest.skip("shape outside the fused encoder")
+    pc, pa = m.encode_pooled(to_dev(inp), fused=True)
+    rc = O.encode(w, "cat", inp["cat_atom"], inp["cat_bond"], inp["cat_connectivity"], pooled_only=True)
+    ra = O.encode(w, "an", inp["an_atom"], inp["an_bond"], inp["an_connectivity"], pooled_only=True)
+    assert_close(pc.cpu().numpy(), rc, what=f"cat pooled (N={N} E={E} K={K} S={S} B={B} Va={Va} Vb={Vb})")
+    assert_close(pa.cpu().numpy(), ra, what="an pooled")
