@@ -338,6 +338,9 @@ __global__ void reduce_scatter_kernel(const float* __restrict__ m, const int32_t
 //   c=[h|agg]; z=sig(cWz+bz); r=sig(cWr+br); ht=tanh([r*h|agg]Wh+bh);
 //   n=(1-z)h+z*ht; n=LN(n)*gamma+beta (eps, biased var); out=n+h.
 // ---------------------------------------------------------------------------------------
+// Thread (row group rg, column i) owns column i of RB rows (rg, rg + G, ...; G = blockDim / D row groups): every
+// weight element it loads from L2 is used for RB rows, so a pass over the 3 x 2D x D kernels serves RB * G rows.
+template <int RB>
 __global__ void gated_update_kernel(const float* __restrict__ h, const float* __restrict__ agg,
                                     const float* __restrict__ Wz, const float* __restrict__ bz,
                                     const float* __restrict__ Wr, const float* __restrict__ br,
@@ -351,37 +354,70 @@ __global__ void gated_update_kernel(const float* __restrict__ h, const float* __
   float* rh = zs + R * D;      // R*D
   float* ns = rh + R * D;      // R*D
   float* st = ns + R * D;      // 2*R (mean, inv)
+  const int G = blockDim.x / D;  // row groups; R == RB * G
+  const int i = threadIdx.x % D, rg = threadIdx.x / D;
+  const bool worker = rg < G;
   const int64_t row0 = (int64_t)blockIdx.x * R;
   const int nr = (int)((rows - row0) < R ? (rows - row0) : R);
-  for (int t = threadIdx.x; t < nr * D; t += blockDim.x) {
-    hs[t] = h[row0 * D + t];
-    as[t] = agg[row0 * D + t];
+  for (int t = threadIdx.x; t < R * D; t += blockDim.x) {
+    const bool in = t < nr * D;
+    hs[t] = in ? h[row0 * D + t] : 0.f;
+    as[t] = in ? agg[row0 * D + t] : 0.f;
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < nr * D; t += blockDim.x) {
-    const int r = t / D, i = t - r * D;
-    float az = bz[i], ar = br[i];
-    for (int j = 0; j < D; ++j) {
-      const float x = hs[r * D + j];
-      az = fmaf(x, Wz[(int64_t)j * D + i], az);
-      ar = fmaf(x, Wr[(int64_t)j * D + i], ar);
+  if (worker) {
+    float az[RB], ar[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      az[u] = bz[i];
+      ar[u] = br[i];
     }
     for (int j = 0; j < D; ++j) {
-      const float x = as[r * D + j];
-      az = fmaf(x, Wz[(int64_t)(D + j) * D + i], az);
-      ar = fmaf(x, Wr[(int64_t)(D + j) * D + i], ar);
+      const float wz = Wz[(int64_t)j * D + i], wr = Wr[(int64_t)j * D + i];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const float x = hs[(rg + u * G) * D + j];
+        az[u] = fmaf(x, wz, az[u]);
+        ar[u] = fmaf(x, wr, ar[u]);
+      }
     }
-    zs[t] = sigmoidf_(az);
-    rh[t] = sigmoidf_(ar) * hs[t];
+    for (int j = 0; j < D; ++j) {
+      const float wz = Wz[(int64_t)(D + j) * D + i], wr = Wr[(int64_t)(D + j) * D + i];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const float x = as[(rg + u * G) * D + j];
+        az[u] = fmaf(x, wz, az[u]);
+        ar[u] = fmaf(x, wr, ar[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int t = (rg + u * G) * D + i;
+      zs[t] = sigmoidf_(az[u]);
+      rh[t] = sigmoidf_(ar[u]) * hs[t];
+    }
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < nr * D; t += blockDim.x) {
-    const int r = t / D, i = t - r * D;
-    float ah = bh[i];
-    for (int j = 0; j < D; ++j) ah = fmaf(rh[r * D + j], Wh[(int64_t)j * D + i], ah);
-    for (int j = 0; j < D; ++j) ah = fmaf(as[r * D + j], Wh[(int64_t)(D + j) * D + i], ah);
-    const float z = zs[t];
-    ns[t] = (1.0f - z) * hs[t] + z * tanhf(ah);
+  if (worker) {
+    float ah[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) ah[u] = bh[i];
+    for (int j = 0; j < D; ++j) {
+      const float w = Wh[(int64_t)j * D + i];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) ah[u] = fmaf(rh[(rg + u * G) * D + j], w, ah[u]);
+    }
+    for (int j = 0; j < D; ++j) {
+      const float w = Wh[(int64_t)(D + j) * D + i];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) ah[u] = fmaf(as[(rg + u * G) * D + j], w, ah[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int t = (rg + u * G) * D + i;
+      const float z = zs[t];
+      ns[t] = (1.0f - z) * hs[t] + z * tanhf(ah[u]);
+    }
   }
   __syncthreads();
   for (int r = threadIdx.x; r < nr; r += blockDim.x) {
@@ -399,8 +435,8 @@ __global__ void gated_update_kernel(const float* __restrict__ h, const float* __
   }
   __syncthreads();
   for (int t = threadIdx.x; t < nr * D; t += blockDim.x) {
-    const int r = t / D, i = t - r * D;
-    out[row0 * D + t] = (ns[t] - st[2 * r]) * st[2 * r + 1] * gamma[i] + beta[i] + hs[t];
+    const int r = t / D, c = t - r * D;
+    out[row0 * D + t] = (ns[t] - st[2 * r]) * st[2 * r + 1] * gamma[c] + beta[c] + hs[t];
   }
 }
 
@@ -750,16 +786,24 @@ int launch_gated_update(const float* h, const float* agg, const float* Wz, const
     gated_update_d32_kernel<<<(unsigned)blocks, 256, 0, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, out, rows);
     return check_launch("gated_update_d32");
   }
-  int R = kBlock / D;
-  if (R < 1) R = 1;
-  size_t lds = ((size_t)5 * R * D + 2 * R) * sizeof(float);
+  if (D > kBlock) return fail(IMPNN_E_UNSUPPORTED, "gated_update: D=%d too large", D);
+  const int G = kBlock / D;
+  const bool big = D >= 64;  // more rows per weight pass where the kernels no longer sit in L1
+  const int R = (big ? 8 : 4) * G;
+  const size_t lds = ((size_t)5 * R * D + 2 * R) * sizeof(float);
   if (lds > kMaxLds) return fail(IMPNN_E_UNSUPPORTED, "gated_update: D=%d too large", D);
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)gated_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
   const int64_t blocks = (rows + R - 1) / R;
-  gated_update_kernel<<<(unsigned)blocks, kBlock, lds, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps,
-                                                           out, rows, D, R);
+  if (big) {
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)gated_update_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    gated_update_kernel<8><<<(unsigned)blocks, kBlock, lds, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, out,
+                                                                rows, D, R);
+  } else {
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)gated_update_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    gated_update_kernel<4><<<(unsigned)blocks, kBlock, lds, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, out,
+                                                                rows, D, R);
+  }
   return check_launch("gated_update");
 }
 
