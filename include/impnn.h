@@ -231,6 +231,13 @@ int impnn_reduce_scatter_bwd(const float* dagg, const int32_t* tgt, int32_t tgt_
 int impnn_global_sum_pool_bwd(const float* dpooled, const int32_t* atom_ids, float* dh, int32_t B, int32_t N,
                               int32_t D, impnn_stream_t stream);
 int64_t impnn_bmm_message_typed_bwd_workspace_bytes(int32_t B, int32_t E, int32_t Vb);
+/*  impnn_bmm_message_typed (forward) over the same type-sorted edge segments, any D <= 128: A[type] staged in LDS,
+ *  one workgroup per <= 64 edges of a type.  Same workspace (and size query) as the backward entry: a sort made here
+ *  serves the backward call of the layer and every other layer of the ion (sorted_ready = 1 there). */
+int impnn_bmm_message_typed_sorted(const float* h, const int32_t* bond_ids, const int32_t* conn,
+                                   const float* type_mats, float* messages, void* workspace, int64_t workspace_bytes,
+                                   int32_t B, int32_t N, int32_t E, int32_t D, int32_t Vb, int32_t sorted_ready,
+                                   impnn_stream_t stream);
 int impnn_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn,
                                 const float* type_mats, const float* dmessages, float* dh, float* dtype_mats,
                                 void* workspace, int64_t workspace_bytes, int32_t B, int32_t N, int32_t E, int32_t D,

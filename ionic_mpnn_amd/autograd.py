@@ -30,6 +30,10 @@ class training_pass:
         return False
 
 
+def current_pass():
+    return _pass["id"]
+
+
 def _sink(param):
     """The existing gradient buffer of a leaf parameter, when a backward kernel may add into it directly
     (float32, contiguous, same device): ionic_mpnn_amd.train.Adam keeps every .grad as a view of one flat buffer.
@@ -109,19 +113,16 @@ class BmmMessageTyped(torch.autograd.Function):
         dm = f32c(dm)
         dh, dmats = torch.zeros_like(h), torch.zeros_like(mats)
         lib = _lib.load()
-        wsb = int(lib.impnn_bmm_message_typed_bwd_workspace_bytes(B, E, Vb))
-        # The edge sort by bond type depends on (conn, bond_ids) only.  It is kept on the connectivity tensor
-        # object, keyed by the in-place version counters of both tensors, so the other layers of this ion in the
-        # same backward pass (and nobody else) reuse it.
+        # the edge sort by bond type depends on (conn, bond_ids) only: shared inside a training pass
         holder, bond_obj, pass_id = ctx.graph_key  # the objects the forward saw (saved tensors may be re-wrapped)
-        key = (pass_id, holder._version, bond_obj.data_ptr(), bond_obj._version, Vb, wsb)
-        cached = getattr(holder, "_impnn_edge_sort", None)
-        ready = pass_id is not None and cached is not None and cached[0] == key
-        ws = cached[1] if ready else torch.empty(max(wsb, 4), dtype=torch.uint8, device=h.device)
+        prev = _pass["id"]
+        _pass["id"] = pass_id                       # backward runs outside the with-block: re-enter its pass
+        try:
+            ws, ready = ops.edge_sort_workspace(holder, bond_obj, B, E, Vb)
+        finally:
+            _pass["id"] = prev
         _lib_call(h.device, lib.impnn_bmm_message_typed_bwd, ptr(h), ptr(bond_ids), ptr(conn), ptr(mats),
-                  ptr(dm), ptr(dh), ptr(dmats), ptr(ws), wsb, B, N, E, D, Vb, 1 if ready else 0)
-        if not ready and pass_id is not None:
-            holder._impnn_edge_sort = (key, ws)
+                  ptr(dm), ptr(dh), ptr(dmats), ptr(ws), ws.numel(), B, N, E, D, Vb, 1 if ready else 0)
         return dh, None, None, dmats
 
 

@@ -57,6 +57,9 @@ int launch_reduce_scatter_bwd(const float* dagg, const int32_t* tgt, int tgt_str
                               int D, hipStream_t s);
 int launch_global_sum_pool_bwd(const float* dp, const int32_t* ids, float* dh, int B, int N, int D, hipStream_t s);
 int64_t bmm_message_typed_bwd_workspace_ints(int B, int E, int Vb);
+int launch_bmm_message_typed_sorted(const float* h, const int32_t* bond_ids, const int32_t* conn, const float* A,
+                                    float* m, int32_t* workspace, int B, int N, int E, int D, int Vb, int sorted_ready,
+                                    hipStream_t s);
 int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn, const float* A,
                                  const float* dm, float* dh, float* dA, int32_t* workspace, int B, int N, int E,
                                  int D, int Vb, int sorted_ready, hipStream_t s);

@@ -192,6 +192,77 @@ __global__ __launch_bounds__(kBlock) void bmm_message_typed_bwd_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// a4 forward over the same type-sorted segments, for any D <= 128 (the D = 32 MFMA kernel of layer_kernels.hip
+// keeps its own in-workgroup sort): A[type] sits in LDS with row stride D+1, so the lanes (output feature i) read
+// their rows without bank conflicts - the per-molecule kernel reads A[type][i][:] with a stride of D floats between
+// lanes, 64 cache lines per load.  Thread (edge lane, i) computes 4 edges at a time from one pass over its row.
+// Masked / out-of-range edges get zero rows from a separate pass (models/layers.py:114-115).
+// ---------------------------------------------------------------------------------------
+__global__ void zero_invalid_messages_kernel(const int32_t* __restrict__ conn, const int32_t* __restrict__ bond_ids,
+                                             float* __restrict__ m, int64_t BE, int N, int D, int Vb) {
+  const int64_t total = BE * D;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t be = t / D;
+    if (edge_type_or_neg(conn, bond_ids, be, N, Vb) < 0) m[t] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void bmm_message_typed_seg_kernel(
+    const float* __restrict__ h, const int32_t* __restrict__ conn, const float* __restrict__ A,
+    float* __restrict__ m_out, const int32_t* __restrict__ start, const int32_t* __restrict__ segbase,
+    const int32_t* __restrict__ order, int N, int E, int D, int Vb) {
+  extern __shared__ __align__(16) float smem[];
+  __shared__ int64_t outrow[kSeg];
+  const int seg = blockIdx.x;
+  if (seg >= segbase[Vb]) return;
+  int lo = 0, hi = Vb - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (segbase[mid] <= seg) lo = mid; else hi = mid - 1;
+  }
+  const int ty = lo;
+  const int p0 = start[ty] + (seg - segbase[ty]) * kSeg;
+  const int n = min(kSeg, start[ty + 1] - p0);
+  if (n <= 0) return;
+  const int tid = threadIdx.x;
+  const int LD = D + 1;
+  float* As = smem;              // D x (D+1)
+  float* xm = As + D * LD;       // kSeg x D, rows beyond n are zero
+  for (int t = tid; t < D * D; t += kBlock) As[(t / D) * LD + (t % D)] = A[(int64_t)ty * D * D + t];
+  for (int t = tid; t < kSeg * D; t += kBlock) {
+    const int e = t / D, c = t - e * D;
+    float v = 0.f;
+    if (e < n) {
+      const int64_t be = order[p0 + e];
+      v = h[((be / E) * N + conn[be * 2]) * D + c];
+      if (c == 0) outrow[e] = be;
+    }
+    xm[t] = v;
+  }
+  __syncthreads();
+  const int lanes = kBlock / D > 0 ? kBlock / D : 1;
+  if (tid < lanes * D) {
+    const int i = tid % D, el = tid / D;
+    const float* arow = As + i * LD;
+    for (int e0 = 4 * el; e0 < n; e0 += 4 * lanes) {
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      const float* x = xm + e0 * D;
+      for (int j = 0; j < D; ++j) {
+        const float w = arow[j];
+        a0 = fmaf(w, x[j], a0);
+        a1 = fmaf(w, x[D + j], a1);
+        a2 = fmaf(w, x[2 * D + j], a2);
+        a3 = fmaf(w, x[3 * D + j], a3);
+      }
+      m_out[outrow[e0] * D + i] = a0;
+      if (e0 + 1 < n) m_out[outrow[e0 + 1] * D + i] = a1;
+      if (e0 + 2 < n) m_out[outrow[e0 + 2] * D + i] = a2;
+      if (e0 + 3 < n) m_out[outrow[e0 + 3] * D + i] = a3;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // schedule A backward: A[v] = sum_k Tb[v,k] W[k]  =>  dW[k] = sum_v Tb[v,k] dA[v];  dTb[v,k] = <dA[v], W[k]>
 // ---------------------------------------------------------------------------------------
 __global__ void bond_type_matrices_bwd_w_kernel(const float* __restrict__ tb, const float* __restrict__ dA,
@@ -652,6 +723,48 @@ int launch_global_sum_pool_bwd(const float* dp, const int32_t* ids, float* dh, i
 
 int64_t bmm_message_typed_bwd_workspace_ints(int B, int E, int Vb) { return (int64_t)4 * (Vb + 1) + (int64_t)B * E; }
 
+// the batch's valid edges, counting-sorted by bond type, in `workspace` (layout at the kernels above)
+static int launch_edge_type_sort(const int32_t* bond_ids, const int32_t* conn, int32_t* workspace, int B, int N, int E,
+                                 int Vb, hipStream_t s) {
+  const int64_t BE = (int64_t)B * E;
+  int32_t* cnt = workspace;
+  int32_t* start = cnt + (Vb + 1);
+  int32_t* cursor = start + (Vb + 1);
+  int32_t* segbase = cursor + (Vb + 1);
+  int32_t* order = segbase + (Vb + 1);
+  // (a kernel, not hipMemsetAsync: the call must behave the same inside a captured hipGraph)
+  zero_ints_kernel<<<grid_for(Vb + 1), kBlock, 0, s>>>(cnt, Vb + 1);
+  if (int rc = check_launch("zero_ints")) return rc;
+  edge_type_hist_kernel<<<grid_for(BE), kBlock, 0, s>>>(conn, bond_ids, cnt, BE, N, Vb);
+  if (int rc = check_launch("edge_type_hist")) return rc;
+  edge_type_prefix_kernel<<<1, 64, 0, s>>>(cnt, start, cursor, segbase, Vb);
+  if (int rc = check_launch("edge_type_prefix")) return rc;
+  edge_type_scatter_kernel<<<grid_for(BE), kBlock, 0, s>>>(conn, bond_ids, cursor, order, BE, N, Vb);
+  return check_launch("edge_type_scatter");
+}
+
+int launch_bmm_message_typed_sorted(const float* h, const int32_t* bond_ids, const int32_t* conn, const float* A,
+                                    float* m, int32_t* workspace, int B, int N, int E, int D, int Vb, int sorted_ready,
+                                    hipStream_t s) {
+  if (Vb > kMaxTypes) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed_sorted: Vb=%d too large", Vb);
+  if (D > 128) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed_sorted: D=%d > 128", D);
+  const int64_t BE = (int64_t)B * E;
+  if (!sorted_ready)
+    if (int rc = launch_edge_type_sort(bond_ids, conn, workspace, B, N, E, Vb, s)) return rc;
+  zero_invalid_messages_kernel<<<grid_for(BE * D), kBlock, 0, s>>>(conn, bond_ids, m, BE, N, D, Vb);
+  if (int rc = check_launch("zero_invalid_messages")) return rc;
+  const int32_t* start = workspace + (Vb + 1);
+  const int32_t* segbase = workspace + 3 * (Vb + 1);
+  const int32_t* order = workspace + 4 * (Vb + 1);
+  const int64_t max_segs = (BE + kSeg - 1) / kSeg + Vb;
+  const size_t lds = sizeof(float) * ((size_t)D * (D + 1) + (size_t)kSeg * D);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)bmm_message_typed_seg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  bmm_message_typed_seg_kernel<<<(int)max_segs, kBlock, lds, s>>>(h, conn, A, m, start, segbase, order, N, E, D, Vb);
+  return check_launch("bmm_message_typed_seg");
+}
+
 int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn, const float* A,
                                  const float* dm, float* dh, float* dA, int32_t* workspace, int B, int N, int E,
                                  int D, int Vb, int sorted_ready, hipStream_t s) {
@@ -663,17 +776,8 @@ int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const 
   int32_t* cursor = start + (Vb + 1);
   int32_t* segbase = cursor + (Vb + 1);
   int32_t* order = segbase + (Vb + 1);
-  if (!sorted_ready) {  // the sort depends on (conn, bond_ids) only: the S layers of one ion share it
-    // (a kernel, not hipMemsetAsync: the call must behave the same inside a captured hipGraph)
-    zero_ints_kernel<<<grid_for(Vb + 1), kBlock, 0, s>>>(cnt, Vb + 1);
-    if (int rc = check_launch("zero_ints")) return rc;
-    edge_type_hist_kernel<<<grid_for(BE), kBlock, 0, s>>>(conn, bond_ids, cnt, BE, N, Vb);
-    if (int rc = check_launch("edge_type_hist")) return rc;
-    edge_type_prefix_kernel<<<1, 64, 0, s>>>(cnt, start, cursor, segbase, Vb);
-    if (int rc = check_launch("edge_type_prefix")) return rc;
-    edge_type_scatter_kernel<<<grid_for(BE), kBlock, 0, s>>>(conn, bond_ids, cursor, order, BE, N, Vb);
-    if (int rc = check_launch("edge_type_scatter")) return rc;
-  }
+  if (!sorted_ready)  // the sort depends on (conn, bond_ids) only: forward and backward of the S layers of an ion share it
+    if (int rc = launch_edge_type_sort(bond_ids, conn, workspace, B, N, E, Vb, s)) return rc;
   const int64_t max_segs = (BE + kSeg - 1) / kSeg + Vb;
   const size_t lds = sizeof(float) * ((size_t)D * D + 2 * (size_t)kSeg * D);
   const int acc = (D * D + kBlock - 1) / kBlock;

@@ -148,10 +148,36 @@ def bmm_message_typed(h, bond_ids, conn, type_mats):
     if DEBUG_VALIDATE:
         validate_indices(conn=conn, bond_ids=bond_ids, N=N, Vb=Vb)
     m = torch.empty(B, E, D, dtype=torch.float32, device=h.device)
+    lib = _lib.load()
     with torch.cuda.device(h.device):
-        check(_lib.load().impnn_bmm_message_typed(ptr(h), ptr(bond_ids), ptr(conn), ptr(type_mats), ptr(m), B, N,
-                                                  E, D, Vb, stream_ptr()))
+        if D != 32 and D <= 128 and E > 0 and B > 0:
+            # any other width: type-sorted segments with A[type] in LDS (the D = 32 kernel sorts inside its workgroups)
+            ws, ready = edge_sort_workspace(conn, bond_ids, B, E, Vb)
+            check(lib.impnn_bmm_message_typed_sorted(ptr(h), ptr(bond_ids), ptr(conn), ptr(type_mats), ptr(m), ptr(ws),
+                                                     ws.numel(), B, N, E, D, Vb, 1 if ready else 0, stream_ptr()))
+        else:
+            check(lib.impnn_bmm_message_typed(ptr(h), ptr(bond_ids), ptr(conn), ptr(type_mats), ptr(m), B, N,
+                                              E, D, Vb, stream_ptr()))
     return m
+
+
+def edge_sort_workspace(conn, bond_ids, B, E, Vb):
+    """Workspace of the by-bond-type edge sort for (conn, bond_ids) and whether it already holds that sort.
+    Inside an ``autograd.training_pass`` the workspace is kept on the connectivity tensor object, so the forward and
+    backward message kernels of all layers of one ion sort once; outside, every call gets a fresh workspace."""
+    from . import autograd
+    lib = _lib.load()
+    wsb = int(lib.impnn_bmm_message_typed_bwd_workspace_bytes(B, E, Vb))
+    pass_id = autograd.current_pass()
+    if pass_id is None:
+        return torch.empty(max(wsb, 4), dtype=torch.uint8, device=conn.device), False
+    key = (pass_id, conn._version, bond_ids.data_ptr(), bond_ids._version, Vb, wsb)
+    cached = getattr(conn, "_impnn_edge_sort", None)
+    if cached is not None and cached[0] == key:
+        return cached[1], True
+    ws = torch.empty(max(wsb, 4), dtype=torch.uint8, device=conn.device)
+    conn._impnn_edge_sort = (key, ws)
+    return ws, False
 
 
 def reduce_scatter_add(messages, tgt_idx, num_atoms):
