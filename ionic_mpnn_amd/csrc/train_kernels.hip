@@ -101,12 +101,23 @@ __global__ void zero_ints_kernel(int32_t* __restrict__ p, int n) {
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) p[t] = 0;
 }
 
-__global__ void edge_type_hist_kernel(const int32_t* __restrict__ conn, const int32_t* __restrict__ bond_ids,
-                                      int32_t* __restrict__ cnt, int64_t BE, int N, int Vb) {
-  for (int64_t be = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; be < BE; be += (int64_t)gridDim.x * blockDim.x) {
+// Histogram of the valid edges by type.  Each workgroup counts a contiguous slice in LDS first and touches the
+// global counters once per type it saw: with ~10^2 types and ~10^5 edges, per-edge global atomics serialise.
+__global__ __launch_bounds__(kBlock) void edge_type_hist_kernel(const int32_t* __restrict__ conn,
+                                                                const int32_t* __restrict__ bond_ids,
+                                                                int32_t* __restrict__ cnt, int64_t BE, int N, int Vb) {
+  __shared__ int32_t lh[kMaxTypes];
+  for (int t = threadIdx.x; t < Vb; t += kBlock) lh[t] = 0;
+  __syncthreads();
+  const int64_t per = (BE + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < BE ? lo + per : BE;
+  for (int64_t be = lo + threadIdx.x; be < hi; be += kBlock) {
     const int ty = edge_type_or_neg(conn, bond_ids, be, N, Vb);
-    if (ty >= 0) atomicAdd(&cnt[ty], 1);
+    if (ty >= 0) atomicAdd(&lh[ty], 1);
   }
+  __syncthreads();
+  for (int t = threadIdx.x; t < Vb; t += kBlock)
+    if (lh[t]) atomicAdd(&cnt[t], lh[t]);
 }
 
 // one workgroup: start[t] = exclusive prefix of cnt, cursor = start, segbase[t] = exclusive prefix of
@@ -128,12 +139,31 @@ __global__ void edge_type_prefix_kernel(const int32_t* __restrict__ cnt, int32_t
   }
 }
 
-__global__ void edge_type_scatter_kernel(const int32_t* __restrict__ conn, const int32_t* __restrict__ bond_ids,
-                                         int32_t* __restrict__ cursor, int32_t* __restrict__ order, int64_t BE, int N,
-                                         int Vb) {
-  for (int64_t be = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; be < BE; be += (int64_t)gridDim.x * blockDim.x) {
+// Scatter of the valid edges into their type's run: a workgroup counts its slice in LDS, reserves one range per type
+// with a single global atomic, and places its edges inside the reserved ranges with LDS atomics.
+__global__ __launch_bounds__(kBlock) void edge_type_scatter_kernel(const int32_t* __restrict__ conn,
+                                                                   const int32_t* __restrict__ bond_ids,
+                                                                   int32_t* __restrict__ cursor,
+                                                                   int32_t* __restrict__ order, int64_t BE, int N,
+                                                                   int Vb) {
+  __shared__ int32_t lh[kMaxTypes];  // count, then the next free position of the reserved range
+  for (int t = threadIdx.x; t < Vb; t += kBlock) lh[t] = 0;
+  __syncthreads();
+  const int64_t per = (BE + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < BE ? lo + per : BE;
+  for (int64_t be = lo + threadIdx.x; be < hi; be += kBlock) {
     const int ty = edge_type_or_neg(conn, bond_ids, be, N, Vb);
-    if (ty >= 0) order[atomicAdd(&cursor[ty], 1)] = (int32_t)be;
+    if (ty >= 0) atomicAdd(&lh[ty], 1);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < Vb; t += kBlock) {
+    const int c = lh[t];
+    lh[t] = c ? atomicAdd(&cursor[t], c) : 0;
+  }
+  __syncthreads();
+  for (int64_t be = lo + threadIdx.x; be < hi; be += kBlock) {
+    const int ty = edge_type_or_neg(conn, bond_ids, be, N, Vb);
+    if (ty >= 0) order[atomicAdd(&lh[ty], 1)] = (int32_t)be;
   }
 }
 
@@ -735,11 +765,12 @@ static int launch_edge_type_sort(const int32_t* bond_ids, const int32_t* conn, i
   // (a kernel, not hipMemsetAsync: the call must behave the same inside a captured hipGraph)
   zero_ints_kernel<<<grid_for(Vb + 1), kBlock, 0, s>>>(cnt, Vb + 1);
   if (int rc = check_launch("zero_ints")) return rc;
-  edge_type_hist_kernel<<<grid_for(BE), kBlock, 0, s>>>(conn, bond_ids, cnt, BE, N, Vb);
+  const int sort_grid = grid_for(BE / 8 + 1, 512);
+  edge_type_hist_kernel<<<sort_grid, kBlock, 0, s>>>(conn, bond_ids, cnt, BE, N, Vb);
   if (int rc = check_launch("edge_type_hist")) return rc;
   edge_type_prefix_kernel<<<1, 64, 0, s>>>(cnt, start, cursor, segbase, Vb);
   if (int rc = check_launch("edge_type_prefix")) return rc;
-  edge_type_scatter_kernel<<<grid_for(BE), kBlock, 0, s>>>(conn, bond_ids, cursor, order, BE, N, Vb);
+  edge_type_scatter_kernel<<<sort_grid, kBlock, 0, s>>>(conn, bond_ids, cursor, order, BE, N, Vb);
   return check_launch("edge_type_scatter");
 }
 

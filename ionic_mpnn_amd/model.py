@@ -322,7 +322,8 @@ class MPNNModel:
             with autograd.training_pass():
                 pc, pa = self.encode_pooled(inputs, fused=False)
                 return self.head(pc, pa, inputs.get("temperature"), differentiable=True)
-        with torch.no_grad():
+        from . import autograd
+        with torch.no_grad(), autograd.training_pass():  # (the scope also lets the layers of an ion share graph work)
             pc, pa = self.encode_pooled(inputs, fused=fused, trace=trace)
             return self.head(pc, pa, inputs.get("temperature"), trace=trace)
 
