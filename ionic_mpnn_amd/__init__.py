@@ -8,10 +8,10 @@ from . import data, synthetic, weights  # noqa: F401  (host-only modules)
 from .layers import (AddTwoTensors, BondMatrixMessage, ComputeLogEta, Dense, EmbeddedLookup, Embedding,  # noqa: F401
                      GatedUpdate, GlobalSumPool, GRUUpdate, Layer, Reduce, ScaleTemperature, SliceParamA,
                      SliceParamB, SliceParamC, register_keras_serializable, reset_uids)
-from .model import MPNNModel, build_melting_point_model, build_model  # noqa: F401
+from .model import MPNNModel, build_melting_point_model, build_model, load_model  # noqa: F401
 
 __all__ = [
     "BondMatrixMessage", "Reduce", "GatedUpdate", "GRUUpdate", "GlobalSumPool", "Embedding", "Dense",
     "AddTwoTensors", "SliceParamA", "SliceParamB", "SliceParamC", "ScaleTemperature", "ComputeLogEta",
-    "build_model", "build_melting_point_model", "MPNNModel",
+    "build_model", "build_melting_point_model", "MPNNModel", "load_model",
 ]

@@ -170,6 +170,11 @@ class MPNNModel:
         cfg = {k: v for k, v in self.get_config().items() if k != "layers"}
         np.savez(path, __config__=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), **arrays)
 
+    def save(self, path):
+        """model.save("models/viscosity_final.keras") (train_viscosity.py:354) - here the .npz of save_weights (config +
+        variables); the Keras zip/HDF5 container is not written."""
+        self.save_weights(path)
+
     @staticmethod
     def load_weight_file(path):
         """-> (config dict, weights dict) from a file written by save_weights (no pickle is involved)."""
@@ -408,9 +413,12 @@ class MPNNModel:
         rng = np.random.default_rng(seed)
         hist = train.History()
         callbacks = list(callbacks or [])
+        self.stop_training = False
         for cb in callbacks:
+            if hasattr(cb, "set_model"):
+                cb.set_model(self)
             if hasattr(cb, "on_train_begin"):
-                cb.on_train_begin(self)
+                cb.on_train_begin({})
         from . import dist as idist
         graphed = None
         use_graph = bool(graph) and not idist.is_distributed() and n >= batch_size
@@ -435,15 +443,14 @@ class MPNNModel:
             hist._log(epoch, logs)
             if verbose:
                 print(f"Epoch {epoch + 1}/{epochs} - " + " - ".join(f"{k}: {v:.4f}" for k, v in logs.items()), flush=True)
-            stop = False
             for cb in callbacks:
-                if hasattr(cb, "on_epoch_end") and cb.on_epoch_end(self, epoch, logs):
-                    stop = True
-            if stop:
+                if hasattr(cb, "on_epoch_end"):
+                    cb.on_epoch_end(epoch, logs)
+            if self.stop_training:
                 break
         for cb in callbacks:
             if hasattr(cb, "on_train_end"):
-                cb.on_train_end(self)
+                cb.on_train_end({})
         self.history = hist
         return hist
 
@@ -483,3 +490,13 @@ def build_melting_point_model(atom_vocab_size, bond_vocab_size, atom_dim=32, fp_
     """train_melting_point.py:137-215: bond embedding width = atom_dim**2 (:146)."""
     return MPNNModel("melting_point", atom_vocab_size, bond_vocab_size, atom_dim, atom_dim * atom_dim, fp_size,
                      mixing_size, num_steps, fp_l2=1e-5, device=device)
+
+
+def load_model(path, custom_objects=None, device=None):
+    """keras.models.load_model analogue for files written by MPNNModel.save / save_weights
+    (train_melting_point_transfer.py:78-93 passes custom_objects: accepted and ignored - the layer classes are
+    this package's own)."""
+    cfg, w = MPNNModel.load_weight_file(path)
+    m = MPNNModel.from_config(cfg, device=device)
+    m.load_weights(w)
+    return m

@@ -154,38 +154,59 @@ class History:
             self.history.setdefault(k, []).append(float(v))
 
 
-class EarlyStopping:
+class Callback:
+    """keras.callbacks.Callback protocol as the trainers use it (train_viscosity.py:112-132 subclasses it):
+    ``set_model`` is called once, then ``on_train_begin(logs)``, ``on_epoch_end(epoch, logs)`` per epoch and
+    ``on_train_end(logs)``; a callback stops training by setting ``self.model.stop_training = True``."""
+
+    def __init__(self):
+        self.model = None
+
+    def set_model(self, model):
+        self.model = model
+
+    def on_train_begin(self, logs=None):
+        pass
+
+    def on_epoch_end(self, epoch, logs=None):
+        pass
+
+    def on_train_end(self, logs=None):
+        pass
+
+
+class EarlyStopping(Callback):
     """keras.callbacks.EarlyStopping(monitor, patience, restore_best_weights) with mode "min"
     (train_viscosity.py:334)."""
 
     def __init__(self, monitor="val_loss", patience=0, restore_best_weights=False, min_delta=0.0):
+        super().__init__()
         self.monitor, self.patience, self.restore_best_weights = monitor, int(patience), bool(restore_best_weights)
         self.min_delta = abs(float(min_delta))
         self.best, self.wait, self.best_weights, self.stopped_epoch, self.best_epoch = np.inf, 0, None, 0, 0
 
-    def on_train_begin(self, model):
+    def on_train_begin(self, logs=None):
         self.best, self.wait, self.best_weights, self.stopped_epoch, self.best_epoch = np.inf, 0, None, 0, 0
 
-    def on_epoch_end(self, model, epoch, logs):
-        cur = logs.get(self.monitor)
+    def on_epoch_end(self, epoch, logs=None):
+        cur = (logs or {}).get(self.monitor)
         if cur is None:
-            return False
+            return
         if self.restore_best_weights and self.best_weights is None:
-            self.best_weights = model.state_dict()
+            self.best_weights = self.model.state_dict()
         self.wait += 1
         if cur < self.best - self.min_delta:
             self.best, self.best_epoch, self.wait = cur, epoch, 0
             if self.restore_best_weights:
-                self.best_weights = model.state_dict()
-            return False
+                self.best_weights = self.model.state_dict()
+            return
         if self.wait >= self.patience and epoch > 0:
             self.stopped_epoch = epoch
-            return True
-        return False
+            self.model.stop_training = True
 
-    def on_train_end(self, model):
+    def on_train_end(self, logs=None):
         if self.restore_best_weights and self.best_weights is not None:
-            model.load_weights(self.best_weights)
+            self.model.load_weights(self.best_weights)
 
 
 def mse(y_true, y_pred):

@@ -132,16 +132,28 @@ def test_early_stopping_and_history_host_logic():
             self.w = d["w"]
 
     m, es, hist = Fake(), train.EarlyStopping(monitor="val_loss", patience=2, restore_best_weights=True), train.History()
-    es.on_train_begin(m)
+    m.stop_training = False
+    es.set_model(m)
+    es.on_train_begin()
     stopped = None
     for epoch, vl in enumerate([3.0, 2.0, 2.5, 2.2, 1.9, 5.0]):
         m.w = epoch
         hist._log(epoch, {"loss": vl + 1, "val_loss": vl})
-        if es.on_epoch_end(m, epoch, {"val_loss": vl}):
+        es.on_epoch_end(epoch, {"val_loss": vl})
+        if m.stop_training:
             stopped = epoch
             break
-    es.on_train_end(m)
+    es.on_train_end()
     assert stopped == 3 and es.best == 2.0 and m.w == 1          # two epochs without improvement after epoch 1
     assert hist.history["val_loss"] == [3.0, 2.0, 2.5, 2.2] and hist.epoch == [0, 1, 2, 3]
+
+    class Selective(train.Callback):                              # the reference's own callback ports as is
+        def __init__(self):
+            super().__init__()
+            self.seen = []
+        def on_epoch_end(self, epoch, logs=None):
+            self.seen.append((epoch + 1, logs.get("loss", 0)))
+    sv = Selective(); sv.set_model(m); sv.on_epoch_end(0, {"loss": 1.5})
+    assert sv.seen == [(1, 1.5)] and sv.model is m
     a = train.Adam(1e-3, clipnorm=1.0)
     assert a.get_config()["clipnorm"] == 1.0 and a.get_config()["epsilon"] == 1e-7

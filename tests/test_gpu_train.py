@@ -240,6 +240,8 @@ def test_weight_file_round_trip(tmp_path):
     assert cfg["atom_dim"] == 16 and cfg["num_steps"] == 2 and "cat_gu_1/dense_z/kernel" in w
     m2 = MM.MPNNModel.from_config(cfg, device=DEV)
     m2.load_weights(path)
+    m3 = MM.load_model(path, custom_objects={"BondMatrixMessage": None}, device=DEV)   # keras.models.load_model analogue
+    assert np.array_equal(m.predict(inp), m3.predict(inp))
     assert [l.name for l in m2.layers] == [l.name for l in m.layers]
     assert np.array_equal(m.predict(inp), m2.predict(inp))
     lc = m.get_config()["layers"]
