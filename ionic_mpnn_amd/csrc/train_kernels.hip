@@ -541,6 +541,259 @@ __global__ __launch_bounds__(BS) void gated_update_bwd_kernel(
 #undef WR_T
 #undef WH_T
 
+// ---------------------------------------------------------------------------------------
+// a7 backward for D = 32 on the matrix cores (exact f32 products, v_mfma_f32_16x16x4_f32), the adjoint of
+// gated_update_d32_kernel in layer_kernels.hip with the same layout: 16 rows per wave and iteration, rows on the
+// MFMA N dimension (lane & 15), features on M, so every accumulator tile (feature 4*(lane>>4)+reg) is directly the
+// B operand of the next product.  The gate kernels sit in LDS twice: transposed ((gate, out) rows of 2D inputs,
+// stride 68) for the forward recompute, and as stored ((gate, in) rows of D outputs, stride 36) for the products
+// with the pre-activation gradients.  Outputs and partial sums are those of gated_update_bwd_kernel.
+// ---------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t ldv4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
+__device__ __forceinline__ void stv4(float* p, f32x4_t v) { *reinterpret_cast<f32x4_t*>(p) = v; }
+__device__ __forceinline__ f32x4_t mfma_f32(float a, float b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// sum over the 16 lanes of a DPP row (the rows of one feature quarter), result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, true));  // row_ror:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, true));  // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, true));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));  // row_ror:8
+  return v;
+}
+constexpr int kBwT = 68;  // stride of the transposed kernels (rows: gate*32 + out, cols: 2D inputs)
+constexpr int kBwN = 36;  // stride of the natural kernels (rows: gate*64 + in, cols: D outputs)
+
+__global__ __launch_bounds__(kBlock) void gated_update_bwd_d32_kernel(
+    const float* __restrict__ h, const float* __restrict__ agg, const float* __restrict__ Wz,
+    const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
+    const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma, float eps,
+    const float* __restrict__ dout, float* __restrict__ dh, float* __restrict__ dagg, float* __restrict__ dpre,
+    float* __restrict__ rh_out, float* __restrict__ small, int64_t rows) {
+  constexpr int D = 32;
+  extern __shared__ __align__(16) float smem[];
+  float* wt = smem;                       // 3*D rows x kBwT
+  float* wn = wt + 3 * D * kBwT;          // 3*2D rows x kBwN
+  float* wvec = wn + 3 * 2 * D * kBwN;    // bz | br | bh | gamma
+  float* red = wvec + 4 * D;              // 4 waves x 5 x D column sums
+  for (int t = threadIdx.x; t < 3 * 2 * D * D; t += kBlock) {
+    const int gate = t / (2 * D * D), rem = t - gate * 2 * D * D;
+    const int jj = rem / D, io = rem - jj * D;  // keras kernel (in = jj, out = io)
+    const float* Wg = gate == 0 ? Wz : (gate == 1 ? Wr : Wh);
+    const float w = Wg[rem];
+    wt[(gate * D + io) * kBwT + jj] = w;
+    wn[(gate * 2 * D + jj) * kBwN + io] = w;
+  }
+  for (int t = threadIdx.x; t < 4 * D; t += kBlock) {
+    const int v = t / D, i = t - v * D;
+    wvec[t] = (v == 0 ? bz : v == 1 ? br : v == 2 ? bh : gamma)[i];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, a = lane & 15, q = lane >> 4;
+  const int64_t ntiles = (rows + 15) >> 4;
+  const int64_t wave_id = (int64_t)blockIdx.x * (kBlock >> 6) + wave;
+  const int64_t nwaves = (int64_t)gridDim.x * (kBlock >> 6);
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t s_bz[2] = {zero4, zero4}, s_br[2] = {zero4, zero4}, s_bh[2] = {zero4, zero4};
+  f32x4_t s_dg[2] = {zero4, zero4}, s_db[2] = {zero4, zero4};
+  const f32x4_t gm0 = ldv4(wvec + 3 * D + 4 * q), gm1 = ldv4(wvec + 3 * D + 16 + 4 * q);
+  for (int64_t tile = wave_id; tile < ntiles; tile += nwaves) {
+    const int64_t row = tile * 16 + a;
+    const bool live = row < rows;
+    const int64_t rl = live ? row : rows - 1;  // clamped load address; stores and sums are masked through dy = 0
+    const f32x4_t h0 = ldv4(h + rl * D + 4 * q), h1 = ldv4(h + rl * D + 16 + 4 * q);
+    const f32x4_t a0 = ldv4(agg + rl * D + 4 * q), a1 = ldv4(agg + rl * D + 16 + 4 * q);
+    f32x4_t dy0 = ldv4(dout + rl * D + 4 * q), dy1 = ldv4(dout + rl * D + 16 + 4 * q);
+    if (!live) {
+      dy0 = zero4;
+      dy1 = zero4;
+    }
+    // ---- forward recompute (as gated_update_d32_kernel)
+    f32x4_t z0 = ldv4(wvec + 4 * q), z1 = ldv4(wvec + 16 + 4 * q);
+    f32x4_t r0 = ldv4(wvec + D + 4 * q), r1 = ldv4(wvec + D + 16 + 4 * q);
+    f32x4_t t0 = ldv4(wvec + 2 * D + 4 * q), t1 = ldv4(wvec + 2 * D + 16 + 4 * q);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int col = 32 * half + 16 * u + 4 * q;
+        const f32x4_t Az0 = ldv4(wt + (0 * D + a) * kBwT + col), Az1 = ldv4(wt + (0 * D + 16 + a) * kBwT + col);
+        const f32x4_t Ar0 = ldv4(wt + (1 * D + a) * kBwT + col), Ar1 = ldv4(wt + (1 * D + 16 + a) * kBwT + col);
+        const f32x4_t Bv = half == 0 ? (u == 0 ? h0 : h1) : (u == 0 ? a0 : a1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          z0 = mfma_f32(Az0[r], Bv[r], z0);
+          z1 = mfma_f32(Az1[r], Bv[r], z1);
+          r0 = mfma_f32(Ar0[r], Bv[r], r0);
+          r1 = mfma_f32(Ar1[r], Bv[r], r1);
+        }
+      }
+    }
+    f32x4_t rh0, rh1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      z0[i] = sigmoid_exact(z0[i]);
+      z1[i] = sigmoid_exact(z1[i]);
+      r0[i] = sigmoid_exact(r0[i]);
+      r1[i] = sigmoid_exact(r1[i]);
+      rh0[i] = r0[i] * h0[i];
+      rh1[i] = r1[i] * h1[i];
+    }
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int col = 32 * half + 16 * u + 4 * q;
+        const f32x4_t Ah0 = ldv4(wt + (2 * D + a) * kBwT + col), Ah1 = ldv4(wt + (2 * D + 16 + a) * kBwT + col);
+        const f32x4_t Bv = half == 0 ? (u == 0 ? rh0 : rh1) : (u == 0 ? a0 : a1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          t0 = mfma_f32(Ah0[r], Bv[r], t0);
+          t1 = mfma_f32(Ah1[r], Bv[r], t1);
+        }
+      }
+    }
+    f32x4_t n0, n1;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      t0[i] = tanhf(t0[i]);
+      t1[i] = tanhf(t1[i]);
+      n0[i] = fmaf(z0[i], t0[i] - h0[i], h0[i]);
+      n1[i] = fmaf(z1[i], t1[i] - h1[i], h1[i]);
+      sum += n0[i] + n1[i];
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float mean = sum * (1.0f / D);
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      n0[i] -= mean;
+      n1[i] -= mean;
+      var = fmaf(n0[i], n0[i], var);
+      var = fmaf(n1[i], n1[i], var);
+    }
+    var += __shfl_xor(var, 16);
+    var += __shfl_xor(var, 32);
+    const float inv = 1.0f / sqrtf(var * (1.0f / D) + eps);
+    // ---- LayerNorm backward
+    f32x4_t dx0, dx1;
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      n0[i] *= inv;  // x-hat
+      n1[i] *= inv;
+      dx0[i] = dy0[i] * gm0[i];
+      dx1[i] = dy1[i] * gm1[i];
+      m1 += dx0[i] + dx1[i];
+      m2 = fmaf(dx0[i], n0[i], m2);
+      m2 = fmaf(dx1[i], n1[i], m2);
+      s_dg[0][i] = fmaf(dy0[i], n0[i], s_dg[0][i]);
+      s_dg[1][i] = fmaf(dy1[i], n1[i], s_dg[1][i]);
+      s_db[0][i] += dy0[i];
+      s_db[1][i] += dy1[i];
+    }
+    m1 += __shfl_xor(m1, 16);
+    m1 += __shfl_xor(m1, 32);
+    m2 += __shfl_xor(m2, 16);
+    m2 += __shfl_xor(m2, 32);
+    m1 *= (1.0f / D);
+    m2 *= (1.0f / D);
+    f32x4_t dzp0, dzp1, dtp0, dtp1, dh0, dh1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float dn0 = inv * (dx0[i] - m1 - n0[i] * m2), dn1 = inv * (dx1[i] - m1 - n1[i] * m2);
+      dzp0[i] = dn0 * (t0[i] - h0[i]) * z0[i] * (1.0f - z0[i]);
+      dzp1[i] = dn1 * (t1[i] - h1[i]) * z1[i] * (1.0f - z1[i]);
+      dtp0[i] = dn0 * z0[i] * (1.0f - t0[i] * t0[i]);
+      dtp1[i] = dn1 * z1[i] * (1.0f - t1[i] * t1[i]);
+      dh0[i] = dy0[i] + dn0 * (1.0f - z0[i]);
+      dh1[i] = dy1[i] + dn1 * (1.0f - z1[i]);
+    }
+    // ---- dc2 = Wh dtp : rows 0..31 of Wh act on r*h, rows 32..63 on agg
+    f32x4_t lo0 = zero4, lo1 = zero4, hi0 = zero4, hi1 = zero4;
+    const float* whn = wn + 2 * 2 * D * kBwN;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int col = 16 * u + 4 * q;
+      const f32x4_t A0 = ldv4(whn + (a) * kBwN + col), A1 = ldv4(whn + (16 + a) * kBwN + col);
+      const f32x4_t A2 = ldv4(whn + (32 + a) * kBwN + col), A3 = ldv4(whn + (48 + a) * kBwN + col);
+      const f32x4_t Bv = u == 0 ? dtp0 : dtp1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        lo0 = mfma_f32(A0[r], Bv[r], lo0);
+        lo1 = mfma_f32(A1[r], Bv[r], lo1);
+        hi0 = mfma_f32(A2[r], Bv[r], hi0);
+        hi1 = mfma_f32(A3[r], Bv[r], hi1);
+      }
+    }
+    f32x4_t drp0, drp1, da0 = hi0, da1 = hi1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      drp0[i] = lo0[i] * h0[i] * r0[i] * (1.0f - r0[i]);
+      drp1[i] = lo1[i] * h1[i] * r1[i] * (1.0f - r1[i]);
+      dh0[i] = fmaf(lo0[i], r0[i], dh0[i]);
+      dh1[i] = fmaf(lo1[i], r1[i], dh1[i]);
+      s_bz[0][i] += dzp0[i]; s_bz[1][i] += dzp1[i];
+      s_br[0][i] += drp0[i]; s_br[1][i] += drp1[i];
+      s_bh[0][i] += dtp0[i]; s_bh[1][i] += dtp1[i];
+    }
+    // ---- dc = Wz dzp + Wr drp
+    lo0 = zero4; lo1 = zero4; hi0 = zero4; hi1 = zero4;
+#pragma unroll
+    for (int gsel = 0; gsel < 2; ++gsel) {
+      const float* wg = wn + gsel * 2 * D * kBwN;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int col = 16 * u + 4 * q;
+        const f32x4_t A0 = ldv4(wg + (a) * kBwN + col), A1 = ldv4(wg + (16 + a) * kBwN + col);
+        const f32x4_t A2 = ldv4(wg + (32 + a) * kBwN + col), A3 = ldv4(wg + (48 + a) * kBwN + col);
+        const f32x4_t Bv = gsel == 0 ? (u == 0 ? dzp0 : dzp1) : (u == 0 ? drp0 : drp1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          lo0 = mfma_f32(A0[r], Bv[r], lo0);
+          lo1 = mfma_f32(A1[r], Bv[r], lo1);
+          hi0 = mfma_f32(A2[r], Bv[r], hi0);
+          hi1 = mfma_f32(A3[r], Bv[r], hi1);
+        }
+      }
+    }
+    if (live) {
+      stv4(dh + row * D + 4 * q, dh0 + lo0);
+      stv4(dh + row * D + 16 + 4 * q, dh1 + lo1);
+      stv4(dagg + row * D + 4 * q, da0 + hi0);
+      stv4(dagg + row * D + 16 + 4 * q, da1 + hi1);
+      float* dp = dpre + row * 3 * D;
+      stv4(dp + 4 * q, dzp0);
+      stv4(dp + 16 + 4 * q, dzp1);
+      stv4(dp + D + 4 * q, drp0);
+      stv4(dp + D + 16 + 4 * q, drp1);
+      stv4(dp + 2 * D + 4 * q, dtp0);
+      stv4(dp + 2 * D + 16 + 4 * q, dtp1);
+      stv4(rh_out + row * D + 4 * q, rh0);
+      stv4(rh_out + row * D + 16 + 4 * q, rh1);
+    }
+  }
+  // ---- column sums: over the 16 rows of a DPP row, then over the 4 waves (fixed order)
+  f32x4_t* sums[5] = {s_bz, s_br, s_bh, s_dg, s_db};
+#pragma unroll
+  for (int w5 = 0; w5 < 5; ++w5)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float v = row16_sum(sums[w5][blk][i]);
+        if (a == 0) red[(wave * 5 + w5) * D + 16 * blk + 4 * q + i] = v;
+      }
+  __syncthreads();
+  float* mine = small + (int64_t)blockIdx.x * 5 * D;
+  for (int t = threadIdx.x; t < 5 * D; t += kBlock)
+    mine[t] = (red[t] + red[5 * D + t]) + (red[10 * D + t] + red[15 * D + t]);
+}
+
 // WT = [Wz^T | Wr^T | Wh^T] (each D x 2D) for the large-D variant above (32x32 LDS tiles)
 __global__ void transpose3_kernel(const float* __restrict__ Wz, const float* __restrict__ Wr,
                                   const float* __restrict__ Wh, float* __restrict__ WT, int D) {
@@ -899,7 +1152,17 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   size_t lds = sizeof(float) * ((size_t)10 * R * D + 4 * R);
   if (lds < sizeof(float) * 5 * kBlock) lds = sizeof(float) * 5 * kBlock;
   const size_t wlds = sizeof(float) * (size_t)3 * 2 * D * (D + 1);
-  if (lds + wlds <= 120 * 1024) {
+  const bool al16 = ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(agg) | reinterpret_cast<uintptr_t>(dout) |
+                      reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(dagg) |
+                      reinterpret_cast<uintptr_t>(workspace)) & 15u) == 0;
+  if (D == 32 && al16) {
+    const size_t l32 = sizeof(float) * ((size_t)3 * 32 * kBwT + 3 * 64 * kBwN + 4 * 32 + 4 * 5 * 32);
+    if (l32 > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)gated_update_bwd_d32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)l32);
+    gated_update_bwd_d32_kernel<<<nblk, kBlock, l32, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, dagg, dpre,
+                                                         rh, small, rows);
+  } else if (lds + wlds <= 120 * 1024) {
     lds += wlds;
     if (lds > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)gated_update_bwd_kernel<true, kBlock>,

@@ -55,7 +55,7 @@ def test_message_reduce_backward(D, K):
     close(tbg.grad, tbo.grad, what="dbond_table")
 
 
-@pytest.mark.parametrize("D,rows", [(8, 37), (32, 301), (128, 19)])
+@pytest.mark.parametrize("D,rows", [(8, 37), (32, 301), (32, 70001), (64, 1500), (128, 19)])
 def test_gated_update_backward(D, rows):
     rng = np.random.default_rng(D + 1)
     names = ["Wz", "bz", "Wr", "br", "Wh", "bh", "gamma", "beta"]
