@@ -13,6 +13,13 @@ constexpr int kBlock = 256;
 
 __device__ __forceinline__ float sigmoid_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t ldv4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
+__device__ __forceinline__ void stv4(float* p, f32x4_t v) { *reinterpret_cast<f32x4_t*>(p) = v; }
+__device__ __forceinline__ f32x4_t mfma_f32(float a, float b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
 // ---------------------------------------------------------------------------------------
 // a1/a2 backward: dtable[ids[r], :] += dout[r, :]   (float atomics: rows of one id meet in any order).
 // Vocabularies are small (~10^2 rows), so thousands of rows collide on the same table row: when the table
@@ -292,6 +299,59 @@ __global__ __launch_bounds__(kBlock) void bmm_message_typed_seg_kernel(
   }
 }
 
+// The same on the matrix cores for D a multiple of 16 (exact f32 products): per segment the GEMM
+// m^T (D x 64) = A[type] (D x D) * x^T (D x 64) in 16x16 output tiles, K index ordered as 16u + 4q + r so that one
+// 16-byte LDS read per lane feeds four MFMA steps of both operands.  Wave w owns the output tiles w, w+4, ...
+__global__ __launch_bounds__(kBlock) void bmm_message_typed_seg_mfma_kernel(
+    const float* __restrict__ h, const int32_t* __restrict__ conn, const float* __restrict__ A,
+    float* __restrict__ m_out, const int32_t* __restrict__ start, const int32_t* __restrict__ segbase,
+    const int32_t* __restrict__ order, int N, int E, int D, int Vb) {
+  extern __shared__ __align__(16) float smem[];
+  __shared__ int64_t outrow[kSeg];
+  const int seg = blockIdx.x;
+  if (seg >= segbase[Vb]) return;
+  int lo = 0, hi = Vb - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (segbase[mid] <= seg) lo = mid; else hi = mid - 1;
+  }
+  const int ty = lo;
+  const int p0 = start[ty] + (seg - segbase[ty]) * kSeg;
+  const int n = min(kSeg, start[ty + 1] - p0);
+  if (n <= 0) return;
+  const int tid = threadIdx.x;
+  const int LD = D + 4;            // 16-byte aligned rows, bank-staggered
+  float* As = smem;                // D x LD
+  float* xm = As + D * LD;         // kSeg x LD, rows beyond n are zero
+  for (int t = tid; t < D * D; t += kBlock) As[(t / D) * LD + (t % D)] = A[(int64_t)ty * D * D + t];
+  for (int t = tid; t < kSeg * D; t += kBlock) {
+    const int e = t / D, c = t - e * D;
+    float v = 0.f;
+    if (e < n) {
+      const int64_t be = order[p0 + e];
+      v = h[((be / E) * N + conn[be * 2]) * D + c];
+      if (c == 0) outrow[e] = be;
+    }
+    xm[e * LD + c] = v;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6, a = lane & 15, q = lane >> 4;
+  const int mt = D >> 4, et = (n + 15) >> 4;          // output tiles: features x edges
+  for (int tile = wave; tile < mt * et; tile += kBlock >> 6) {
+    const int T = tile % mt, Et = tile / mt;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const float* arow = As + (16 * T + a) * LD + 4 * q;
+    const float* xrow = xm + (16 * Et + a) * LD + 4 * q;
+    for (int u = 0; u < mt; ++u) {
+      const f32x4_t av = ldv4(arow + 16 * u), xv = ldv4(xrow + 16 * u);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc = mfma_f32(av[r], xv[r], acc);
+    }
+    const int e = 16 * Et + a;                        // accumulator: feature 16T + 4q + reg of edge e
+    if (e < n) stv4(m_out + outrow[e] * D + 16 * T + 4 * q, acc);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // schedule A backward: A[v] = sum_k Tb[v,k] W[k]  =>  dW[k] = sum_v Tb[v,k] dA[v];  dTb[v,k] = <dA[v], W[k]>
 // ---------------------------------------------------------------------------------------
@@ -549,12 +609,6 @@ __global__ __launch_bounds__(BS) void gated_update_bwd_kernel(
 // stride 68) for the forward recompute, and as stored ((gate, in) rows of D outputs, stride 36) for the products
 // with the pre-activation gradients.  Outputs and partial sums are those of gated_update_bwd_kernel.
 // ---------------------------------------------------------------------------------------
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4_t ldv4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
-__device__ __forceinline__ void stv4(float* p, f32x4_t v) { *reinterpret_cast<f32x4_t*>(p) = v; }
-__device__ __forceinline__ f32x4_t mfma_f32(float a, float b, f32x4_t c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
 // sum over the 16 lanes of a DPP row (the rows of one feature quarter), result in every lane of the row
 __device__ __forceinline__ float row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, true));  // row_ror:1
@@ -1041,6 +1095,15 @@ int launch_bmm_message_typed_sorted(const float* h, const int32_t* bond_ids, con
   const int32_t* segbase = workspace + 3 * (Vb + 1);
   const int32_t* order = workspace + 4 * (Vb + 1);
   const int64_t max_segs = (BE + kSeg - 1) / kSeg + Vb;
+  if (D % 16 == 0 && (reinterpret_cast<uintptr_t>(m) & 15u) == 0) {
+    const size_t lm = sizeof(float) * ((size_t)D * (D + 4) + (size_t)kSeg * (D + 4));
+    if (lm > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)bmm_message_typed_seg_mfma_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
+    bmm_message_typed_seg_mfma_kernel<<<(int)max_segs, kBlock, lm, s>>>(h, conn, A, m, start, segbase, order, N, E, D,
+                                                                        Vb);
+    return check_launch("bmm_message_typed_seg_mfma");
+  }
   const size_t lds = sizeof(float) * ((size_t)D * (D + 1) + (size_t)kSeg * D);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)bmm_message_typed_seg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
