@@ -556,6 +556,131 @@ __global__ __launch_bounds__(256) void gated_update_d32_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// a7 for wider states (D a multiple of 16, 48 <= D <= 128) on the matrix cores, exact f32 products.
+// A workgroup owns 64 rows (wave w: rows 16w..16w+15) for which c = [h | agg] and r*h stay in LDS; the gate kernels
+// (3 x 2D x D floats: 393 KB at D = 128) stream through LDS in slices of 16 input rows.  Orientation
+// out (rows x features) = c (rows x 2D) W (2D x D): rows on the MFMA M dimension, features on N, so the keras
+// kernels are read as stored.  K index ordered 16u + 4q + r: one 16-byte LDS read of c feeds four steps.
+// Row reductions of LayerNorm: 16-lane DPP rows (features) x the feature tiles in registers.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float row16_sum_f(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));
+  return v;
+}
+
+template <int NT>  // NT = D / 16 feature tiles
+__global__ __launch_bounds__(256) void gated_update_wide_kernel(
+    const float* __restrict__ h, const float* __restrict__ agg, const float* __restrict__ Wz,
+    const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
+    const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float* __restrict__ out, int64_t rows) {
+  constexpr int D = 16 * NT, LDC = 2 * D + 4, LDR = D + 4, LDW = 2 * D + 16;
+  extern __shared__ __align__(16) float smem[];
+  float* cs = smem;                 // 64 x LDC : [h | agg]
+  float* rhs = cs + 64 * LDC;       // 64 x LDR : r * h
+  float* ws = rhs + 64 * LDR;       // 16 x LDW : slice of 16 input rows of the gate kernels
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = lane & 15, q = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  for (int t = tid; t < 64 * D; t += 256) {
+    const int r = t / D, c = t - r * D;
+    const bool in = row0 + r < rows;
+    cs[r * LDC + c] = in ? h[(row0 + r) * D + c] : 0.f;
+    cs[r * LDC + D + c] = in ? agg[(row0 + r) * D + c] : 0.f;
+  }
+  f32x4_t z[NT], rg[NT];
+#pragma unroll
+  for (int T = 0; T < NT; ++T) {
+    const float b0 = bz[16 * T + a], b1 = br[16 * T + a];
+    z[T] = f32x4_t{b0, b0, b0, b0};
+    rg[T] = f32x4_t{b1, b1, b1, b1};
+  }
+  const float* crow = cs + (16 * wave + a) * LDC + 4 * q;
+  for (int u = 0; u < 2 * NT; ++u) {
+    __syncthreads();
+    for (int t = tid; t < 16 * 2 * D; t += 256) {
+      const int jj = t / (2 * D), c = t - jj * 2 * D;
+      ws[jj * LDW + c] = c < D ? Wz[(int64_t)(16 * u + jj) * D + c] : Wr[(int64_t)(16 * u + jj) * D + c - D];
+    }
+    __syncthreads();
+    const f32x4_t av = ldv4(crow + 16 * u);
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        z[T] = mfma_f32(av[r], ws[(4 * q + r) * LDW + 16 * T + a], z[T]);
+        rg[T] = mfma_f32(av[r], ws[(4 * q + r) * LDW + D + 16 * T + a], rg[T]);
+      }
+  }
+  // z, r -> sigmoid; r * h into LDS (every wave only touches its own 16 rows)
+#pragma unroll
+  for (int T = 0; T < NT; ++T)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int rl = 16 * wave + 4 * q + g, f = 16 * T + a;
+      z[T][g] = sigmoidf_(z[T][g]);
+      rhs[rl * LDR + f] = sigmoidf_(rg[T][g]) * cs[rl * LDC + f];
+    }
+  f32x4_t tt[NT];
+#pragma unroll
+  for (int T = 0; T < NT; ++T) {
+    const float b2 = bh[16 * T + a];
+    tt[T] = f32x4_t{b2, b2, b2, b2};
+  }
+  const float* rrow = rhs + (16 * wave + a) * LDR + 4 * q;
+  for (int u = 0; u < 2 * NT; ++u) {
+    __syncthreads();
+    for (int t = tid; t < 16 * D; t += 256) {
+      const int jj = t / D, c = t - jj * D;
+      ws[jj * LDW + c] = Wh[(int64_t)(16 * u + jj) * D + c];
+    }
+    __syncthreads();
+    const f32x4_t av = u < NT ? ldv4(rrow + 16 * u) : ldv4(crow + 16 * u);  // [r*h | agg]
+#pragma unroll
+    for (int T = 0; T < NT; ++T)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tt[T] = mfma_f32(av[r], ws[(4 * q + r) * LDW + 16 * T + a], tt[T]);
+  }
+  // blend, LayerNorm over the D features of each row, residual
+  float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int T = 0; T < NT; ++T)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float hv = cs[(16 * wave + 4 * q + g) * LDC + 16 * T + a];
+      const float n = (1.0f - z[T][g]) * hv + z[T][g] * tanhf(tt[T][g]);
+      tt[T][g] = n;
+      sum[g] += n;
+    }
+  float mean[4], inv[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) mean[g] = row16_sum_f(sum[g]) * (1.0f / D);
+  float var[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int T = 0; T < NT; ++T)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float d = tt[T][g] - mean[g];
+      var[g] = fmaf(d, d, var[g]);
+    }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) inv[g] = 1.0f / sqrtf(row16_sum_f(var[g]) * (1.0f / D) + eps);
+#pragma unroll
+  for (int T = 0; T < NT; ++T) {
+    const int f = 16 * T + a;
+    const float gm = gamma[f], bt = beta[f];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int rl = 16 * wave + 4 * q + g;
+      if (row0 + rl < rows)
+        out[(row0 + rl) * D + f] = (tt[T][g] - mean[g]) * inv[g] * gm + bt + cs[rl * LDC + f];
+    }
+  }
+}
+
 // a8  GlobalSumPool.call (models/layers.py:161-164)
 __global__ void global_sum_pool_kernel(const float* __restrict__ h, const int32_t* __restrict__ ids,
                                        float* __restrict__ out, int B, int N, int D) {
@@ -785,6 +910,27 @@ int launch_gated_update(const float* h, const float* agg, const float* Wz, const
     if (blocks > 256 * 4) blocks = 256 * 4;  // grid-stride: the weight transpose is paid once per workgroup
     gated_update_d32_kernel<<<(unsigned)blocks, 256, 0, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, out, rows);
     return check_launch("gated_update_d32");
+  }
+  if (D % 16 == 0 && D >= 48 && D <= 128) {  // matrix cores; the kernels stream through LDS in 16-row slices
+    const size_t lw = sizeof(float) * ((size_t)64 * (2 * D + 4) + 64 * (D + 4) + 16 * (2 * D + 16));
+    const unsigned blocks = (unsigned)((rows + 63) / 64);
+#define WIDE(NT_)                                                                                                  \
+    do {                                                                                                            \
+      if (lw > 48 * 1024)                                                                                           \
+        (void)hipFuncSetAttribute((const void*)gated_update_wide_kernel<NT_>,                                       \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);                             \
+      gated_update_wide_kernel<NT_><<<blocks, 256, lw, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, out, rows); \
+      return check_launch("gated_update_wide");                                                                     \
+    } while (0)
+    switch (D / 16) {
+      case 3: WIDE(3);
+      case 4: WIDE(4);
+      case 5: WIDE(5);
+      case 6: WIDE(6);
+      case 7: WIDE(7);
+      case 8: WIDE(8);
+    }
+#undef WIDE
   }
   if (D > kBlock) return fail(IMPNN_E_UNSUPPORTED, "gated_update: D=%d too large", D);
   const int G = kBlock / D;
