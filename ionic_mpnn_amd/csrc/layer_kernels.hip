@@ -578,11 +578,12 @@ __global__ __launch_bounds__(256) void gated_update_wide_kernel(
     const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
     const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float* __restrict__ out, int64_t rows) {
-  constexpr int D = 16 * NT, LDC = 2 * D + 4, LDR = D + 4, LDW = 2 * D + 16;
+  constexpr int D = 16 * NT, LDC = 2 * D + 4, LDR = D + 4;
+  constexpr int LDW = 2 * D;  // slice layout: element (input row 4*qq + r, column c) at ((qq * LDW + c) * 4 + r)
   extern __shared__ __align__(16) float smem[];
   float* cs = smem;                 // 64 x LDC : [h | agg]
   float* rhs = cs + 64 * LDC;       // 64 x LDR : r * h
-  float* ws = rhs + 64 * LDR;       // 16 x LDW : slice of 16 input rows of the gate kernels
+  float* ws = rhs + 64 * LDR;       // 2 x 16 x LDW : slices of 16 input rows of the gate kernels, double-buffered
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = lane & 15, q = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * 64;
   for (int t = tid; t < 64 * D; t += 256) {
@@ -599,21 +600,42 @@ __global__ __launch_bounds__(256) void gated_update_wide_kernel(
     rg[T] = f32x4_t{b1, b1, b1, b1};
   }
   const float* crow = cs + (16 * wave + a) * LDC + 4 * q;
-  for (int u = 0; u < 2 * NT; ++u) {
-    __syncthreads();
-    for (int t = tid; t < 16 * 2 * D; t += 256) {
-      const int jj = t / (2 * D), c = t - jj * 2 * D;
-      ws[jj * LDW + c] = c < D ? Wz[(int64_t)(16 * u + jj) * D + c] : Wr[(int64_t)(16 * u + jj) * D + c - D];
+  // kernel slices: global -> registers one slice ahead (in flight under the MFMAs) -> the other LDS buffer
+  constexpr int kP1 = 16 * 2 * D / 256, kP2 = 16 * D / 256;
+  float pre[kP1];
+  auto fetch1 = [&](int u) {
+#pragma unroll
+    for (int i = 0; i < kP1; ++i) {
+      const int t = tid + 256 * i, jj = t / (2 * D), c = t - jj * 2 * D;
+      pre[i] = c < D ? Wz[(int64_t)(16 * u + jj) * D + c] : Wr[(int64_t)(16 * u + jj) * D + c - D];
     }
-    __syncthreads();
+  };
+  auto park1 = [&](float* dst) {
+#pragma unroll
+    for (int i = 0; i < kP1; ++i) {
+      const int t = tid + 256 * i, jj = t / (2 * D), c = t - jj * 2 * D;
+      dst[(((jj >> 2) * LDW + c) << 2) + (jj & 3)] = pre[i];
+    }
+  };
+  fetch1(0);
+  park1(ws);
+  __syncthreads();
+  for (int u = 0; u < 2 * NT; ++u) {
+    float* cur = ws + (u & 1) * 16 * LDW;
+    float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
+    if (u + 1 < 2 * NT) fetch1(u + 1);
     const f32x4_t av = ldv4(crow + 16 * u);
 #pragma unroll
-    for (int T = 0; T < NT; ++T)
+    for (int T = 0; T < NT; ++T) {
+      const f32x4_t bzv = ldv4(cur + ((q * LDW + 16 * T + a) << 2)), brv = ldv4(cur + ((q * LDW + D + 16 * T + a) << 2));
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        z[T] = mfma_f32(av[r], ws[(4 * q + r) * LDW + 16 * T + a], z[T]);
-        rg[T] = mfma_f32(av[r], ws[(4 * q + r) * LDW + D + 16 * T + a], rg[T]);
+        z[T] = mfma_f32(av[r], bzv[r], z[T]);
+        rg[T] = mfma_f32(av[r], brv[r], rg[T]);
       }
+    }
+    if (u + 1 < 2 * NT) park1(nxt);  // nxt was last read two iterations ago: the barrier below orders it
+    __syncthreads();
   }
   // z, r -> sigmoid; r * h into LDS (every wave only touches its own 16 rows)
 #pragma unroll
@@ -631,18 +653,36 @@ __global__ __launch_bounds__(256) void gated_update_wide_kernel(
     tt[T] = f32x4_t{b2, b2, b2, b2};
   }
   const float* rrow = rhs + (16 * wave + a) * LDR + 4 * q;
-  for (int u = 0; u < 2 * NT; ++u) {
-    __syncthreads();
-    for (int t = tid; t < 16 * D; t += 256) {
-      const int jj = t / D, c = t - jj * D;
-      ws[jj * LDW + c] = Wh[(int64_t)(16 * u + jj) * D + c];
+  auto fetch2 = [&](int u) {
+#pragma unroll
+    for (int i = 0; i < kP2; ++i) {
+      const int t = tid + 256 * i, jj = t / D, c = t - jj * D;
+      pre[i] = Wh[(int64_t)(16 * u + jj) * D + c];
     }
-    __syncthreads();
+  };
+  auto park2 = [&](float* dst) {
+#pragma unroll
+    for (int i = 0; i < kP2; ++i) {
+      const int t = tid + 256 * i, jj = t / D, c = t - jj * D;
+      dst[(((jj >> 2) * LDW + c) << 2) + (jj & 3)] = pre[i];
+    }
+  };
+  fetch2(0);
+  park2(ws);
+  __syncthreads();
+  for (int u = 0; u < 2 * NT; ++u) {
+    float* cur = ws + (u & 1) * 16 * LDW;
+    float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
+    if (u + 1 < 2 * NT) fetch2(u + 1);
     const f32x4_t av = u < NT ? ldv4(rrow + 16 * u) : ldv4(crow + 16 * u);  // [r*h | agg]
 #pragma unroll
-    for (int T = 0; T < NT; ++T)
+    for (int T = 0; T < NT; ++T) {
+      const f32x4_t bv = ldv4(cur + ((q * LDW + 16 * T + a) << 2));
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tt[T] = mfma_f32(av[r], ws[(4 * q + r) * LDW + 16 * T + a], tt[T]);
+      for (int r = 0; r < 4; ++r) tt[T] = mfma_f32(av[r], bv[r], tt[T]);
+    }
+    if (u + 1 < 2 * NT) park2(nxt);
+    __syncthreads();
   }
   // blend, LayerNorm over the D features of each row, residual
   float sum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -912,7 +952,7 @@ int launch_gated_update(const float* h, const float* agg, const float* Wz, const
     return check_launch("gated_update_d32");
   }
   if (D % 16 == 0 && D >= 48 && D <= 128) {  // matrix cores; the kernels stream through LDS in 16-row slices
-    const size_t lw = sizeof(float) * ((size_t)64 * (2 * D + 4) + 64 * (D + 4) + 16 * (2 * D + 16));
+    const size_t lw = sizeof(float) * ((size_t)64 * (2 * D + 4) + 64 * (D + 4) + 2 * 16 * (2 * D));
     const unsigned blocks = (unsigned)((rows + 63) / 64);
 #define WIDE(NT_)                                                                                                  \
     do {                                                                                                            \
