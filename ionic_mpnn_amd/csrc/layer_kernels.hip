@@ -721,6 +721,180 @@ __global__ __launch_bounds__(256) void gated_update_wide_kernel(
   }
 }
 
+// The same with 16 waves (4 per SIMD, so LDS / MFMA latencies overlap): wave (row tile w & 3, feature group w >> 2)
+// owns NT/4 feature tiles of 16 rows; LayerNorm's row sums are completed across the 4 feature groups through LDS.
+template <int NT>  // NT = D / 16 feature tiles, NT % 4 == 0
+__global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
+    const float* __restrict__ h, const float* __restrict__ agg, const float* __restrict__ Wz,
+    const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
+    const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, float* __restrict__ out, int64_t rows) {
+  constexpr int D = 16 * NT, LDC = 2 * D + 4, LDR = D + 4;
+  constexpr int LDW = 2 * D;  // slice layout: element (input row 4*qq + r, column c) at ((qq * LDW + c) * 4 + r)
+  extern __shared__ __align__(16) float smem[];
+  float* cs = smem;                 // 64 x LDC : [h | agg]
+  float* rhs = cs + 64 * LDC;       // 64 x LDR : r * h
+  float* ws = rhs + 64 * LDR;       // 2 x 16 x LDW : slices of 16 input rows of the gate kernels, double-buffered
+  constexpr int NL = NT / 4;  // feature tiles of this wave
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, a = lane & 15, q = lane >> 4;
+  const int wave = wv & 3, fg = wv >> 2;  // row tile, feature group
+  float* part = ws + 2 * 16 * LDW;  // 2 x 4 x 64 row partials (sum, squared deviation) of LayerNorm
+  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  for (int t = tid; t < 64 * D; t += 1024) {
+    const int r = t / D, c = t - r * D;
+    const bool in = row0 + r < rows;
+    cs[r * LDC + c] = in ? h[(row0 + r) * D + c] : 0.f;
+    cs[r * LDC + D + c] = in ? agg[(row0 + r) * D + c] : 0.f;
+  }
+  f32x4_t z[NL], rg[NL];
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL) {
+    const int T = fg * NL + TL;
+    const float b0 = bz[16 * T + a], b1 = br[16 * T + a];
+    z[TL] = f32x4_t{b0, b0, b0, b0};
+    rg[TL] = f32x4_t{b1, b1, b1, b1};
+  }
+  const float* crow = cs + (16 * wave + a) * LDC + 4 * q;
+  // kernel slices: global -> registers one slice ahead (in flight under the MFMAs) -> the other LDS buffer
+  constexpr int kP1 = 16 * 2 * D / 1024, kP2 = 16 * D / 1024;
+  float pre[kP1];
+  auto fetch1 = [&](int u) {
+#pragma unroll
+    for (int i = 0; i < kP1; ++i) {
+      const int t = tid + 1024 * i, jj = t / (2 * D), c = t - jj * 2 * D;
+      pre[i] = c < D ? Wz[(int64_t)(16 * u + jj) * D + c] : Wr[(int64_t)(16 * u + jj) * D + c - D];
+    }
+  };
+  auto park1 = [&](float* dst) {
+#pragma unroll
+    for (int i = 0; i < kP1; ++i) {
+      const int t = tid + 1024 * i, jj = t / (2 * D), c = t - jj * 2 * D;
+      dst[(((jj >> 2) * LDW + c) << 2) + (jj & 3)] = pre[i];
+    }
+  };
+  fetch1(0);
+  park1(ws);
+  __syncthreads();
+  for (int u = 0; u < 2 * NT; ++u) {
+    float* cur = ws + (u & 1) * 16 * LDW;
+    float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
+    if (u + 1 < 2 * NT) fetch1(u + 1);
+    const f32x4_t av = ldv4(crow + 16 * u);
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL) {
+      const int T = fg * NL + TL;
+      const f32x4_t bzv = ldv4(cur + ((q * LDW + 16 * T + a) << 2)), brv = ldv4(cur + ((q * LDW + D + 16 * T + a) << 2));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        z[TL] = mfma_f32(av[r], bzv[r], z[TL]);
+        rg[TL] = mfma_f32(av[r], brv[r], rg[TL]);
+      }
+    }
+    if (u + 1 < 2 * NT) park1(nxt);  // nxt was last read two iterations ago: the barrier below orders it
+    __syncthreads();
+  }
+  // z, r -> sigmoid; r * h into LDS (every wave only touches its own 16 rows)
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int rl = 16 * wave + 4 * q + g, f = 16 * (fg * NL + TL) + a;
+      z[TL][g] = sigmoidf_(z[TL][g]);
+      rhs[rl * LDR + f] = sigmoidf_(rg[TL][g]) * cs[rl * LDC + f];
+    }
+  f32x4_t tt[NL];
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL) {
+    const float b2 = bh[16 * (fg * NL + TL) + a];
+    tt[TL] = f32x4_t{b2, b2, b2, b2};
+  }
+  const float* rrow = rhs + (16 * wave + a) * LDR + 4 * q;
+  auto fetch2 = [&](int u) {
+#pragma unroll
+    for (int i = 0; i < kP2; ++i) {
+      const int t = tid + 1024 * i, jj = t / D, c = t - jj * D;
+      pre[i] = Wh[(int64_t)(16 * u + jj) * D + c];
+    }
+  };
+  auto park2 = [&](float* dst) {
+#pragma unroll
+    for (int i = 0; i < kP2; ++i) {
+      const int t = tid + 1024 * i, jj = t / D, c = t - jj * D;
+      dst[(((jj >> 2) * LDW + c) << 2) + (jj & 3)] = pre[i];
+    }
+  };
+  fetch2(0);
+  park2(ws);
+  __syncthreads();
+  for (int u = 0; u < 2 * NT; ++u) {
+    float* cur = ws + (u & 1) * 16 * LDW;
+    float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
+    if (u + 1 < 2 * NT) fetch2(u + 1);
+    const f32x4_t av = u < NT ? ldv4(rrow + 16 * u) : ldv4(crow + 16 * u);  // [r*h | agg]
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL) {
+      const f32x4_t bv = ldv4(cur + ((q * LDW + 16 * (fg * NL + TL) + a) << 2));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tt[TL] = mfma_f32(av[r], bv[r], tt[TL]);
+    }
+    if (u + 1 < 2 * NT) park2(nxt);
+    __syncthreads();
+  }
+  // blend, LayerNorm over the D features of each row (partials of the 4 feature groups meet in LDS), residual
+  float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float hv = cs[(16 * wave + 4 * q + g) * LDC + 16 * (fg * NL + TL) + a];
+      const float n = (1.0f - z[TL][g]) * hv + z[TL][g] * tanhf(tt[TL][g]);
+      tt[TL][g] = n;
+      sum[g] += n;
+    }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float v = row16_sum_f(sum[g]);
+    if (a == 0) part[fg * 64 + 16 * wave + 4 * q + g] = v;
+  }
+  __syncthreads();
+  float mean[4], inv[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int rl = 16 * wave + 4 * q + g;
+    mean[g] = ((part[rl] + part[64 + rl]) + (part[128 + rl] + part[192 + rl])) * (1.0f / D);
+  }
+  float var[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float d = tt[TL][g] - mean[g];
+      var[g] = fmaf(d, d, var[g]);
+    }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float v = row16_sum_f(var[g]);
+    if (a == 0) part[256 + fg * 64 + 16 * wave + 4 * q + g] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int rl = 256 + 16 * wave + 4 * q + g;
+    inv[g] = 1.0f / sqrtf(((part[rl] + part[64 + rl]) + (part[128 + rl] + part[192 + rl])) * (1.0f / D) + eps);
+  }
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL) {
+    const int f = 16 * (fg * NL + TL) + a;
+    const float gm = gamma[f], bt = beta[f];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int rl = 16 * wave + 4 * q + g;
+      if (row0 + rl < rows)
+        out[(row0 + rl) * D + f] = (tt[TL][g] - mean[g]) * inv[g] * gm + bt + cs[rl * LDC + f];
+    }
+  }
+}
+
 // a8  GlobalSumPool.call (models/layers.py:161-164)
 __global__ void global_sum_pool_kernel(const float* __restrict__ h, const int32_t* __restrict__ ids,
                                        float* __restrict__ out, int B, int N, int D) {
@@ -962,6 +1136,20 @@ int launch_gated_update(const float* h, const float* agg, const float* Wz, const
       gated_update_wide_kernel<NT_><<<blocks, 256, lw, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, out, rows); \
       return check_launch("gated_update_wide");                                                                     \
     } while (0)
+    if (D % 64 == 0) {  // 16 waves per workgroup: 4 per SIMD
+      const size_t l16 = lw + sizeof(float) * 512;
+#define WIDE16(NT_)                                                                                                \
+      do {                                                                                                          \
+        (void)hipFuncSetAttribute((const void*)gated_update_wide16_kernel<NT_>,                                     \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)l16);                            \
+        gated_update_wide16_kernel<NT_><<<blocks, 1024, l16, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, out, \
+                                                                 rows);                                             \
+        return check_launch("gated_update_wide16");                                                                 \
+      } while (0)
+      if (D == 64) WIDE16(4);
+      WIDE16(8);
+#undef WIDE16
+    }
     switch (D / 16) {
       case 3: WIDE(3);
       case 4: WIDE(4);
