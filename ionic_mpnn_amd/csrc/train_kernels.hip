@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kBlock) void bmm_message_typed_seg_kernel(
 // The same on the matrix cores for D a multiple of 16 (exact f32 products): per segment the GEMM
 // m^T (D x 64) = A[type] (D x D) * x^T (D x 64) in 16x16 output tiles, K index ordered as 16u + 4q + r so that one
 // 16-byte LDS read per lane feeds four MFMA steps of both operands.  Wave w owns the output tiles w, w+4, ...
-__global__ __launch_bounds__(kBlock) void bmm_message_typed_seg_mfma_kernel(
+__global__ __launch_bounds__(1024) void bmm_message_typed_seg_mfma_kernel(
     const float* __restrict__ h, const int32_t* __restrict__ conn, const float* __restrict__ A,
     float* __restrict__ m_out, const int32_t* __restrict__ start, const int32_t* __restrict__ segbase,
     const int32_t* __restrict__ order, int N, int E, int D, int Vb) {
@@ -323,8 +323,8 @@ __global__ __launch_bounds__(kBlock) void bmm_message_typed_seg_mfma_kernel(
   const int LD = D + 4;            // 16-byte aligned rows, bank-staggered
   float* As = smem;                // D x LD
   float* xm = As + D * LD;         // kSeg x LD, rows beyond n are zero
-  for (int t = tid; t < D * D; t += kBlock) As[(t / D) * LD + (t % D)] = A[(int64_t)ty * D * D + t];
-  for (int t = tid; t < kSeg * D; t += kBlock) {
+  for (int t = tid; t < D * D; t += (int)blockDim.x) As[(t / D) * LD + (t % D)] = A[(int64_t)ty * D * D + t];
+  for (int t = tid; t < kSeg * D; t += (int)blockDim.x) {
     const int e = t / D, c = t - e * D;
     float v = 0.f;
     if (e < n) {
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void bmm_message_typed_seg_mfma_kernel(
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6, a = lane & 15, q = lane >> 4;
   const int mt = D >> 4, et = (n + 15) >> 4;          // output tiles: features x edges
-  for (int tile = wave; tile < mt * et; tile += kBlock >> 6) {
+  for (int tile = wave; tile < mt * et; tile += (int)blockDim.x >> 6) {
     const int T = tile % mt, Et = tile / mt;
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
     const float* arow = As + (16 * T + a) * LD + 4 * q;
@@ -1100,8 +1100,9 @@ int launch_bmm_message_typed_sorted(const float* h, const int32_t* bond_ids, con
     if (lm > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)bmm_message_typed_seg_mfma_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
-    bmm_message_typed_seg_mfma_kernel<<<(int)max_segs, kBlock, lm, s>>>(h, conn, A, m, start, segbase, order, N, E, D,
-                                                                        Vb);
+    // wide states: 16 waves (4 per SIMD) share the segment's 32 output tiles, so LDS reads overlap the MFMAs
+    bmm_message_typed_seg_mfma_kernel<<<(int)max_segs, D >= 64 ? 1024 : kBlock, lm, s>>>(h, conn, A, m, start, segbase,
+                                                                                          order, N, E, D, Vb);
     return check_launch("bmm_message_typed_seg_mfma");
   }
   const size_t lds = sizeof(float) * ((size_t)D * (D + 1) + (size_t)kSeg * D);
