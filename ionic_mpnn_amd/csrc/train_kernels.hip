@@ -174,8 +174,8 @@ __global__ __launch_bounds__(kBlock) void edge_type_scatter_kernel(const int32_t
   }
 }
 
-template <int ACC>  // ACC = ceil(D*D / kBlock) accumulators per thread
-__global__ __launch_bounds__(kBlock) void bmm_message_typed_bwd_kernel(
+template <int ACC>  // ACC = ceil(D*D / blockDim.x) accumulators per thread
+__global__ __launch_bounds__(1024) void bmm_message_typed_bwd_kernel(
     const float* __restrict__ h, const int32_t* __restrict__ conn, const float* __restrict__ A,
     const float* __restrict__ dm, float* __restrict__ dh, float* __restrict__ dA, const int32_t* __restrict__ start,
     const int32_t* __restrict__ segbase, const int32_t* __restrict__ order, int N, int E, int D, int Vb) {
@@ -197,8 +197,8 @@ __global__ __launch_bounds__(kBlock) void bmm_message_typed_bwd_kernel(
   float* As = smem;            // D*D
   float* gm = As + DD;         // kSeg x D: dm rows of the segment's edges
   float* xm = gm + kSeg * D;   // kSeg x D: their source rows of h
-  for (int t = tid; t < DD; t += kBlock) As[t] = A[(int64_t)ty * DD + t];
-  for (int t = tid; t < n * D; t += kBlock) {
+  for (int t = tid; t < DD; t += (int)blockDim.x) As[t] = A[(int64_t)ty * DD + t];
+  for (int t = tid; t < n * D; t += (int)blockDim.x) {
     const int e = t / D, c = t - e * D;
     const int64_t be = order[p0 + e];
     const int64_t row = (be / E) * N + conn[be * 2];
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void bmm_message_typed_bwd_kernel(
     if (c == 0) srcrow[e] = row;
   }
   __syncthreads();
-  const int lanes = kBlock / D > 0 ? kBlock / D : 1;
+  const int lanes = (int)blockDim.x / D > 0 ? (int)blockDim.x / D : 1;
   if (tid < lanes * D) {  // dh: thread (edge lane, column j)
     const int j = tid % D, el = tid / D;
     for (int e = el; e < n; e += lanes) {
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kBlock) void bmm_message_typed_bwd_kernel(
   }
 #pragma unroll
   for (int a = 0; a < ACC; ++a) {  // dA of this segment: entry q = (i, j)
-    const int q = tid + a * kBlock;
+    const int q = tid + a * (int)blockDim.x;
     if (q < DD) {
       const int i = q / D, j = q - i * D;
       float v = 0.f;
@@ -1128,14 +1128,16 @@ int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const 
     if (int rc = launch_edge_type_sort(bond_ids, conn, workspace, B, N, E, Vb, s)) return rc;
   const int64_t max_segs = (BE + kSeg - 1) / kSeg + Vb;
   const size_t lds = sizeof(float) * ((size_t)D * D + 2 * (size_t)kSeg * D);
-  const int acc = (D * D + kBlock - 1) / kBlock;
+  // wide states need > 64 KB of LDS (one workgroup per CU): 16 waves instead of 4 keep every SIMD busy
+  const int threads = D >= 64 ? 1024 : kBlock;
+  const int acc = (D * D + threads - 1) / threads;
 #define LAUNCH(ACC)                                                                                          \
   do {                                                                                                       \
     if (lds > 48 * 1024)                                                                                     \
       (void)hipFuncSetAttribute((const void*)bmm_message_typed_bwd_kernel<ACC>,                              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-    bmm_message_typed_bwd_kernel<ACC><<<(int)max_segs, kBlock, lds, s>>>(h, conn, A, dm, dh, dA, start, segbase, \
-                                                                          order, N, E, D, Vb);              \
+    bmm_message_typed_bwd_kernel<ACC><<<(int)max_segs, threads, lds, s>>>(h, conn, A, dm, dh, dA, start, segbase, \
+                                                                           order, N, E, D, Vb);             \
   } while (0)
   if (acc <= 1) LAUNCH(1);
   else if (acc <= 4) LAUNCH(4);
