@@ -10,7 +10,23 @@ from . import _lib, ops
 from ._lib import check, f32c, i32c, ptr, stream_ptr
 
 
-_pass = {"id": None, "next": 1}
+import itertools
+import threading
+
+
+class _PassState(threading.local):  # one scope stack per host thread
+    def __init__(self):
+        self.d = {"id": None}
+
+    def __getitem__(self, k):
+        return self.d[k]
+
+    def __setitem__(self, k, v):
+        self.d[k] = v
+
+
+_pass = _PassState()
+_pass_ids = itertools.count(1)  # ids are unique across threads (next() is atomic under the GIL)
 
 
 class training_pass:
@@ -21,8 +37,7 @@ class training_pass:
 
     def __enter__(self):
         self.prev = _pass["id"]
-        _pass["id"] = _pass["next"]
-        _pass["next"] += 1
+        _pass["id"] = next(_pass_ids)
         return self
 
     def __exit__(self, *exc):
