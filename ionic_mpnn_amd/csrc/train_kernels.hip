@@ -104,6 +104,10 @@ __device__ __forceinline__ int edge_type_or_neg(const int32_t* conn, const int32
   return (src > 0 && tgt > 0 && src < N && tgt < N && (unsigned)ty < (unsigned)Vb) ? ty : -1;
 }
 
+__global__ void zero_floats_kernel(float* __restrict__ p, int64_t n) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) p[t] = 0.f;
+}
+
 __global__ void zero_ints_kernel(int32_t* __restrict__ p, int n) {
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) p[t] = 0;
 }
@@ -848,6 +852,355 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_d32_kernel(
     mine[t] = (red[t] + red[5 * D + t]) + (red[10 * D + t] + red[15 * D + t]);
 }
 
+// ---------------------------------------------------------------------------------------
+// a7 backward for wide states (D = 64, 128) on the matrix cores: the adjoint of gated_update_wide16_kernel
+// (layer_kernels.hip) with its layout - a workgroup of 16 waves owns 64 rows at a time, wave (row tile rt,
+// feature group fg) the NT/4 feature tiles 16*(fg*NT/4 + TL) + a of 16 rows; rows on the MFMA M dimension, the
+// kernels stream through LDS in double-buffered slices of 16 contraction indices, read as stored for the forward
+// recompute and column-wise (W^T) for the products with the pre-activation gradients:
+//   P1  z, r   = [h|agg] [Wz|Wr]            P2  t = [r*h|agg] Wh
+//   P3  dc2    = dtp Wh^T                    P4  dc = [dzp|drp] [Wz^T ; Wr^T]
+// LDS: c = [h|agg] (later [dzp|drp]), r*h (later dtp), two slice buffers, LayerNorm row partials, column sums.
+// Outputs and partial sums are those of gated_update_bwd_kernel.
+// ---------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
+    const float* __restrict__ h, const float* __restrict__ agg, const float* __restrict__ Wz,
+    const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
+    const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma, float eps,
+    const float* __restrict__ dout, float* __restrict__ dh, float* __restrict__ dagg, float* __restrict__ dpre,
+    float* __restrict__ rh_out, float* __restrict__ small, int64_t rows) {
+  constexpr int D = 16 * NT, LDC = 2 * D + 4, LDR = D + 4, LDW = 2 * D, NL = NT / 4;
+  extern __shared__ __align__(16) float smem[];
+  float* cs = smem;                   // 64 x LDC
+  float* rhs = cs + 64 * LDC;         // 64 x LDR
+  float* ws = rhs + 64 * LDR;         // 2 x 16 x LDW, element (k = 4*qq + r, column c) at ((qq * LDW + c) * 4 + r)
+  float* part = ws + 2 * 16 * LDW;    // 4 x (4 x 64): LayerNorm row partials (sum, sq. deviation, m1, m2)
+  float* red = part + 4 * 256;        // 4 row tiles x 5 x D column sums
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, a = lane & 15, q = lane >> 4;
+  const int rt = wv & 3, fg = wv >> 2;
+  constexpr int kPre = 16 * 2 * D / 1024;
+  float pre[kPre];
+  auto park = [&](float* dst, int ncols) {  // slice element t -> (k = t / ncols, column t % ncols)
+#pragma unroll
+    for (int i = 0; i < kPre; ++i) {
+      const int t = tid + 1024 * i;
+      if (t < 16 * ncols) {
+        const int jj = t / ncols, c = t - jj * ncols;
+        dst[(((jj >> 2) * LDW + c) << 2) + (jj & 3)] = pre[i];
+      }
+    }
+  };
+  auto park_t = [&](float* dst) {           // transposed slices: element t -> (column t / 16, k = t % 16)
+#pragma unroll
+    for (int i = 0; i < kPre; ++i) {
+      const int t = tid + 1024 * i, c = t >> 4, jj = t & 15;
+      dst[(((jj >> 2) * LDW + c) << 2) + (jj & 3)] = pre[i];
+    }
+  };
+  float s_bz[NL] = {}, s_br[NL] = {}, s_bh[NL] = {}, s_dg[NL] = {}, s_db[NL] = {};
+  const int64_t ntile = (rows + 63) / 64;
+  for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const int64_t row0 = tile * 64;
+    __syncthreads();
+    for (int t = tid; t < 64 * D; t += 1024) {
+      const int r = t / D, c = t - r * D;
+      const bool in = row0 + r < rows;
+      cs[r * LDC + c] = in ? h[(row0 + r) * D + c] : 0.f;
+      cs[r * LDC + D + c] = in ? agg[(row0 + r) * D + c] : 0.f;
+    }
+    const float* crow = cs + (16 * rt + a) * LDC + 4 * q;
+    const float* rrow = rhs + (16 * rt + a) * LDR + 4 * q;
+    // ---- P1: z, r
+    f32x4_t z[NL], rr[NL];
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL) {
+      const int f = 16 * (fg * NL + TL) + a;
+      z[TL] = f32x4_t{bz[f], bz[f], bz[f], bz[f]};
+      rr[TL] = f32x4_t{br[f], br[f], br[f], br[f]};
+    }
+    auto fetch1 = [&](int u) {
+#pragma unroll
+      for (int i = 0; i < kPre; ++i) {
+        const int t = tid + 1024 * i, jj = t / (2 * D), c = t - jj * 2 * D;
+        pre[i] = c < D ? Wz[(int64_t)(16 * u + jj) * D + c] : Wr[(int64_t)(16 * u + jj) * D + c - D];
+      }
+    };
+    fetch1(0);
+    park(ws, 2 * D);
+    __syncthreads();
+    for (int u = 0; u < 2 * NT; ++u) {
+      float* cur = ws + (u & 1) * 16 * LDW;
+      float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
+      if (u + 1 < 2 * NT) fetch1(u + 1);
+      const f32x4_t av = ldv4(crow + 16 * u);
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL) {
+        const int col = 16 * (fg * NL + TL) + a;
+        const f32x4_t b0 = ldv4(cur + ((q * LDW + col) << 2)), b1 = ldv4(cur + ((q * LDW + D + col) << 2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          z[TL] = mfma_f32(av[r], b0[r], z[TL]);
+          rr[TL] = mfma_f32(av[r], b1[r], rr[TL]);
+        }
+      }
+      if (u + 1 < 2 * NT) park(nxt, 2 * D);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int rl = 16 * rt + 4 * q + g, f = 16 * (fg * NL + TL) + a;
+        z[TL][g] = sigmoid_exact(z[TL][g]);
+        rr[TL][g] = sigmoid_exact(rr[TL][g]);
+        const float v = rr[TL][g] * cs[rl * LDC + f];
+        rhs[rl * LDR + f] = v;
+        if (row0 + rl < rows) rh_out[(row0 + rl) * D + f] = v;
+      }
+    // ---- P2: t
+    f32x4_t tt[NL];
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL) {
+      const float b2 = bh[16 * (fg * NL + TL) + a];
+      tt[TL] = f32x4_t{b2, b2, b2, b2};
+    }
+    auto fetch2 = [&](int u) {
+#pragma unroll
+      for (int i = 0; i < kPre; ++i) {
+        const int t = tid + 1024 * i;
+        if (t < 16 * D) pre[i] = Wh[(int64_t)(16 * u + t / D) * D + t % D];
+      }
+    };
+    fetch2(0);
+    park(ws, D);
+    __syncthreads();
+    for (int u = 0; u < 2 * NT; ++u) {
+      float* cur = ws + (u & 1) * 16 * LDW;
+      float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
+      if (u + 1 < 2 * NT) fetch2(u + 1);
+      const f32x4_t av = u < NT ? ldv4(rrow + 16 * u) : ldv4(crow + 16 * u);
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL) {
+        const f32x4_t bv = ldv4(cur + ((q * LDW + 16 * (fg * NL + TL) + a) << 2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tt[TL] = mfma_f32(av[r], bv[r], tt[TL]);
+      }
+      if (u + 1 < 2 * NT) park(nxt, D);
+      __syncthreads();
+    }
+    // ---- blend, LayerNorm forward statistics
+    f32x4_t xh[NL], dy[NL];
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int rl = 16 * rt + 4 * q + g, f = 16 * (fg * NL + TL) + a;
+        const float hv = cs[rl * LDC + f];
+        tt[TL][g] = tanhf(tt[TL][g]);
+        xh[TL][g] = (1.0f - z[TL][g]) * hv + z[TL][g] * tt[TL][g];
+        sum[g] += xh[TL][g];
+        dy[TL][g] = row0 + rl < rows ? dout[(row0 + rl) * D + f] : 0.f;
+      }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float v = row16_sum(sum[g]);
+      if (a == 0) part[fg * 64 + 16 * rt + 4 * q + g] = v;
+    }
+    __syncthreads();
+    float mean[4], inv[4], var[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int rl = 16 * rt + 4 * q + g;
+      mean[g] = ((part[rl] + part[64 + rl]) + (part[128 + rl] + part[192 + rl])) * (1.0f / D);
+    }
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        xh[TL][g] -= mean[g];
+        var[g] = fmaf(xh[TL][g], xh[TL][g], var[g]);
+      }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float v = row16_sum(var[g]);
+      if (a == 0) part[256 + fg * 64 + 16 * rt + 4 * q + g] = v;
+    }
+    __syncthreads();
+    float m1[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int rl = 256 + 16 * rt + 4 * q + g;
+      inv[g] = 1.0f / sqrtf(((part[rl] + part[64 + rl]) + (part[128 + rl] + part[192 + rl])) * (1.0f / D) + eps);
+    }
+    // ---- LayerNorm backward
+    f32x4_t dxh[NL];
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL) {
+      const float gm = gamma[16 * (fg * NL + TL) + a];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        xh[TL][g] *= inv[g];
+        dxh[TL][g] = dy[TL][g] * gm;
+        m1[g] += dxh[TL][g];
+        m2[g] = fmaf(dxh[TL][g], xh[TL][g], m2[g]);
+        s_dg[TL] = fmaf(dy[TL][g], xh[TL][g], s_dg[TL]);
+        s_db[TL] += dy[TL][g];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float v1 = row16_sum(m1[g]), v2 = row16_sum(m2[g]);
+      if (a == 0) {
+        part[512 + fg * 64 + 16 * rt + 4 * q + g] = v1;
+        part[768 + fg * 64 + 16 * rt + 4 * q + g] = v2;
+      }
+    }
+    __syncthreads();  // (also: every wave is done reading r*h from `rhs`)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int rl = 16 * rt + 4 * q + g;
+      m1[g] = ((part[512 + rl] + part[576 + rl]) + (part[640 + rl] + part[704 + rl])) * (1.0f / D);
+      m2[g] = ((part[768 + rl] + part[832 + rl]) + (part[896 + rl] + part[960 + rl])) * (1.0f / D);
+    }
+    f32x4_t dzp[NL], dhA[NL];
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int rl = 16 * rt + 4 * q + g, f = 16 * (fg * NL + TL) + a;
+        const float hv = cs[rl * LDC + f];
+        const float dn = inv[g] * (dxh[TL][g] - m1[g] - xh[TL][g] * m2[g]);
+        const float zz = z[TL][g], tv = tt[TL][g];
+        dzp[TL][g] = dn * (tv - hv) * zz * (1.0f - zz);
+        const float dtp = dn * zz * (1.0f - tv * tv);
+        dhA[TL][g] = dy[TL][g] + dn * (1.0f - zz);
+        s_bz[TL] += dzp[TL][g];
+        s_bh[TL] += dtp;
+        rhs[rl * LDR + f] = dtp;  // A operand of P3
+        if (row0 + rl < rows) {
+          float* dp = dpre + (row0 + rl) * 3 * D;
+          dp[f] = dzp[TL][g];
+          dp[2 * D + f] = dtp;
+        }
+      }
+    // ---- P3: dc2 = dtp Wh^T  (lo: through r*h, hi: to agg)
+    f32x4_t lo[NL], hi[NL];
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL) lo[TL] = hi[TL] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto fetch3 = [&](int u) {  // slice u of Wh^T: (k = j - 16u, column i') = Wh[i'][16u + k]
+#pragma unroll
+      for (int i = 0; i < kPre; ++i) {
+        const int t = tid + 1024 * i;
+        pre[i] = Wh[(int64_t)(t >> 4) * D + 16 * u + (t & 15)];
+      }
+    };
+    fetch3(0);
+    park_t(ws);
+    __syncthreads();
+    for (int u = 0; u < NT; ++u) {
+      float* cur = ws + (u & 1) * 16 * LDW;
+      float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
+      if (u + 1 < NT) fetch3(u + 1);
+      const f32x4_t av = ldv4(rrow + 16 * u);
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL) {
+        const int col = 16 * (fg * NL + TL) + a;
+        const f32x4_t b0 = ldv4(cur + ((q * LDW + col) << 2)), b1 = ldv4(cur + ((q * LDW + D + col) << 2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          lo[TL] = mfma_f32(av[r], b0[r], lo[TL]);
+          hi[TL] = mfma_f32(av[r], b1[r], hi[TL]);
+        }
+      }
+      if (u + 1 < NT) park_t(nxt);
+      __syncthreads();
+    }
+    f32x4_t daA[NL];
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int rl = 16 * rt + 4 * q + g, f = 16 * (fg * NL + TL) + a;
+        const float hv = cs[rl * LDC + f], rv = rr[TL][g];
+        const float drp = lo[TL][g] * hv * rv * (1.0f - rv);
+        dhA[TL][g] = fmaf(lo[TL][g], rv, dhA[TL][g]);
+        daA[TL][g] = hi[TL][g];
+        s_br[TL] += drp;
+        lo[TL][g] = drp;  // parked below, after every wave is done with h
+        if (row0 + rl < rows) dpre[(row0 + rl) * 3 * D + D + f] = drp;
+      }
+    __syncthreads();  // all reads of c = [h|agg] are done: it becomes [dzp|drp]
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int rl = 16 * rt + 4 * q + g, f = 16 * (fg * NL + TL) + a;
+        cs[rl * LDC + f] = dzp[TL][g];
+        cs[rl * LDC + D + f] = lo[TL][g];
+      }
+    // ---- P4: dc = [dzp|drp] [Wz^T ; Wr^T]
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL) lo[TL] = hi[TL] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto fetch4 = [&](int u) {
+      const float* W = u < NT ? Wz : Wr;
+      const int u0 = u < NT ? u : u - NT;
+#pragma unroll
+      for (int i = 0; i < kPre; ++i) {
+        const int t = tid + 1024 * i;
+        pre[i] = W[(int64_t)(t >> 4) * D + 16 * u0 + (t & 15)];
+      }
+    };
+    fetch4(0);
+    park_t(ws);
+    __syncthreads();
+    for (int u = 0; u < 2 * NT; ++u) {
+      float* cur = ws + (u & 1) * 16 * LDW;
+      float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
+      if (u + 1 < 2 * NT) fetch4(u + 1);
+      const f32x4_t av = ldv4(crow + 16 * u);
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL) {
+        const int col = 16 * (fg * NL + TL) + a;
+        const f32x4_t b0 = ldv4(cur + ((q * LDW + col) << 2)), b1 = ldv4(cur + ((q * LDW + D + col) << 2));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          lo[TL] = mfma_f32(av[r], b0[r], lo[TL]);
+          hi[TL] = mfma_f32(av[r], b1[r], hi[TL]);
+        }
+      }
+      if (u + 1 < 2 * NT) park_t(nxt);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int rl = 16 * rt + 4 * q + g, f = 16 * (fg * NL + TL) + a;
+        if (row0 + rl < rows) {
+          dh[(row0 + rl) * D + f] = dhA[TL][g] + lo[TL][g];
+          dagg[(row0 + rl) * D + f] = daA[TL][g] + hi[TL][g];
+        }
+      }
+  }
+  // ---- column sums: the 4 row quarters of a wave, then the 4 row tiles (fixed order)
+  float* sums[5] = {s_bz, s_br, s_bh, s_dg, s_db};
+#pragma unroll
+  for (int w5 = 0; w5 < 5; ++w5)
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL) {
+      float v = sums[w5][TL];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (q == 0) red[(rt * 5 + w5) * D + 16 * (fg * NL + TL) + a] = v;
+    }
+  __syncthreads();
+  float* mine = small + (int64_t)blockIdx.x * 5 * D;
+  for (int t = tid; t < 5 * D; t += 1024)
+    mine[t] = (red[t] + red[5 * D + t]) + (red[10 * D + t] + red[15 * D + t]);
+}
+
 // WT = [Wz^T | Wr^T | Wh^T] (each D x 2D) for the large-D variant above (32x32 LDS tiles)
 __global__ void transpose3_kernel(const float* __restrict__ Wz, const float* __restrict__ Wr,
                                   const float* __restrict__ Wh, float* __restrict__ WT, int D) {
@@ -1221,7 +1574,25 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   const bool al16 = ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(agg) | reinterpret_cast<uintptr_t>(dout) |
                       reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(dagg) |
                       reinterpret_cast<uintptr_t>(workspace)) & 15u) == 0;
-  if (D == 32 && al16) {
+  if ((D == 64 || D == 128) && al16) {
+    const size_t lw = sizeof(float) * ((size_t)64 * (2 * D + 4) + 64 * (D + 4) + 2 * 16 * 2 * D + 4 * 256 + 4 * 5 * D);
+    const int64_t tiles64 = (rows + 63) / 64;
+    const int nb = (int)(tiles64 < nblk ? tiles64 : nblk);  // `small` has nblk slices: unused ones must be zero
+    // (zeroing is a kernel, not hipMemsetAsync: the call may sit inside a captured graph)
+    zero_floats_kernel<<<grid_for((int64_t)nblk * 5 * D), kBlock, 0, s>>>(small, (int64_t)nblk * 5 * D);
+    if (int rc = check_launch("zero_floats")) return rc;
+    if (D == 64) {
+      (void)hipFuncSetAttribute((const void*)gated_update_bwd_wide16_kernel<4>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
+      gated_update_bwd_wide16_kernel<4><<<nb, 1024, lw, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, dagg,
+                                                            dpre, rh, small, rows);
+    } else {
+      (void)hipFuncSetAttribute((const void*)gated_update_bwd_wide16_kernel<8>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
+      gated_update_bwd_wide16_kernel<8><<<nb, 1024, lw, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, dagg,
+                                                            dpre, rh, small, rows);
+    }
+  } else if (D == 32 && al16) {
     const size_t l32 = sizeof(float) * ((size_t)3 * 32 * kBwT + 3 * 64 * kBwN + 4 * 32 + 4 * 5 * 32);
     if (l32 > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)gated_update_bwd_d32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
