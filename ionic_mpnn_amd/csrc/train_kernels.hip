@@ -1234,17 +1234,22 @@ __global__ __launch_bounds__(kBlock) void strided_gemm_splitk_kernel(GemmProblem
                                                                      int64_t rows, int M, int Mh, int N,
                                                                      int64_t a_rs, int64_t a_cs, int64_t b_rs,
                                                                      int64_t b_cs, int nchunk, int tilesN) {
-  __shared__ __align__(16) float As[kGR][kGM];
-  __shared__ __align__(16) float Bs[kGR][kGN];
+  // LDS tiles of kGR contraction rows; row strides chosen so that the four k-rows of one MFMA step fall into
+  // disjoint bank groups (80 = 64 + 16, 48 = 32 + 16 floats)
+  constexpr int kLA = kGM + 16, kLB = kGN + 16;
+  __shared__ __align__(16) float As[kGR * kLA];
+  __shared__ __align__(16) float Bs[kGR * kLB];
   const int chunk = blockIdx.x, tile = blockIdx.y, prob = blockIdx.z;
   const int tm0 = (tile / tilesN) * kGM, tn0 = (tile % tilesN) * kGN;
   const float* A1 = ga.A1[prob];
   const float* A2 = ga.A2[prob];
   const float* B = ga.B[prob];
-  const int tid = threadIdx.x, tm = tid / 16, tn = tid % 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = lane & 15, q = lane >> 4;
   const int64_t per = (rows + nchunk - 1) / nchunk;
   const int64_t r_lo = (int64_t)chunk * per, r_hi = r_lo + per < rows ? r_lo + per : rows;
-  float acc[4][2] = {};
+  // exact-f32 MFMA: wave w owns output rows m = 16w .. 16w+15 of the 64 x 32 tile (two 16 x 16 tiles);
+  // contraction rows on K: lane (a, q) feeds A[row 4s+q][16w + a] and B[row 4s+q][16t + a] straight from the tiles
+  f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   for (int64_t r0 = r_lo; r0 < r_hi; r0 += kGR) {
     const int nr = (int)((r_hi - r0) < kGR ? (r_hi - r0) : kGR);
     __syncthreads();
@@ -1253,46 +1258,45 @@ __global__ __launch_bounds__(kBlock) void strided_gemm_splitk_kernel(GemmProblem
         const int r = t / kGM, mm = t % kGM, m = tm0 + mm;
         float v = 0.f;
         if (r < nr && m < M) v = m < Mh ? A1[(r0 + r) * a_rs + m] : A2[(r0 + r) * a_rs + (m - Mh)];
-        As[r][mm] = v;
+        As[r * kLA + mm] = v;
       }
     } else {          // rows contiguous (a transposed operand): lanes walk r
       for (int t = tid; t < kGR * kGM; t += kBlock) {
         const int mm = t / kGR, r = t % kGR, m = tm0 + mm;
         float v = 0.f;
         if (r < nr && m < M) v = m < Mh ? A1[(r0 + r) * a_rs + m * a_cs] : A2[(r0 + r) * a_rs + (m - Mh) * a_cs];
-        As[r][mm] = v;
+        As[r * kLA + mm] = v;
       }
     }
     if (b_cs == 1) {
       for (int t = tid; t < kGR * kGN; t += kBlock) {
         const int r = t / kGN, nn = t % kGN, n = tn0 + nn;
-        Bs[r][nn] = (r < nr && n < N) ? B[(r0 + r) * b_rs + n] : 0.f;
+        Bs[r * kLB + nn] = (r < nr && n < N) ? B[(r0 + r) * b_rs + n] : 0.f;
       }
     } else {
       for (int t = tid; t < kGR * kGN; t += kBlock) {
         const int nn = t / kGR, r = t % kGR, n = tn0 + nn;
-        Bs[r][nn] = (r < nr && n < N) ? B[(r0 + r) * b_rs + n * b_cs] : 0.f;
+        Bs[r * kLB + nn] = (r < nr && n < N) ? B[(r0 + r) * b_rs + n * b_cs] : 0.f;
       }
     }
     __syncthreads();
-#pragma unroll 8
-    for (int r = 0; r < kGR; ++r) {
-      const float4 a = *reinterpret_cast<const float4*>(&As[r][tm * 4]);
-      const float2 b = *reinterpret_cast<const float2*>(&Bs[r][tn * 2]);
-      acc[0][0] = fmaf(a.x, b.x, acc[0][0]); acc[0][1] = fmaf(a.x, b.y, acc[0][1]);
-      acc[1][0] = fmaf(a.y, b.x, acc[1][0]); acc[1][1] = fmaf(a.y, b.y, acc[1][1]);
-      acc[2][0] = fmaf(a.z, b.x, acc[2][0]); acc[2][1] = fmaf(a.z, b.y, acc[2][1]);
-      acc[3][0] = fmaf(a.w, b.x, acc[3][0]); acc[3][1] = fmaf(a.w, b.y, acc[3][1]);
+#pragma unroll
+    for (int st = 0; st < kGR / 4; ++st) {
+      const float av = As[(4 * st + q) * kLA + 16 * wave + a];
+      const float b0 = Bs[(4 * st + q) * kLB + a], b1 = Bs[(4 * st + q) * kLB + 16 + a];
+      acc0 = mfma_f32(av, b0, acc0);
+      acc1 = mfma_f32(av, b1, acc1);
     }
   }
   float* o = out + ((int64_t)prob * nchunk + chunk) * M * N;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int m = tm0 + tm * 4 + i, n = tn0 + tn * 2 + j;
-      if (m < M && n < N) o[(int64_t)m * N + n] = acc[i][j];
+  for (int g = 0; g < 4; ++g) {  // accumulator: row 16w + 4q + g, column 16t + a
+    const int m = tm0 + 16 * wave + 4 * q + g;
+    if (m < M) {
+      if (tn0 + a < N) o[(int64_t)m * N + tn0 + a] = acc0[g];
+      if (tn0 + 16 + a < N) o[(int64_t)m * N + tn0 + 16 + a] = acc1[g];
     }
+  }
 }
 
 // dparams = fixed-order sums of the partials (canonical layout, see above).  One wave per output: lane l adds
