@@ -902,12 +902,19 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
   const int64_t ntile = (rows + 63) / 64;
   for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     const int64_t row0 = tile * 64;
+    const int nrt = (int)((rows - row0) < 64 ? (rows - row0) : 64);  // rows of this tile
+    // per-tile base pointers (scalar) + 32-bit offsets: keeps the per-element addresses out of the register file
+    const float* dout_t = dout + row0 * D;
+    float* dh_t = dh + row0 * D;
+    float* dagg_t = dagg + row0 * D;
+    float* rh_t = rh_out + row0 * D;
+    float* dpre_t = dpre + row0 * 3 * D;
     __syncthreads();
     for (int t = tid; t < 64 * D; t += 1024) {
       const int r = t / D, c = t - r * D;
-      const bool in = row0 + r < rows;
-      cs[r * LDC + c] = in ? h[(row0 + r) * D + c] : 0.f;
-      cs[r * LDC + D + c] = in ? agg[(row0 + r) * D + c] : 0.f;
+      const bool in = r < nrt;
+      cs[r * LDC + c] = in ? h[row0 * D + t] : 0.f;
+      cs[r * LDC + D + c] = in ? agg[row0 * D + t] : 0.f;
     }
     const float* crow = cs + (16 * rt + a) * LDC + 4 * q;
     const float* rrow = rhs + (16 * rt + a) * LDR + 4 * q;
@@ -929,6 +936,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     fetch1(0);
     park(ws, 2 * D);
     __syncthreads();
+#pragma unroll 1
     for (int u = 0; u < 2 * NT; ++u) {
       float* cur = ws + (u & 1) * 16 * LDW;
       float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
@@ -956,7 +964,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
         rr[TL][g] = sigmoid_exact(rr[TL][g]);
         const float v = rr[TL][g] * cs[rl * LDC + f];
         rhs[rl * LDR + f] = v;
-        if (row0 + rl < rows) rh_out[(row0 + rl) * D + f] = v;
+        if (rl < nrt) rh_t[rl * D + f] = v;
       }
     // ---- P2: t
     f32x4_t tt[NL];
@@ -975,6 +983,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     fetch2(0);
     park(ws, D);
     __syncthreads();
+#pragma unroll 1
     for (int u = 0; u < 2 * NT; ++u) {
       float* cur = ws + (u & 1) * 16 * LDW;
       float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
@@ -1001,7 +1010,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
         tt[TL][g] = tanhf(tt[TL][g]);
         xh[TL][g] = (1.0f - z[TL][g]) * hv + z[TL][g] * tt[TL][g];
         sum[g] += xh[TL][g];
-        dy[TL][g] = row0 + rl < rows ? dout[(row0 + rl) * D + f] : 0.f;
+        dy[TL][g] = rl < nrt ? dout_t[rl * D + f] : 0.f;
       }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1079,10 +1088,9 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
         s_bz[TL] += dzp[TL][g];
         s_bh[TL] += dtp;
         rhs[rl * LDR + f] = dtp;  // A operand of P3
-        if (row0 + rl < rows) {
-          float* dp = dpre + (row0 + rl) * 3 * D;
-          dp[f] = dzp[TL][g];
-          dp[2 * D + f] = dtp;
+        if (rl < nrt) {
+          dpre_t[rl * 3 * D + f] = dzp[TL][g];
+          dpre_t[rl * 3 * D + 2 * D + f] = dtp;
         }
       }
     // ---- P3: dc2 = dtp Wh^T  (lo: through r*h, hi: to agg)
@@ -1099,6 +1107,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     fetch3(0);
     park_t(ws);
     __syncthreads();
+#pragma unroll 1
     for (int u = 0; u < NT; ++u) {
       float* cur = ws + (u & 1) * 16 * LDW;
       float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
@@ -1129,7 +1138,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
         daA[TL][g] = hi[TL][g];
         s_br[TL] += drp;
         lo[TL][g] = drp;  // parked below, after every wave is done with h
-        if (row0 + rl < rows) dpre[(row0 + rl) * 3 * D + D + f] = drp;
+        if (rl < nrt) dpre_t[rl * 3 * D + D + f] = drp;
       }
     __syncthreads();  // all reads of c = [h|agg] are done: it becomes [dzp|drp]
 #pragma unroll
@@ -1155,6 +1164,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     fetch4(0);
     park_t(ws);
     __syncthreads();
+#pragma unroll 1
     for (int u = 0; u < 2 * NT; ++u) {
       float* cur = ws + (u & 1) * 16 * LDW;
       float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
@@ -1178,9 +1188,9 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int rl = 16 * rt + 4 * q + g, f = 16 * (fg * NL + TL) + a;
-        if (row0 + rl < rows) {
-          dh[(row0 + rl) * D + f] = dhA[TL][g] + lo[TL][g];
-          dagg[(row0 + rl) * D + f] = daA[TL][g] + hi[TL][g];
+        if (rl < nrt) {
+          dh_t[rl * D + f] = dhA[TL][g] + lo[TL][g];
+          dagg_t[rl * D + f] = daA[TL][g] + hi[TL][g];
         }
       }
   }
