@@ -160,6 +160,22 @@ int impnn_model_head(int32_t kind, const float* pooled_cat, const float* pooled_
                      const float* temperature, const float* head_weights, float* out, int32_t B,
                      int32_t D, int32_t F, int32_t Mx, impnn_stream_t stream);
 
+/* ---- f1 for training (f4): the same head read from the INDIVIDUAL weight tensors - `weights` is a host array of
+ *      device pointers in the order of impnn_model_head's packed layout (10 tensors for kind 0, 12 for kind 1), so a
+ *      training step does not re-pack the head after every optimizer update - and its backward in one launch.
+ *      impnn_model_head_bwd recomputes the forward per sample, writes dpooled_cat / dpooled_an (B,D) and ADDS the
+ *      parameter gradients to dweights[i] (same order and shapes as weights[i]; float atomics, so the sum order
+ *      over workgroups is not fixed - fp32 rounding-level run-to-run differences in these ~5k values).
+ *      Gradient of clip follows tf.clip_by_value / torch.clamp: passes where min <= x <= max.
+ *      Replaces the autograd tape of train_viscosity.py:189-214 / train_melting_point.py:173-198. */
+int impnn_model_head_tensors(int32_t kind, const float* pooled_cat, const float* pooled_an,
+                             const float* temperature, const float* const* weights, float* out,
+                             int32_t B, int32_t D, int32_t F, int32_t Mx, impnn_stream_t stream);
+int impnn_model_head_bwd(int32_t kind, const float* pooled_cat, const float* pooled_an,
+                         const float* temperature, const float* const* weights, const float* dout,
+                         float* dpooled_cat, float* dpooled_an, float* const* dweights, int32_t B,
+                         int32_t D, int32_t F, int32_t Mx, impnn_stream_t stream);
+
 /* ---- a9 in two halves, for callers that pipeline batches.  impnn_encoder_plan runs only the
  *      graph-dependent plan kernels (row counts, shares, chunk records) of a batch into `workspace`;
  *      impnn_encoder_run runs only the encoder kernel from a planned workspace.  The plan needs no

@@ -230,3 +230,45 @@ class GlobalSumPool(torch.autograd.Function):
         dh = torch.empty(B, N, ctx.D, dtype=torch.float32, device=dp.device)
         _lib_call(dp.device, _lib.load().impnn_global_sum_pool_bwd, ptr(dp), ptr(ids), ptr(dh), B, N, ctx.D)
         return dh, None
+
+
+class ModelHead(torch.autograd.Function):
+    """Everything after GlobalSumPool as one node (SURVEY.md 8 f1 + f4): forward impnn_model_head_tensors, backward
+    impnn_model_head_bwd, both reading the individual Dense kernels/biases (train_viscosity.py:189-214 /
+    train_melting_point.py:173-198)."""
+
+    @staticmethod
+    def forward(ctx, kind, fp_size, mixing_size, pooled_cat, pooled_an, temperature, *weights):
+        import ctypes as C
+        pooled_cat, pooled_an = f32c(pooled_cat), f32c(pooled_an)
+        weights = tuple(f32c(w) for w in weights)
+        B, D = pooled_cat.shape
+        T = f32c(temperature).reshape(-1) if kind == 0 else None
+        if T is not None and T.numel() != B:
+            raise ValueError("temperature must hold one value per sample")
+        out = torch.empty(B, 1, dtype=torch.float32, device=pooled_cat.device)
+        table = (C.c_void_p * len(weights))(*[w.data_ptr() for w in weights])
+        _lib_call(pooled_cat.device, _lib.load().impnn_model_head_tensors, kind, ptr(pooled_cat), ptr(pooled_an),
+                  ptr(T) if T is not None else None, table, ptr(out), B, D, fp_size, mixing_size)
+        ctx.save_for_backward(pooled_cat, pooled_an, *(() if T is None else (T,)), *weights)
+        ctx.meta = (kind, fp_size, mixing_size, weights)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes as C
+        kind, F, Mx, params = ctx.meta
+        saved = ctx.saved_tensors
+        pooled_cat, pooled_an = saved[0], saved[1]
+        T = saved[2] if kind == 0 else None
+        weights = saved[3 if kind == 0 else 2:]
+        B, D = pooled_cat.shape
+        dout = f32c(dout).reshape(-1)
+        sinks = [_sink(p) for p in params]
+        grads = [s if s is not None else torch.zeros_like(w) for s, w in zip(sinks, weights)]
+        dpc, dpa = torch.empty_like(pooled_cat), torch.empty_like(pooled_an)
+        wt = (C.c_void_p * len(weights))(*[w.data_ptr() for w in weights])
+        gt = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        _lib_call(dout.device, _lib.load().impnn_model_head_bwd, kind, ptr(pooled_cat), ptr(pooled_an),
+                  ptr(T) if T is not None else None, wt, ptr(dout), ptr(dpc), ptr(dpa), gt, B, D, F, Mx)
+        return (None, None, None, dpc, dpa, None) + tuple(None if s is not None else g for s, g in zip(sinks, grads))

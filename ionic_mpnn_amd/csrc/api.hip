@@ -275,6 +275,30 @@ int impnn_model_head(int32_t kind, const float* pooled_cat, const float* pooled_
   return launch_model_head(kind, pooled_cat, pooled_an, temperature, head_weights, out, B, D, F, Mx, as_stream(stream));
 }
 
+int impnn_model_head_tensors(int32_t kind, const float* pooled_cat, const float* pooled_an, const float* temperature,
+                             const float* const* weights, float* out, int32_t B, int32_t D, int32_t F, int32_t Mx,
+                             impnn_stream_t stream) {
+  REQUIRE(kind == 0 || kind == 1, "kind must be 0 (viscosity) or 1 (melting point)");
+  REQUIRE(B >= 0 && D > 0 && F > 0 && Mx > 0, "bad shape");
+  if (B == 0) return IMPNN_OK;
+  REQUIRE(pooled_cat && pooled_an && weights && out && (kind == 1 || temperature), "null pointer");
+  return launch_model_head_tensors(kind, pooled_cat, pooled_an, temperature, weights, out, B, D, F, Mx,
+                                   as_stream(stream));
+}
+
+int impnn_model_head_bwd(int32_t kind, const float* pooled_cat, const float* pooled_an, const float* temperature,
+                         const float* const* weights, const float* dout, float* dpooled_cat, float* dpooled_an,
+                         float* const* dweights, int32_t B, int32_t D, int32_t F, int32_t Mx, impnn_stream_t stream) {
+  REQUIRE(kind == 0 || kind == 1, "kind must be 0 (viscosity) or 1 (melting point)");
+  REQUIRE(B >= 0 && D > 0 && F > 0 && Mx > 0, "bad shape");
+  if (B == 0) return IMPNN_OK;
+  REQUIRE(pooled_cat && pooled_an && weights && dout && dpooled_cat && dpooled_an && dweights &&
+              (kind == 1 || temperature),
+          "null pointer");
+  return launch_model_head_bwd(kind, pooled_cat, pooled_an, temperature, weights, dout, dpooled_cat, dpooled_an,
+                               dweights, B, D, F, Mx, as_stream(stream));
+}
+
 int impnn_profile_enable(int32_t capacity) {
   REQUIRE(capacity > 0 && capacity <= (1 << 20), "capacity out of range");
   impnn_profile_disable();

@@ -1394,6 +1394,240 @@ __global__ __launch_bounds__(1024) void adam_clipnorm_kernel(const unsigned long
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// f1 for training: everything after GlobalSumPool, forward from the individual weight tensors (no packing) and
+// its backward, one launch each (train_viscosity.py:189,197-214 + models/layers.py:10-49;
+// train_melting_point.py:173,191-198).  Tensor order = the packed order of impnn_model_head:
+//   Wfp_cat | bfp_cat | Wfp_an | bfp_an | Wp_cat | bp_cat | Wp_an | bp_an | kind 0: Wv | bv ; kind 1: Wh | bh | Wo | bo
+// Backward: 8 samples per workgroup, 32 threads per sample; the forward is recomputed; parameter gradients are
+// summed in LDS per workgroup and ADDED to the individual gradient buffers with float atomics.
+// ---------------------------------------------------------------------------------------
+constexpr int kHdMax = 64, kHdSPB = 8, kHdTensors = 12;
+struct HeadTensors {
+  const float* w[kHdTensors];
+  float* g[kHdTensors];
+  int off[kHdTensors + 1];
+  int n;
+};
+__device__ __forceinline__ float softplus_stable(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+
+__device__ __forceinline__ void head_load_weights(const HeadTensors& ht, float* ws) {
+  const int total = ht.off[ht.n];
+  for (int t = threadIdx.x; t < total; t += blockDim.x) {
+    int sgm = 0;
+    while (sgm + 1 < ht.n && t >= ht.off[sgm + 1]) ++sgm;
+    ws[t] = ht.w[sgm][t - ht.off[sgm]];
+  }
+}
+
+// forward up to the mixed vector; returns through LDS: fpre (pre-activation of the fingerprint Dense), fp, ppre, mix
+__device__ __forceinline__ void head_forward_mix(const float* ws, const float* xs, float* fpre, float* ppre, float* mix,
+                                                 int sl, int jj, int D, int F, int Mx) {
+  const float* Wfp[2] = {ws, ws + D * F + F};
+  const float* wp = ws + 2 * (D * F + F);
+  const float* Wp[2] = {wp, wp + F * Mx + Mx};
+  for (int g = 0; g < 2; ++g)
+    for (int j = jj; j < F; j += 32) {
+      float acc = Wfp[g][D * F + j];
+      const float* x = xs + (sl * 2 + g) * kHdMax;
+      for (int i = 0; i < D; ++i) acc = fmaf(x[i], Wfp[g][i * F + j], acc);
+      fpre[(sl * 2 + g) * kHdMax + j] = acc;
+    }
+  __syncthreads();
+  for (int j = jj; j < Mx; j += 32) {
+    float m = 0.f;
+    for (int g = 0; g < 2; ++g) {
+      float acc = Wp[g][F * Mx + j];
+      const float* x = fpre + (sl * 2 + g) * kHdMax;
+      for (int i = 0; i < F; ++i) acc = fmaf(fmaxf(x[i], 0.f), Wp[g][i * Mx + j], acc);
+      ppre[(sl * 2 + g) * kHdMax + j] = acc;
+      m += fmaxf(acc, 0.f);
+    }
+    mix[sl * kHdMax + j] = m;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void model_head_tensors_kernel(int kind, const float* __restrict__ pc,
+                                                                 const float* __restrict__ pa,
+                                                                 const float* __restrict__ T, HeadTensors ht,
+                                                                 float* __restrict__ out, int B, int D, int F, int Mx) {
+  extern __shared__ __align__(16) float hsm[];
+  const int total = ht.off[ht.n];
+  float* ws = hsm;
+  float* xs = ws + ((total + 3) & ~3);
+  float* fpre = xs + kHdSPB * 2 * kHdMax;
+  float* ppre = fpre + kHdSPB * 2 * kHdMax;
+  float* mix = ppre + kHdSPB * 2 * kHdMax;
+  float* hid = mix + kHdSPB * kHdMax;
+  const int tid = threadIdx.x, sl = tid >> 5, jj = tid & 31;
+  const int b = blockIdx.x * kHdSPB + sl;
+  const bool live = b < B;
+  head_load_weights(ht, ws);
+  for (int g = 0; g < 2; ++g)
+    for (int i = jj; i < D; i += 32) xs[(sl * 2 + g) * kHdMax + i] = live ? (g == 0 ? pc : pa)[(int64_t)b * D + i] : 0.f;
+  __syncthreads();
+  head_forward_mix(ws, xs, fpre, ppre, mix, sl, jj, D, F, Mx);
+  const float* wt = ws + 2 * (D * F + F) + 2 * (F * Mx + Mx);
+  const float* mx = mix + sl * kHdMax;
+  if (kind == 0) {
+    if (jj < 3) {
+      float acc = wt[Mx * 3 + jj];
+      for (int i = 0; i < Mx; ++i) acc = fmaf(mx[i], wt[i * 3 + jj], acc);
+      hid[sl * kHdMax + jj] = acc;
+    }
+    __syncthreads();
+    if (jj == 0 && live) {
+      const float* vp = hid + sl * kHdMax;
+      const float Bc = fminf(fmaxf(softplus_stable(vp[1]), 0.f), 20.f);
+      const float Cc = fminf(fmaxf(softplus_stable(vp[2]), 0.1f), 50.f);
+      out[b] = vp[0] + Bc / (T[b] / 100.0f + Cc + 1e-6f);
+    }
+  } else {
+    const float* Wh = wt;
+    const float* bh = Wh + Mx * F;
+    const float* Wo = bh + F;
+    for (int j = jj; j < F; j += 32) {
+      float acc = bh[j];
+      for (int i = 0; i < Mx; ++i) acc = fmaf(mx[i], Wh[i * F + j], acc);
+      hid[sl * kHdMax + j] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    if (jj == 0 && live) {
+      float acc = Wo[F];
+      for (int j = 0; j < F; ++j) acc = fmaf(hid[sl * kHdMax + j], Wo[j], acc);
+      out[b] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void model_head_bwd_kernel(int kind, const float* __restrict__ pc,
+                                                             const float* __restrict__ pa, const float* __restrict__ T,
+                                                             HeadTensors ht, const float* __restrict__ dout,
+                                                             float* __restrict__ dpc, float* __restrict__ dpa, int B,
+                                                             int D, int F, int Mx) {
+  extern __shared__ __align__(16) float hsm[];
+  const int total = ht.off[ht.n];
+  const int tpad = (total + 3) & ~3;
+  float* ws = hsm;
+  float* dws = ws + tpad;                       // parameter-gradient sums of this workgroup
+  float* xs = dws + tpad;
+  float* fpre = xs + kHdSPB * 2 * kHdMax;
+  float* ppre = fpre + kHdSPB * 2 * kHdMax;
+  float* mix = ppre + kHdSPB * 2 * kHdMax;
+  float* hid = mix + kHdSPB * kHdMax;           // vp (kind 0) / hidden pre-activation (kind 1)
+  float* dmix = hid + kHdSPB * kHdMax;
+  float* dfp = dmix + kHdSPB * kHdMax;          // [kHdSPB][2][kHdMax]: gradient w.r.t. the fingerprint pre-activation
+  const int tid = threadIdx.x, sl = tid >> 5, jj = tid & 31;
+  const int b = blockIdx.x * kHdSPB + sl;
+  const bool live = b < B;
+  head_load_weights(ht, ws);
+  for (int t = tid; t < tpad; t += blockDim.x) dws[t] = 0.f;
+  for (int g = 0; g < 2; ++g)
+    for (int i = jj; i < D; i += 32) xs[(sl * 2 + g) * kHdMax + i] = live ? (g == 0 ? pc : pa)[(int64_t)b * D + i] : 0.f;
+  __syncthreads();
+  head_forward_mix(ws, xs, fpre, ppre, mix, sl, jj, D, F, Mx);
+  const int o_fp[2] = {0, D * F + F};
+  const int o_p0 = 2 * (D * F + F);
+  const int o_p[2] = {o_p0, o_p0 + F * Mx + Mx};
+  const int o_t = o_p0 + 2 * (F * Mx + Mx);
+  const float* mx = mix + sl * kHdMax;
+  const float d = live ? dout[b] : 0.f;
+  // ---- top of the head -> dmix
+  if (kind == 0) {
+    if (jj < 3) {
+      float acc = ws[o_t + Mx * 3 + jj];
+      for (int i = 0; i < Mx; ++i) acc = fmaf(mx[i], ws[o_t + i * 3 + jj], acc);
+      hid[sl * kHdMax + jj] = acc;
+    }
+    __syncthreads();
+    const float* vp = hid + sl * kHdMax;
+    const float sp1 = softplus_stable(vp[1]), sp2 = softplus_stable(vp[2]);
+    const float Bc = fminf(fmaxf(sp1, 0.f), 20.f), Cc = fminf(fmaxf(sp2, 0.1f), 50.f);
+    const float den = (live ? T[b] : 300.f) / 100.0f + Cc + 1e-6f;
+    float dvp[3];
+    dvp[0] = d;
+    dvp[1] = (sp1 >= 0.f && sp1 <= 20.f) ? d / den / (1.0f + expf(-vp[1])) : 0.f;          // clamp passes inside [min,max]
+    dvp[2] = (sp2 >= 0.1f && sp2 <= 50.f) ? -d * Bc / (den * den) / (1.0f + expf(-vp[2])) : 0.f;
+    for (int i = jj; i < Mx; i += 32) {
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        acc = fmaf(ws[o_t + i * 3 + c], dvp[c], acc);
+        atomicAdd(&dws[o_t + i * 3 + c], mx[i] * dvp[c]);
+      }
+      dmix[sl * kHdMax + i] = acc;
+    }
+    if (jj < 3) atomicAdd(&dws[o_t + Mx * 3 + jj], dvp[jj]);
+  } else {
+    const int o_bh = o_t + Mx * F, o_wo = o_bh + F, o_bo = o_wo + F;
+    for (int j = jj; j < F; j += 32) {
+      float acc = ws[o_bh + j];
+      for (int i = 0; i < Mx; ++i) acc = fmaf(mx[i], ws[o_t + i * F + j], acc);
+      hid[sl * kHdMax + j] = acc;  // pre-activation
+    }
+    __syncthreads();
+    for (int j = jj; j < F; j += 32) {
+      const float pre = hid[sl * kHdMax + j];
+      atomicAdd(&dws[o_wo + j], fmaxf(pre, 0.f) * d);
+      const float dh_ = pre > 0.f ? ws[o_wo + j] * d : 0.f;
+      atomicAdd(&dws[o_bh + j], dh_);
+      hid[sl * kHdMax + j] = dh_;  // now the gradient of the hidden pre-activation
+    }
+    if (jj == 0) atomicAdd(&dws[o_bo], d);
+    __syncthreads();
+    for (int i = jj; i < Mx; i += 32) {
+      float acc = 0.f;
+      for (int j = 0; j < F; ++j) {
+        const float dh_ = hid[sl * kHdMax + j];
+        acc = fmaf(ws[o_t + i * F + j], dh_, acc);
+        atomicAdd(&dws[o_t + i * F + j], mx[i] * dh_);
+      }
+      dmix[sl * kHdMax + i] = acc;
+    }
+  }
+  __syncthreads();
+  // ---- projections (relu) -> fingerprints (relu) -> pooled
+  for (int g = 0; g < 2; ++g) {
+    const float* fpg = fpre + (sl * 2 + g) * kHdMax;
+    const float* ppg = ppre + (sl * 2 + g) * kHdMax;
+    for (int j = jj; j < Mx; j += 32) {
+      const float dp = ppg[j] > 0.f ? dmix[sl * kHdMax + j] : 0.f;
+      atomicAdd(&dws[o_p[g] + F * Mx + j], dp);
+      for (int i = 0; i < F; ++i) atomicAdd(&dws[o_p[g] + i * Mx + j], fmaxf(fpg[i], 0.f) * dp);
+    }
+    for (int i = jj; i < F; i += 32) {
+      float acc = 0.f;
+      for (int j = 0; j < Mx; ++j) acc = fmaf(ws[o_p[g] + i * Mx + j], ppg[j] > 0.f ? dmix[sl * kHdMax + j] : 0.f, acc);
+      dfp[(sl * 2 + g) * kHdMax + i] = fpg[i] > 0.f ? acc : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int g = 0; g < 2; ++g) {
+    const float* x = xs + (sl * 2 + g) * kHdMax;
+    const float* dfg = dfp + (sl * 2 + g) * kHdMax;
+    for (int j = jj; j < F; j += 32) {
+      atomicAdd(&dws[o_fp[g] + D * F + j], dfg[j]);
+      for (int i = 0; i < D; ++i) atomicAdd(&dws[o_fp[g] + i * F + j], x[i] * dfg[j]);
+    }
+    float* dx = g == 0 ? dpc : dpa;
+    for (int i = jj; i < D; i += 32) {
+      float acc = 0.f;
+      for (int j = 0; j < F; ++j) acc = fmaf(ws[o_fp[g] + i * F + j], dfg[j], acc);
+      if (live) dx[(int64_t)b * D + i] = acc;
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < total; t += blockDim.x) {
+    const float v = dws[t];
+    if (v != 0.f) {
+      int sgm = 0;
+      while (sgm + 1 < ht.n && t >= ht.off[sgm + 1]) ++sgm;
+      atomicAdd(ht.g[sgm] + (t - ht.off[sgm]), v);
+    }
+  }
+}
+
 inline int grid_for(int64_t items, int cap = 256 * 8) {
   int64_t g = (items + kBlock - 1) / kBlock;
   if (g < 1) g = 1;
@@ -1663,6 +1897,53 @@ int launch_adam_clipnorm(const void* table, const void* sizes, int n_vars, int64
                                                static_cast<const long long*>(sizes), lr, b1, b2, eps, clipnorm,
                                                corr1, corr2, reinterpret_cast<const long long*>(step_dev));
   return check_launch("adam_clipnorm");
+}
+
+static int head_tensor_table(int kind, const float* const* weights, float* const* grads, int D, int F, int Mx,
+                             HeadTensors* ht) {
+  const int sizes0[10] = {D * F, F, D * F, F, F * Mx, Mx, F * Mx, Mx, Mx * 3, 3};
+  const int sizes1[12] = {D * F, F, D * F, F, F * Mx, Mx, F * Mx, Mx, Mx * F, F, F, 1};
+  ht->n = kind == 0 ? 10 : 12;
+  int off = 0;
+  for (int i = 0; i < ht->n; ++i) {
+    if (!weights[i]) return fail(IMPNN_E_BADARG, "model_head: null weight tensor %d", i);
+    ht->w[i] = weights[i];
+    ht->g[i] = grads ? grads[i] : nullptr;
+    if (grads && !grads[i]) return fail(IMPNN_E_BADARG, "model_head_bwd: null gradient tensor %d", i);
+    ht->off[i] = off;
+    off += kind == 0 ? sizes0[i] : sizes1[i];
+  }
+  ht->off[ht->n] = off;
+  return IMPNN_OK;
+}
+
+int launch_model_head_tensors(int kind, const float* pc, const float* pa, const float* T, const float* const* weights,
+                              float* out, int B, int D, int F, int Mx, hipStream_t s) {
+  if (D > kHdMax || F > kHdMax || Mx > kHdMax)
+    return fail(IMPNN_E_UNSUPPORTED, "model_head: dims D=%d F=%d Mx=%d exceed %d", D, F, Mx, kHdMax);
+  HeadTensors ht{};
+  if (int rc = head_tensor_table(kind, weights, nullptr, D, F, Mx, &ht)) return rc;
+  const size_t lds = sizeof(float) * (((size_t)ht.off[ht.n] + 3) / 4 * 4 + (size_t)kHdSPB * 8 * kHdMax);
+  if (lds > 64 * 1024) return fail(IMPNN_E_UNSUPPORTED, "model_head: weights do not fit LDS");
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)model_head_tensors_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  model_head_tensors_kernel<<<(B + kHdSPB - 1) / kHdSPB, 256, lds, s>>>(kind, pc, pa, T, ht, out, B, D, F, Mx);
+  return check_launch("model_head_tensors");
+}
+
+int launch_model_head_bwd(int kind, const float* pc, const float* pa, const float* T, const float* const* weights,
+                          const float* dout, float* dpc, float* dpa, float* const* grads, int B, int D, int F, int Mx,
+                          hipStream_t s) {
+  if (D > kHdMax || F > kHdMax || Mx > kHdMax)
+    return fail(IMPNN_E_UNSUPPORTED, "model_head_bwd: dims D=%d F=%d Mx=%d exceed %d", D, F, Mx, kHdMax);
+  HeadTensors ht{};
+  if (int rc = head_tensor_table(kind, weights, grads, D, F, Mx, &ht)) return rc;
+  const size_t lds = sizeof(float) * (2 * (((size_t)ht.off[ht.n] + 3) / 4 * 4) + (size_t)kHdSPB * 11 * kHdMax);
+  if (lds > 96 * 1024) return fail(IMPNN_E_UNSUPPORTED, "model_head_bwd: weights do not fit LDS");
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)model_head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  model_head_bwd_kernel<<<(B + kHdSPB - 1) / kHdSPB, 256, lds, s>>>(kind, pc, pa, T, ht, dout, dpc, dpa, B, D, F, Mx);
+  return check_launch("model_head_bwd");
 }
 
 }  // namespace impnn

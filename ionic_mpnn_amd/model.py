@@ -193,18 +193,23 @@ class MPNNModel:
             for lyr in self.branches[p]["bmm"]:
                 lyr.invalidate_cache()
 
+    def _head_tensors(self):
+        """Head weight tensors in the order of impnn_model_head's packed layout (include/impnn.h)."""
+        parts = []
+        for p in ("cat", "an"):
+            parts += [self.branches[p]["fp"].kernel, self.branches[p]["fp"].bias]
+        parts += [self.cat_proj.kernel, self.cat_proj.bias, self.an_proj.kernel, self.an_proj.bias]
+        if self.kind == "viscosity":
+            parts += [self.visc_params.kernel, self.visc_params.bias]
+        else:
+            parts += [self.mp_hidden.kernel, self.mp_hidden.bias, self.mp_out.kernel, self.mp_out.bias]
+        return parts
+
     def _packed_head(self):
         """Head weights in the layout of impnn_model_head (include/impnn.h), cached per weight version."""
         if getattr(self, "_head_packed", None) is None:
-            parts = []
-            for p in ("cat", "an"):
-                parts += [self.branches[p]["fp"].kernel, self.branches[p]["fp"].bias]
-            parts += [self.cat_proj.kernel, self.cat_proj.bias, self.an_proj.kernel, self.an_proj.bias]
-            if self.kind == "viscosity":
-                parts += [self.visc_params.kernel, self.visc_params.bias]
-            else:
-                parts += [self.mp_hidden.kernel, self.mp_hidden.bias, self.mp_out.kernel, self.mp_out.bias]
-            self._head_packed = torch.cat([t.reshape(-1) for t in parts]).contiguous()
+            with torch.no_grad():
+                self._head_packed = torch.cat([t.reshape(-1) for t in self._head_tensors()]).contiguous()
         return self._head_packed
 
     def _prepared_weights(self, mode):
@@ -304,6 +309,12 @@ class MPNNModel:
         if trace is None and not differentiable and max(self.atom_dim, self.fp_size, self.mixing_size) <= 64:
             return ops.model_head(self.kind, pooled_cat, pooled_an, temperature, self._packed_head(), self.fp_size,
                                   self.mixing_size)  # one launch
+        if trace is None and differentiable and max(self.atom_dim, self.fp_size, self.mixing_size) <= 64 \
+                and torch.is_grad_enabled():
+            from . import autograd
+            T = temperature if self.kind == "viscosity" else None
+            return autograd.ModelHead.apply({"viscosity": 0, "melting_point": 1}[self.kind], self.fp_size,
+                                            self.mixing_size, pooled_cat, pooled_an, T, *self._head_tensors())
         fp_cat = self.branches["cat"]["fp"](pooled_cat)   # Dense(fp_size, relu), :189
         fp_an = self.branches["an"]["fp"](pooled_an)
         mixed = self.mix([self.cat_proj(fp_cat), self.an_proj(fp_an)])

@@ -152,6 +152,50 @@ def test_melting_point_model_gradients_match_the_oracle():
         close(t.grad, wo[name].grad, 2e-4, f"grad {name}")
 
 
+@pytest.mark.parametrize("kind", ["viscosity", "melting_point"])
+@pytest.mark.parametrize("sinks", [False, True])
+def test_head_node_matches_the_layer_by_layer_head(kind, sinks):
+    """impnn_model_head_tensors / impnn_model_head_bwd against the torch-op head (Dense, relu, Add, softplus, clip,
+    LogViscosity), including samples inside the clip plateaus (zero gradient through B or C) and a batch that is not
+    a multiple of the 8 samples a workgroup takes."""
+    Va, Vb, D, K, B = 11, 6, 16, 4, 203
+    build = MM.build_model if kind == "viscosity" else MM.build_melting_point_model
+    kw = dict(atom_dim=D, fp_size=12, mixing_size=10, num_steps=1, device=DEV)
+    if kind == "viscosity":
+        kw["bond_dim"] = K
+    m = build(Va, Vb, **kw)
+    m.load_weights(weights.init_weights(kind, Va, Vb, atom_dim=D, bond_dim=K if kind == "viscosity" else D * D,
+                                        fp_size=12, mixing_size=10, num_steps=1, seed=9, perturb=True))
+    g = torch.Generator(device="cpu").manual_seed(3)
+    pc = (torch.randn(B, D, generator=g) * 3).to(DEV).requires_grad_(True)
+    pa = (torch.randn(B, D, generator=g) * 3).to(DEV).requires_grad_(True)
+    T = (torch.rand(B, 1, generator=g) * 150 + 250).to(DEV)
+    go = torch.randn(B, 1, generator=g).to(DEV)
+    if kind == "viscosity":
+        with torch.no_grad():  # push b and c of some samples onto the clip plateaus
+            m.visc_params.kernel.mul_(6.0)
+    params = m._head_tensors()
+    for t in params:
+        t.requires_grad_(True)
+        t.grad = None
+    ref = m.head(pc, pa, T, trace={}, differentiable=True)
+    (ref * go).sum().backward()
+    want = [t.grad.clone() for t in params] + [pc.grad.clone(), pa.grad.clone()]
+    if kind == "viscosity":
+        vp = m.visc_params(m.mix([m.cat_proj(m.branches["cat"]["fp"](pc)), m.an_proj(m.branches["an"]["fp"](pa))]))
+        sp = torch.nn.functional.softplus(vp.detach())
+        assert (sp[:, 1] > 20).any() and (sp[:, 2] < 0.1).any() and ((sp[:, 1] < 20) & (sp[:, 2] > 0.1)).any()
+    pc.grad = pa.grad = None
+    for t in params:
+        t.grad = torch.zeros_like(t) if sinks else None
+    got = m.head(pc, pa, T, differentiable=True)
+    close(got, ref, 1e-5, "head forward")
+    (got * go).sum().backward()
+    have = [t.grad for t in params] + [pc.grad, pa.grad]
+    for i, (a, b) in enumerate(zip(have, want)):
+        close(a, b, 1e-4, f"head gradient {i}")
+
+
 def test_config5_shape_trains_without_nonfinite_gradients():
     """D=128, S=6 (SURVEY config 5): untrained pre-activations of the viscosity head exceed 88, where a naive
     log1p(exp(x)) differentiates to NaN."""
