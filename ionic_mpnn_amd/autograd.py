@@ -126,7 +126,8 @@ class BmmMessageTyped(torch.autograd.Function):
         B, N, D = h.shape
         E, Vb = conn.shape[1], mats.shape[0]
         dm = f32c(dm)
-        dh, dmats = torch.zeros_like(h), torch.zeros_like(mats)
+        both = torch.zeros(h.numel() + mats.numel(), dtype=torch.float32, device=h.device)  # one fill for both sums
+        dh, dmats = both[:h.numel()].view_as(h), both[h.numel():].view_as(mats)
         lib = _lib.load()
         # the edge sort by bond type depends on (conn, bond_ids) only: shared inside a training pass
         holder, bond_obj, pass_id = ctx.graph_key  # the objects the forward saw (saved tensors may be re-wrapped)

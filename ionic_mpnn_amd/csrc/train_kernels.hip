@@ -364,7 +364,15 @@ __global__ void bond_type_matrices_bwd_w_kernel(const float* __restrict__ tb, co
   const int k = blockIdx.y;
   for (int ij = blockIdx.x * blockDim.x + threadIdx.x; ij < DD; ij += gridDim.x * blockDim.x) {
     float acc = 0.f;
-    for (int v = 0; v < Vb; ++v) acc = fmaf(tb[(int64_t)v * K + k], dA[(int64_t)v * DD + ij], acc);
+    int v = 0;
+    for (; v + 16 <= Vb; v += 16) {  // 16 independent rows in flight; the adds stay in vocabulary order
+      float x[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) x[u] = dA[(int64_t)(v + u) * DD + ij];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = fmaf(tb[(int64_t)(v + u) * K + k], x[u], acc);
+    }
+    for (; v < Vb; ++v) acc = fmaf(tb[(int64_t)v * K + k], dA[(int64_t)v * DD + ij], acc);
     dW[(int64_t)k * DD + ij] = accumulate ? dW[(int64_t)k * DD + ij] + acc : acc;
   }
 }
@@ -1411,12 +1419,52 @@ struct HeadTensors {
 };
 __device__ __forceinline__ float softplus_stable(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
 
+__device__ __forceinline__ int head_total(const HeadTensors& ht) {
+  int tot = ht.off[1];
+#pragma unroll
+  for (int q = 2; q <= kHdTensors; ++q) tot = ht.n == q ? ht.off[q] : tot;
+  return tot;
+}
+// segment of packed index t.  Constant indices only: the table is a kernel argument, a dynamic index into it would
+// be a dependent load from the kernarg segment per probe.
+__device__ __forceinline__ int head_segment(const HeadTensors& ht, int t, int* base) {
+  int sgm = 0, b = 0;
+#pragma unroll
+  for (int q = 1; q < kHdTensors; ++q)
+    if (q < ht.n && t >= ht.off[q]) sgm = q, b = ht.off[q];
+  *base = b;
+  return sgm;
+}
+__device__ __forceinline__ const float* head_wptr(const HeadTensors& ht, int sgm) {
+  const float* p = ht.w[0];
+#pragma unroll
+  for (int q = 1; q < kHdTensors; ++q) p = sgm == q ? ht.w[q] : p;
+  return p;
+}
+__device__ __forceinline__ float* head_gptr(const HeadTensors& ht, int sgm) {
+  float* p = ht.g[0];
+#pragma unroll
+  for (int q = 1; q < kHdTensors; ++q) p = sgm == q ? ht.g[q] : p;
+  return p;
+}
+
 __device__ __forceinline__ void head_load_weights(const HeadTensors& ht, float* ws) {
-  const int total = ht.off[ht.n];
-  for (int t = threadIdx.x; t < total; t += blockDim.x) {
-    int sgm = 0;
-    while (sgm + 1 < ht.n && t >= ht.off[sgm + 1]) ++sgm;
-    ws[t] = ht.w[sgm][t - ht.off[sgm]];
+  const int total = head_total(ht);
+  constexpr int kU = 8;  // independent loads in flight per thread
+  for (int t0 = threadIdx.x; t0 < total; t0 += blockDim.x * kU) {
+    float v[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int t = t0 + u * blockDim.x;
+      int base;
+      const int sgm = head_segment(ht, t, &base);
+      v[u] = t < total ? head_wptr(ht, sgm)[t - base] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int t = t0 + u * blockDim.x;
+      if (t < total) ws[t] = v[u];
+    }
   }
 }
 
@@ -1453,7 +1501,7 @@ __global__ __launch_bounds__(256) void model_head_tensors_kernel(int kind, const
                                                                  const float* __restrict__ T, HeadTensors ht,
                                                                  float* __restrict__ out, int B, int D, int F, int Mx) {
   extern __shared__ __align__(16) float hsm[];
-  const int total = ht.off[ht.n];
+  const int total = head_total(ht);
   float* ws = hsm;
   float* xs = ws + ((total + 3) & ~3);
   float* fpre = xs + kHdSPB * 2 * kHdMax;
@@ -1501,129 +1549,167 @@ __global__ __launch_bounds__(256) void model_head_tensors_kernel(int kind, const
   }
 }
 
+// per-sample vectors of the backward, kHdMax floats each, in LDS: the parameter gradients are outer products of these
+enum { kVX0, kVX1, kVFp0, kVFp1, kVDfp0, kVDfp1, kVDpr0, kVDpr1, kVMix, kVTop, kVHid, kVOne, kHdVecs };
+
 __global__ __launch_bounds__(256) void model_head_bwd_kernel(int kind, const float* __restrict__ pc,
                                                              const float* __restrict__ pa, const float* __restrict__ T,
                                                              HeadTensors ht, const float* __restrict__ dout,
                                                              float* __restrict__ dpc, float* __restrict__ dpa, int B,
                                                              int D, int F, int Mx) {
   extern __shared__ __align__(16) float hsm[];
-  const int total = ht.off[ht.n];
+  const int total = head_total(ht);
   const int tpad = (total + 3) & ~3;
   float* ws = hsm;
-  float* dws = ws + tpad;                       // parameter-gradient sums of this workgroup
-  float* xs = dws + tpad;
-  float* fpre = xs + kHdSPB * 2 * kHdMax;
+  float* dws = ws + tpad;  // parameter-gradient sums of this workgroup; element t is owned by thread t % 256
+  float* vec = dws + tpad;  // [kHdSPB][kHdVecs][kHdMax]
+  float* fpre = vec + kHdSPB * kHdVecs * kHdMax;
   float* ppre = fpre + kHdSPB * 2 * kHdMax;
-  float* mix = ppre + kHdSPB * 2 * kHdMax;
-  float* hid = mix + kHdSPB * kHdMax;           // vp (kind 0) / hidden pre-activation (kind 1)
-  float* dmix = hid + kHdSPB * kHdMax;
-  float* dfp = dmix + kHdSPB * kHdMax;          // [kHdSPB][2][kHdMax]: gradient w.r.t. the fingerprint pre-activation
   const int tid = threadIdx.x, sl = tid >> 5, jj = tid & 31;
-  const int b = blockIdx.x * kHdSPB + sl;
-  const bool live = b < B;
+  float* my = vec + sl * kHdVecs * kHdMax;
+  auto V = [&](int which) { return my + which * kHdMax; };
   head_load_weights(ht, ws);
   for (int t = tid; t < tpad; t += blockDim.x) dws[t] = 0.f;
-  for (int g = 0; g < 2; ++g)
-    for (int i = jj; i < D; i += 32) xs[(sl * 2 + g) * kHdMax + i] = live ? (g == 0 ? pc : pa)[(int64_t)b * D + i] : 0.f;
-  __syncthreads();
-  head_forward_mix(ws, xs, fpre, ppre, mix, sl, jj, D, F, Mx);
   const int o_fp[2] = {0, D * F + F};
   const int o_p0 = 2 * (D * F + F);
   const int o_p[2] = {o_p0, o_p0 + F * Mx + Mx};
   const int o_t = o_p0 + 2 * (F * Mx + Mx);
-  const float* mx = mix + sl * kHdMax;
-  const float d = live ? dout[b] : 0.f;
-  // ---- top of the head -> dmix
-  if (kind == 0) {
-    if (jj < 3) {
-      float acc = ws[o_t + Mx * 3 + jj];
-      for (int i = 0; i < Mx; ++i) acc = fmaf(mx[i], ws[o_t + i * 3 + jj], acc);
-      hid[sl * kHdMax + jj] = acc;
-    }
+
+  for (int b0 = blockIdx.x * kHdSPB; b0 < B; b0 += gridDim.x * kHdSPB) {
+    const int b = b0 + sl;
+    const bool live = b < B;
+    __syncthreads();  // the previous group's outer products are done with vec
+    // xs of head_forward_mix = vectors kVX0,kVX1 (contiguous)
+    for (int g = 0; g < 2; ++g)
+      for (int i = jj; i < D; i += 32) V(kVX0 + g)[i] = live ? (g == 0 ? pc : pa)[(int64_t)b * D + i] : 0.f;
     __syncthreads();
-    const float* vp = hid + sl * kHdMax;
-    const float sp1 = softplus_stable(vp[1]), sp2 = softplus_stable(vp[2]);
-    const float Bc = fminf(fmaxf(sp1, 0.f), 20.f), Cc = fminf(fmaxf(sp2, 0.1f), 50.f);
-    const float den = (live ? T[b] : 300.f) / 100.0f + Cc + 1e-6f;
-    float dvp[3];
-    dvp[0] = d;
-    dvp[1] = (sp1 >= 0.f && sp1 <= 20.f) ? d / den / (1.0f + expf(-vp[1])) : 0.f;          // clamp passes inside [min,max]
-    dvp[2] = (sp2 >= 0.1f && sp2 <= 50.f) ? -d * Bc / (den * den) / (1.0f + expf(-vp[2])) : 0.f;
-    for (int i = jj; i < Mx; i += 32) {
-      float acc = 0.f;
+    {  // forward (same arithmetic as head_forward_mix, on this kernel's vector layout)
+      for (int g = 0; g < 2; ++g)
+        for (int j = jj; j < F; j += 32) {
+          float acc = ws[o_fp[g] + D * F + j];
+          const float* x = V(kVX0 + g);
+          for (int i = 0; i < D; ++i) acc = fmaf(x[i], ws[o_fp[g] + i * F + j], acc);
+          fpre[(sl * 2 + g) * kHdMax + j] = acc;
+          V(kVFp0 + g)[j] = fmaxf(acc, 0.f);
+        }
+      __syncthreads();
+      for (int j = jj; j < Mx; j += 32) {
+        float m = 0.f;
+        for (int g = 0; g < 2; ++g) {
+          float acc = ws[o_p[g] + F * Mx + j];
+          const float* x = V(kVFp0 + g);
+          for (int i = 0; i < F; ++i) acc = fmaf(x[i], ws[o_p[g] + i * Mx + j], acc);
+          ppre[(sl * 2 + g) * kHdMax + j] = acc;
+          m += fmaxf(acc, 0.f);
+        }
+        V(kVMix)[j] = m;
+      }
+      __syncthreads();
+    }
+    const float* mx = V(kVMix);
+    const float d = live ? dout[b] : 0.f;
+    float* top = V(kVTop);
+    if (jj == 0) V(kVOne)[0] = d;
+    // ---- top of the head: kVTop = gradient of [A,b,c] (kind 0) / of the hidden pre-activation (kind 1)
+    if (kind == 0) {
+      if (jj < 3) {
+        float acc = ws[o_t + Mx * 3 + jj];
+        for (int i = 0; i < Mx; ++i) acc = fmaf(mx[i], ws[o_t + i * 3 + jj], acc);
+        V(kVHid)[jj] = acc;
+      }
+      __syncthreads();
+      const float* vp = V(kVHid);
+      const float sp1 = softplus_stable(vp[1]), sp2 = softplus_stable(vp[2]);
+      const float Bc = fminf(fmaxf(sp1, 0.f), 20.f), Cc = fminf(fmaxf(sp2, 0.1f), 50.f);
+      const float den = (live ? T[b] : 300.f) / 100.0f + Cc + 1e-6f;
+      float dvp[3];
+      dvp[0] = d;
+      dvp[1] = (sp1 >= 0.f && sp1 <= 20.f) ? d / den / (1.0f + expf(-vp[1])) : 0.f;  // clamp passes inside [min,max]
+      dvp[2] = (sp2 >= 0.1f && sp2 <= 50.f) ? -d * Bc / (den * den) / (1.0f + expf(-vp[2])) : 0.f;
+      if (jj < 3) top[jj] = jj == 0 ? dvp[0] : (jj == 1 ? dvp[1] : dvp[2]);
+      for (int i = jj; i < Mx; i += 32) {
+        float acc = 0.f;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        acc = fmaf(ws[o_t + i * 3 + c], dvp[c], acc);
-        atomicAdd(&dws[o_t + i * 3 + c], mx[i] * dvp[c]);
+        for (int c = 0; c < 3; ++c) acc = fmaf(ws[o_t + i * 3 + c], dvp[c], acc);
+        V(kVDpr0)[i] = ppre[(sl * 2 + 0) * kHdMax + i] > 0.f ? acc : 0.f;
+        V(kVDpr1)[i] = ppre[(sl * 2 + 1) * kHdMax + i] > 0.f ? acc : 0.f;
       }
-      dmix[sl * kHdMax + i] = acc;
-    }
-    if (jj < 3) atomicAdd(&dws[o_t + Mx * 3 + jj], dvp[jj]);
-  } else {
-    const int o_bh = o_t + Mx * F, o_wo = o_bh + F, o_bo = o_wo + F;
-    for (int j = jj; j < F; j += 32) {
-      float acc = ws[o_bh + j];
-      for (int i = 0; i < Mx; ++i) acc = fmaf(mx[i], ws[o_t + i * F + j], acc);
-      hid[sl * kHdMax + j] = acc;  // pre-activation
+    } else {
+      const int o_bh = o_t + Mx * F, o_wo = o_bh + F;
+      for (int j = jj; j < F; j += 32) {
+        float acc = ws[o_bh + j];
+        for (int i = 0; i < Mx; ++i) acc = fmaf(mx[i], ws[o_t + i * F + j], acc);
+        V(kVHid)[j] = fmaxf(acc, 0.f);
+        top[j] = acc > 0.f ? ws[o_wo + j] * d : 0.f;
+      }
+      __syncthreads();
+      for (int i = jj; i < Mx; i += 32) {
+        float acc = 0.f;
+        for (int j = 0; j < F; ++j) acc = fmaf(ws[o_t + i * F + j], top[j], acc);
+        V(kVDpr0)[i] = ppre[(sl * 2 + 0) * kHdMax + i] > 0.f ? acc : 0.f;
+        V(kVDpr1)[i] = ppre[(sl * 2 + 1) * kHdMax + i] > 0.f ? acc : 0.f;
+      }
     }
     __syncthreads();
-    for (int j = jj; j < F; j += 32) {
-      const float pre = hid[sl * kHdMax + j];
-      atomicAdd(&dws[o_wo + j], fmaxf(pre, 0.f) * d);
-      const float dh_ = pre > 0.f ? ws[o_wo + j] * d : 0.f;
-      atomicAdd(&dws[o_bh + j], dh_);
-      hid[sl * kHdMax + j] = dh_;  // now the gradient of the hidden pre-activation
-    }
-    if (jj == 0) atomicAdd(&dws[o_bo], d);
-    __syncthreads();
-    for (int i = jj; i < Mx; i += 32) {
-      float acc = 0.f;
-      for (int j = 0; j < F; ++j) {
-        const float dh_ = hid[sl * kHdMax + j];
-        acc = fmaf(ws[o_t + i * F + j], dh_, acc);
-        atomicAdd(&dws[o_t + i * F + j], mx[i] * dh_);
+    // ---- projections (relu) -> fingerprints (relu) -> pooled
+    for (int g = 0; g < 2; ++g) {
+      const float* dpr = V(kVDpr0 + g);
+      for (int i = jj; i < F; i += 32) {
+        float acc = 0.f;
+        for (int j = 0; j < Mx; ++j) acc = fmaf(ws[o_p[g] + i * Mx + j], dpr[j], acc);
+        V(kVDfp0 + g)[i] = fpre[(sl * 2 + g) * kHdMax + i] > 0.f ? acc : 0.f;
       }
-      dmix[sl * kHdMax + i] = acc;
     }
-  }
-  __syncthreads();
-  // ---- projections (relu) -> fingerprints (relu) -> pooled
-  for (int g = 0; g < 2; ++g) {
-    const float* fpg = fpre + (sl * 2 + g) * kHdMax;
-    const float* ppg = ppre + (sl * 2 + g) * kHdMax;
-    for (int j = jj; j < Mx; j += 32) {
-      const float dp = ppg[j] > 0.f ? dmix[sl * kHdMax + j] : 0.f;
-      atomicAdd(&dws[o_p[g] + F * Mx + j], dp);
-      for (int i = 0; i < F; ++i) atomicAdd(&dws[o_p[g] + i * Mx + j], fmaxf(fpg[i], 0.f) * dp);
+    __syncthreads();
+    for (int g = 0; g < 2; ++g) {
+      const float* dfg = V(kVDfp0 + g);
+      float* dx = g == 0 ? dpc : dpa;
+      for (int i = jj; i < D; i += 32) {
+        float acc = 0.f;
+        for (int j = 0; j < F; ++j) acc = fmaf(ws[o_fp[g] + i * F + j], dfg[j], acc);
+        if (live) dx[(int64_t)b * D + i] = acc;
+      }
     }
-    for (int i = jj; i < F; i += 32) {
+    // ---- parameter gradients: element t of the packed layout = sum over the samples of a[i] * b[j]
+    for (int t = tid; t < total; t += blockDim.x) {
+      int base;
+      const int sgm = head_segment(ht, t, &base);
+      const int loc = t - base;
+      int va, vb, ncols;  // va < 0: a bias (sum of b[j])
+      switch (sgm) {
+        case 0: va = kVX0, vb = kVDfp0, ncols = F; break;
+        case 1: va = -1, vb = kVDfp0, ncols = F; break;
+        case 2: va = kVX1, vb = kVDfp1, ncols = F; break;
+        case 3: va = -1, vb = kVDfp1, ncols = F; break;
+        case 4: va = kVFp0, vb = kVDpr0, ncols = Mx; break;
+        case 5: va = -1, vb = kVDpr0, ncols = Mx; break;
+        case 6: va = kVFp1, vb = kVDpr1, ncols = Mx; break;
+        case 7: va = -1, vb = kVDpr1, ncols = Mx; break;
+        case 8: va = kVMix, vb = kVTop, ncols = kind == 0 ? 3 : F; break;
+        case 9: va = -1, vb = kVTop, ncols = kind == 0 ? 3 : F; break;
+        case 10: va = kVHid, vb = kVOne, ncols = 1; break;  // Wo (F,1): hidden * dout
+        default: va = -1, vb = kVOne, ncols = 1; break;     // bo
+      }
+      const int i = loc / ncols, j = loc - i * ncols;
       float acc = 0.f;
-      for (int j = 0; j < Mx; ++j) acc = fmaf(ws[o_p[g] + i * Mx + j], ppg[j] > 0.f ? dmix[sl * kHdMax + j] : 0.f, acc);
-      dfp[(sl * 2 + g) * kHdMax + i] = fpg[i] > 0.f ? acc : 0.f;
-    }
-  }
-  __syncthreads();
-  for (int g = 0; g < 2; ++g) {
-    const float* x = xs + (sl * 2 + g) * kHdMax;
-    const float* dfg = dfp + (sl * 2 + g) * kHdMax;
-    for (int j = jj; j < F; j += 32) {
-      atomicAdd(&dws[o_fp[g] + D * F + j], dfg[j]);
-      for (int i = 0; i < D; ++i) atomicAdd(&dws[o_fp[g] + i * F + j], x[i] * dfg[j]);
-    }
-    float* dx = g == 0 ? dpc : dpa;
-    for (int i = jj; i < D; i += 32) {
-      float acc = 0.f;
-      for (int j = 0; j < F; ++j) acc = fmaf(ws[o_fp[g] + i * F + j], dfg[j], acc);
-      if (live) dx[(int64_t)b * D + i] = acc;
+      if (va < 0) {
+#pragma unroll
+        for (int q = 0; q < kHdSPB; ++q) acc += vec[(q * kHdVecs + vb) * kHdMax + j];
+      } else {
+#pragma unroll
+        for (int q = 0; q < kHdSPB; ++q)
+          acc = fmaf(vec[(q * kHdVecs + va) * kHdMax + i], vec[(q * kHdVecs + vb) * kHdMax + j], acc);
+      }
+      dws[t] += acc;
     }
   }
   __syncthreads();
   for (int t = tid; t < total; t += blockDim.x) {
     const float v = dws[t];
     if (v != 0.f) {
-      int sgm = 0;
-      while (sgm + 1 < ht.n && t >= ht.off[sgm + 1]) ++sgm;
-      atomicAdd(ht.g[sgm] + (t - ht.off[sgm]), v);
+      int base;
+      const int sgm = head_segment(ht, t, &base);
+      atomicAdd(head_gptr(ht, sgm) + (t - base), v);
     }
   }
 }
@@ -1938,11 +2024,13 @@ int launch_model_head_bwd(int kind, const float* pc, const float* pa, const floa
     return fail(IMPNN_E_UNSUPPORTED, "model_head_bwd: dims D=%d F=%d Mx=%d exceed %d", D, F, Mx, kHdMax);
   HeadTensors ht{};
   if (int rc = head_tensor_table(kind, weights, grads, D, F, Mx, &ht)) return rc;
-  const size_t lds = sizeof(float) * (2 * (((size_t)ht.off[ht.n] + 3) / 4 * 4) + (size_t)kHdSPB * 11 * kHdMax);
-  if (lds > 96 * 1024) return fail(IMPNN_E_UNSUPPORTED, "model_head_bwd: weights do not fit LDS");
+  const size_t lds =
+      sizeof(float) * (2 * (((size_t)ht.off[ht.n] + 3) / 4 * 4) + (size_t)kHdSPB * (kHdVecs + 4) * kHdMax);
+  if (lds > 160 * 1024) return fail(IMPNN_E_UNSUPPORTED, "model_head_bwd: weights do not fit LDS");
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)model_head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  model_head_bwd_kernel<<<(B + kHdSPB - 1) / kHdSPB, 256, lds, s>>>(kind, pc, pa, T, ht, dout, dpc, dpa, B, D, F, Mx);
+  const int groups = (B + kHdSPB - 1) / kHdSPB;  // bounded grid: every workgroup flushes ~|weights| atomics once
+  model_head_bwd_kernel<<<groups < 512 ? groups : 512, 256, lds, s>>>(kind, pc, pa, T, ht, dout, dpc, dpa, B, D, F, Mx);
   return check_launch("model_head_bwd");
 }
 
