@@ -331,7 +331,7 @@ class MPNNModel:
     def __call__(self, inputs, fused=None, trace=None, training=False):
         """Inference by default (no graph is kept, the fused encoder and the head kernel run).  With
         ``training=True`` the call is differentiable: layer-at-a-time path (ionic_mpnn_amd.autograd) and the
-        head in torch ops."""
+        head as one autograd node over impnn_model_head_tensors / impnn_model_head_bwd."""
         inputs = self._to_device(inputs)
         if training:
             from . import autograd
