@@ -258,6 +258,13 @@ int impnn_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const i
                                 const float* type_mats, const float* dmessages, float* dh, float* dtype_mats,
                                 void* workspace, int64_t workspace_bytes, int32_t B, int32_t N, int32_t E, int32_t D,
                                 int32_t Vb, int32_t sorted_ready, impnn_stream_t stream);
+/*  Backward of Reduce o BondMatrixMessage in one launch (models/layers.py:57-83 after :100-117): the gradient of a
+ *  message IS the gradient of the aggregate row it was added to, so the (B,E,D) message gradient is never
+ *  materialised - the kernel reads dagg (B,N,D) at row tgt(e).  Otherwise identical to impnn_bmm_message_typed_bwd. */
+int impnn_message_reduce_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn,
+                                   const float* type_mats, const float* dagg, float* dh, float* dtype_mats,
+                                   void* workspace, int64_t workspace_bytes, int32_t B, int32_t N, int32_t E,
+                                   int32_t D, int32_t Vb, int32_t sorted_ready, impnn_stream_t stream);
 int impnn_bond_type_matrices_bwd(const float* bond_table, const float* W, const float* dtype_mats, float* dW,
                                  float* dbond_table, int32_t Vb, int32_t K, int32_t D, int32_t accumulate,
                                  impnn_stream_t stream);

@@ -142,6 +142,39 @@ class BmmMessageTyped(torch.autograd.Function):
         return dh, None, None, dmats
 
 
+class MessageReduceTyped(torch.autograd.Function):
+    """Reduce o BondMatrixMessage as one node (models/layers.py:100-117 then :57-83): the forward runs the two entries
+    and keeps no messages; the backward reads the aggregate's gradient at every edge's target row
+    (impnn_message_reduce_typed_bwd), so neither the (B,E,D) messages nor their gradient outlive the forward."""
+
+    @staticmethod
+    def forward(ctx, h, bond_ids, conn, type_mats):
+        h, type_mats, bond_ids, conn = f32c(h), f32c(type_mats), i32c(bond_ids), i32c(conn)
+        ctx.save_for_backward(h, bond_ids, conn, type_mats)
+        ctx.graph_key = (conn, bond_ids, _pass["id"])
+        m = ops.bmm_message_typed(h, bond_ids, conn, type_mats)
+        return ops.reduce_scatter_add(m, conn[:, :, 1], h.shape[1])
+
+    @staticmethod
+    def backward(ctx, dagg):
+        h, bond_ids, conn, mats = ctx.saved_tensors
+        B, N, D = h.shape
+        E, Vb = conn.shape[1], mats.shape[0]
+        dagg = f32c(dagg)
+        both = torch.zeros(h.numel() + mats.numel(), dtype=torch.float32, device=h.device)
+        dh, dmats = both[:h.numel()].view_as(h), both[h.numel():].view_as(mats)
+        holder, bond_obj, pass_id = ctx.graph_key
+        prev = _pass["id"]
+        _pass["id"] = pass_id
+        try:
+            ws, ready = ops.edge_sort_workspace(holder, bond_obj, B, E, Vb)
+        finally:
+            _pass["id"] = prev
+        _lib_call(h.device, _lib.load().impnn_message_reduce_typed_bwd, ptr(h), ptr(bond_ids), ptr(conn), ptr(mats),
+                  ptr(dagg), ptr(dh), ptr(dmats), ptr(ws), ws.numel(), B, N, E, D, Vb, 1 if ready else 0)
+        return dh, None, None, dmats
+
+
 class ReduceScatterAdd(torch.autograd.Function):
     """Reduce.call (models/layers.py:57-83)."""
 

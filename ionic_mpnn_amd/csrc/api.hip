@@ -409,7 +409,22 @@ int impnn_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const i
   if (workspace_bytes < impnn_bmm_message_typed_bwd_workspace_bytes(B, E, Vb))
     return fail(IMPNN_E_WORKSPACE, "bmm_message_typed_bwd: workspace of %lld bytes is too small", (long long)workspace_bytes);
   return launch_bmm_message_typed_bwd(h, bond_ids, conn, type_mats, dmessages, dh, dtype_mats,
-                                      static_cast<int32_t*>(workspace), B, N, E, D, Vb, sorted_ready != 0,
+                                      static_cast<int32_t*>(workspace), B, N, E, D, Vb, sorted_ready != 0, 0,
+                                      as_stream(stream));
+}
+
+int impnn_message_reduce_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn,
+                                   const float* type_mats, const float* dagg, float* dh, float* dtype_mats,
+                                   void* workspace, int64_t workspace_bytes, int32_t B, int32_t N, int32_t E, int32_t D,
+                                   int32_t Vb, int32_t sorted_ready, impnn_stream_t stream) {
+  REQUIRE(B >= 0 && N > 0 && E >= 0 && D > 0 && Vb > 0, "bad shape");
+  if (B == 0 || E == 0) return IMPNN_OK;
+  REQUIRE(h && bond_ids && conn && type_mats && dagg && dh && dtype_mats && workspace, "null pointer");
+  if (workspace_bytes < impnn_bmm_message_typed_bwd_workspace_bytes(B, E, Vb))
+    return fail(IMPNN_E_WORKSPACE, "message_reduce_typed_bwd: workspace of %lld bytes is too small",
+                (long long)workspace_bytes);
+  return launch_bmm_message_typed_bwd(h, bond_ids, conn, type_mats, dagg, dh, dtype_mats,
+                                      static_cast<int32_t*>(workspace), B, N, E, D, Vb, sorted_ready != 0, 1,
                                       as_stream(stream));
 }
 

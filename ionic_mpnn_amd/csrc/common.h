@@ -67,7 +67,7 @@ int launch_bmm_message_typed_sorted(const float* h, const int32_t* bond_ids, con
                                     hipStream_t s);
 int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn, const float* A,
                                  const float* dm, float* dh, float* dA, int32_t* workspace, int B, int N, int E,
-                                 int D, int Vb, int sorted_ready, hipStream_t s);
+                                 int D, int Vb, int sorted_ready, int from_agg, hipStream_t s);
 int launch_strided_gemm(const float* A, const float* B, float* out, int64_t rows, int M, int N, int64_t a_rs,
                         int64_t a_cs, int64_t b_rs, int64_t b_cs, hipStream_t s);
 int launch_bond_type_matrices_bwd(const float* tb, const float* W, const float* dA, float* dW, float* dtb, int Vb,

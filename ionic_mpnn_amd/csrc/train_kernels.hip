@@ -182,7 +182,8 @@ template <int ACC>  // ACC = ceil(D*D / blockDim.x) accumulators per thread
 __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_kernel(
     const float* __restrict__ h, const int32_t* __restrict__ conn, const float* __restrict__ A,
     const float* __restrict__ dm, float* __restrict__ dh, float* __restrict__ dA, const int32_t* __restrict__ start,
-    const int32_t* __restrict__ segbase, const int32_t* __restrict__ order, int N, int E, int D, int Vb) {
+    const int32_t* __restrict__ segbase, const int32_t* __restrict__ order, int N, int E, int D, int Vb,
+    int from_agg) {  // from_agg: dm is the gradient of Reduce's output (B,N,D) and dm of edge e is its row tgt(e)
   extern __shared__ __align__(16) float smem[];
   __shared__ int64_t srcrow[kSeg];
   const int seg = blockIdx.x;
@@ -206,7 +207,8 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_kernel(
     const int e = t / D, c = t - e * D;
     const int64_t be = order[p0 + e];
     const int64_t row = (be / E) * N + conn[be * 2];
-    gm[e * D + c] = dm[be * D + c];
+    const int64_t grow = from_agg ? (be / E) * N + conn[be * 2 + 1] : be;
+    gm[e * D + c] = dm[grow * D + c];
     xm[e * D + c] = h[row * D + c];
     if (c == 0) srcrow[e] = row;
   }
@@ -1802,7 +1804,7 @@ int launch_bmm_message_typed_sorted(const float* h, const int32_t* bond_ids, con
 
 int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn, const float* A,
                                  const float* dm, float* dh, float* dA, int32_t* workspace, int B, int N, int E,
-                                 int D, int Vb, int sorted_ready, hipStream_t s) {
+                                 int D, int Vb, int sorted_ready, int from_agg, hipStream_t s) {
   if (Vb > kMaxTypes) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed_bwd: Vb=%d too large", Vb);
   if (D > 128) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed_bwd: D=%d > 128", D);
   const int64_t BE = (int64_t)B * E;
@@ -1824,7 +1826,7 @@ int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const 
       (void)hipFuncSetAttribute((const void*)bmm_message_typed_bwd_kernel<ACC>,                              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
     bmm_message_typed_bwd_kernel<ACC><<<(int)max_segs, threads, lds, s>>>(h, conn, A, dm, dh, dA, start, segbase, \
-                                                                           order, N, E, D, Vb);             \
+                                                                           order, N, E, D, Vb, from_agg);   \
   } while (0)
   if (acc <= 1) LAUNCH(1);
   else if (acc <= 4) LAUNCH(4);

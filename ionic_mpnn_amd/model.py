@@ -258,9 +258,15 @@ class MPNNModel:
         bond = self.bond_emb(bond_ids)
         if not typed:
             bond = bond.dense()
+        one_node = typed and trace is None and torch.is_grad_enabled()  # training: Reduce o Message as one node
         for i in range(self.num_steps):
-            m = br["bmm"][i]([h, bond, conn])
-            agg = br["reduce"][i]([m, conn[:, :, 1], h])
+            if one_node:
+                from . import autograd
+                m = None
+                agg = autograd.MessageReduceTyped.apply(h, bond.ids, conn, br["bmm"][i]._type_matrices(bond.table))
+            else:
+                m = br["bmm"][i]([h, bond, conn])
+                agg = br["reduce"][i]([m, conn[:, :, 1], h])
             h = br["update"][i]([h, agg])
             if trace is not None:
                 trace[f"{prefix}/m{i}"], trace[f"{prefix}/agg{i}"], trace[f"{prefix}/h{i + 1}"] = m, agg, h

@@ -53,6 +53,15 @@ def test_message_reduce_backward(D, K):
     close(hg.grad, ho.grad, what="dh")
     close(Wg.grad, Wo.grad, what="dW")
     close(tbg.grad, tbo.grad, what="dbond_table")
+    # the two layers as ONE node (impnn_message_reduce_typed_bwd gathers dagg at the edge targets)
+    from ionic_mpnn_amd import autograd
+    hf, tbf, Wf = (torch.tensor(a, dtype=torch.float32, device=DEV, requires_grad=True) for a in (h, tb, W))
+    af = autograd.MessageReduceTyped.apply(hf, bg, cg, ops.bond_type_matrices(tbf, Wf))
+    assert torch.equal(af, ag)
+    (af * torch.tensor(go, dtype=torch.float32, device=DEV)).sum().backward()
+    close(hf.grad, ho.grad, what="dh (one node)")
+    close(Wf.grad, Wo.grad, what="dW (one node)")
+    close(tbf.grad, tbo.grad, what="dbond_table (one node)")
 
 
 @pytest.mark.parametrize("D,rows", [(8, 37), (32, 301), (32, 70001), (64, 1500), (128, 19)])
