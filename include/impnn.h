@@ -268,6 +268,18 @@ int impnn_message_reduce_typed_bwd(const float* h, const int32_t* bond_ids, cons
 int impnn_bond_type_matrices_bwd(const float* bond_table, const float* W, const float* dtype_mats, float* dW,
                                  float* dbond_table, int32_t Vb, int32_t K, int32_t D, int32_t accumulate,
                                  impnn_stream_t stream);
+/*  The per-bond-type matrices of ALL message layers of a model (both ions, every step) in one launch, and their
+ *  backward in two: `W`, `type_mats`, `dtype_mats`, `dW` are host arrays of n device pointers (layer p: W_p (K,D,D),
+ *  A_p (Vb,D,D)); the bond embedding table is shared (train_viscosity.py:172), so dbond_table (Vb,K) is the sum over
+ *  the layers, accumulated in layer order.  accumulate as in impnn_bond_type_matrices_bwd.  Same arithmetic per layer
+ *  as the single-layer entries (bitwise equal A_p and dW_p).  A training step at the reference's batch 32 is bound by
+ *  the number of launches: 3 launches here replace 3 per layer. */
+int impnn_bond_type_matrices_multi(const float* bond_table, const float* const* W, float* const* type_mats,
+                                   int32_t n, int32_t Vb, int32_t K, int32_t D, impnn_stream_t stream);
+int impnn_bond_type_matrices_multi_bwd(const float* bond_table, const float* const* W,
+                                       const float* const* dtype_mats, float* const* dW, float* dbond_table,
+                                       int32_t n, int32_t Vb, int32_t K, int32_t D, int32_t accumulate,
+                                       impnn_stream_t stream);
 int64_t impnn_gated_update_param_floats(int32_t D);
 int64_t impnn_gated_update_bwd_workspace_floats(int64_t rows, int32_t D);
 int impnn_gated_update_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,

@@ -110,6 +110,48 @@ class BondTypeMatrices(torch.autograd.Function):
         return dtb, dW
 
 
+class BondTypeMatricesAll(torch.autograd.Function):
+    """The type matrices of all message layers (both ions, every step) as one node: one forward launch, two backward
+    launches (impnn_bond_type_matrices_multi[_bwd]) instead of three per layer."""
+
+    @staticmethod
+    def forward(ctx, bond_table, *Ws):
+        import ctypes as C
+        bond_table = f32c(bond_table)
+        Ws = tuple(f32c(W) for W in Ws)
+        Vb, K = bond_table.shape
+        D = Ws[0].shape[-1]
+        outs = tuple(torch.empty(Vb, D, D, dtype=torch.float32, device=bond_table.device) for _ in Ws)
+        wt = (C.c_void_p * len(Ws))(*[W.data_ptr() for W in Ws])
+        ot = (C.c_void_p * len(Ws))(*[o.data_ptr() for o in outs])
+        _lib_call(bond_table.device, _lib.load().impnn_bond_type_matrices_multi, ptr(bond_table), wt, ot, len(Ws), Vb, K, D)
+        ctx.save_for_backward(bond_table, *Ws)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *dmats):
+        import ctypes as C
+        bond_table, *Ws = ctx.saved_tensors
+        Vb, K = bond_table.shape
+        D = Ws[0].shape[-1]
+        dmats = [f32c(d) if d is not None else torch.zeros(Vb, D, D, dtype=torch.float32, device=bond_table.device)
+                 for d in dmats]
+        sinks = [_sink(W) for W in Ws]
+        st = _sink(bond_table)
+        use_sinks = st is not None and all(sk is not None for sk in sinks)
+        dWs = sinks if use_sinks else [torch.empty_like(W) for W in Ws]
+        dtb = st if use_sinks else torch.empty_like(bond_table)
+        n = len(Ws)
+        wt = (C.c_void_p * n)(*[W.data_ptr() for W in Ws])
+        dt = (C.c_void_p * n)(*[d.data_ptr() for d in dmats])
+        gt = (C.c_void_p * n)(*[g.data_ptr() for g in dWs])
+        _lib_call(bond_table.device, _lib.load().impnn_bond_type_matrices_multi_bwd, ptr(bond_table), wt, dt, gt, ptr(dtb),
+                  n, Vb, K, D, 1 if use_sinks else 0)
+        if use_sinks:
+            return (None,) * (n + 1)
+        return (dtb, *dWs)
+
+
 class BmmMessageTyped(torch.autograd.Function):
     """BondMatrixMessage.call in the per-bond-type schedule (models/layers.py:100-117)."""
 

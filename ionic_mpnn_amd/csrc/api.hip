@@ -437,6 +437,24 @@ int impnn_bond_type_matrices_bwd(const float* bond_table, const float* W, const 
                                        as_stream(stream));
 }
 
+int impnn_bond_type_matrices_multi(const float* bond_table, const float* const* W, float* const* type_mats, int32_t n,
+                                   int32_t Vb, int32_t K, int32_t D, impnn_stream_t stream) {
+  REQUIRE(n >= 0 && Vb > 0 && K > 0 && D > 0, "bad shape");
+  if (n == 0) return IMPNN_OK;
+  REQUIRE(bond_table && W && type_mats, "null pointer");
+  return launch_bond_type_matrices_multi(bond_table, W, type_mats, n, Vb, K, D, as_stream(stream));
+}
+
+int impnn_bond_type_matrices_multi_bwd(const float* bond_table, const float* const* W, const float* const* dtype_mats,
+                                       float* const* dW, float* dbond_table, int32_t n, int32_t Vb, int32_t K,
+                                       int32_t D, int32_t accumulate, impnn_stream_t stream) {
+  REQUIRE(n >= 0 && Vb > 0 && K > 0 && D > 0, "bad shape");
+  if (n == 0) return IMPNN_OK;
+  REQUIRE(bond_table && W && dtype_mats && dW && dbond_table, "null pointer");
+  return launch_bond_type_matrices_multi_bwd(bond_table, W, dtype_mats, dW, dbond_table, n, Vb, K, D, accumulate != 0,
+                                             as_stream(stream));
+}
+
 int64_t impnn_gated_update_param_floats(int32_t D) { return D > 0 ? gated_update_param_floats(D) : 0; }
 
 int64_t impnn_gated_update_bwd_workspace_floats(int64_t rows, int32_t D) {

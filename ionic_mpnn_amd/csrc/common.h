@@ -70,6 +70,11 @@ int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const 
                                  int D, int Vb, int sorted_ready, int from_agg, hipStream_t s);
 int launch_strided_gemm(const float* A, const float* B, float* out, int64_t rows, int M, int N, int64_t a_rs,
                         int64_t a_cs, int64_t b_rs, int64_t b_cs, hipStream_t s);
+int launch_bond_type_matrices_multi(const float* tb, const float* const* W, float* const* out, int n, int Vb, int K,
+                                    int D, hipStream_t s);
+int launch_bond_type_matrices_multi_bwd(const float* tb, const float* const* W, const float* const* dA,
+                                        float* const* dW, float* dtb, int n, int Vb, int K, int D, int accumulate,
+                                        hipStream_t s);
 int launch_bond_type_matrices_bwd(const float* tb, const float* W, const float* dA, float* dW, float* dtb, int Vb,
                                   int K, int D, int accumulate, hipStream_t s);
 int gated_update_bwd_blocks(int64_t rows, int D);

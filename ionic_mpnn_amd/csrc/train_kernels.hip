@@ -404,6 +404,88 @@ __global__ void bond_type_matrices_bwd_t_kernel(const float* __restrict__ W, con
 }
 
 // ---------------------------------------------------------------------------------------
+// The same for ALL message layers of a model in one launch each (training at the reference's batch 32 is bound by
+// the number of launches, and these depend on the weights only): problem p = (ion, step) has its own W_p, the bond
+// embedding table is shared, so dTb sums over the problems.
+// ---------------------------------------------------------------------------------------
+constexpr int kBtmMax = 16;
+struct BtmBatch {
+  const float* W[kBtmMax];
+  const float* dA[kBtmMax];
+  float* out[kBtmMax];  // forward: A_p (Vb x DD); backward: dW_p (K x DD)
+  int n;
+};
+// kernel-argument tables are indexed with constants only (a dynamic index is a dependent kernarg load per use)
+#define BTM_STAGE(bt)                                                       \
+  __shared__ const float* sW[kBtmMax];                                      \
+  __shared__ const float* sdA[kBtmMax];                                     \
+  __shared__ float* sout[kBtmMax];                                          \
+  _Pragma("unroll") for (int q = 0; q < kBtmMax; ++q) if ((int)threadIdx.x == q) {  \
+    sW[q] = bt.W[q];                                                        \
+    sdA[q] = bt.dA[q];                                                      \
+    sout[q] = bt.out[q];                                                    \
+  }                                                                         \
+  __syncthreads();
+
+__global__ void bond_type_matrices_multi_kernel(const float* __restrict__ tb, BtmBatch bt, int Vb, int K, int DD) {
+  BTM_STAGE(bt)
+  const int v = blockIdx.y;
+  const float* W = sW[blockIdx.z];
+  float* out = sout[blockIdx.z];
+  for (int ij = blockIdx.x * blockDim.x + threadIdx.x; ij < DD; ij += gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(tb[(int64_t)v * K + k], W[(int64_t)k * DD + ij], acc);  // as the single kernel
+    out[(int64_t)v * DD + ij] = acc;
+  }
+}
+__global__ void bond_type_matrices_multi_bwd_w_kernel(const float* __restrict__ tb, BtmBatch bt, int Vb, int K, int DD,
+                                                      int accumulate) {
+  BTM_STAGE(bt)
+  const int k = blockIdx.y;
+  const float* dA = sdA[blockIdx.z];
+  float* dW = sout[blockIdx.z];
+  for (int ij = blockIdx.x * blockDim.x + threadIdx.x; ij < DD; ij += gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    int v = 0;
+    for (; v + 16 <= Vb; v += 16) {
+      float x[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) x[u] = dA[(int64_t)(v + u) * DD + ij];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = fmaf(tb[(int64_t)(v + u) * K + k], x[u], acc);
+    }
+    for (; v < Vb; ++v) acc = fmaf(tb[(int64_t)v * K + k], dA[(int64_t)v * DD + ij], acc);
+    dW[(int64_t)k * DD + ij] = accumulate ? dW[(int64_t)k * DD + ij] + acc : acc;
+  }
+}
+__global__ void bond_type_matrices_multi_bwd_t_kernel(BtmBatch bt, float* __restrict__ dtb, int Vb, int K, int DD,
+                                                      int accumulate) {
+  BTM_STAGE(bt)
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= Vb * K) return;
+  const int v = wave / K, k = wave - v * K;
+  float acc = 0.f;
+  for (int p = 0; p < bt.n; ++p) {  // problems in order, then the lanes: a fixed summation order
+    const float* da = sdA[p] + (int64_t)v * DD;
+    const float* w = sW[p] + (int64_t)k * DD;
+    int ij = lane;
+    for (; ij + 7 * 64 < DD; ij += 8 * 64) {
+      float x[8], y[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        x[u] = da[ij + 64 * u];
+        y[u] = w[ij + 64 * u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = fmaf(x[u], y[u], acc);
+    }
+    for (; ij < DD; ij += 64) acc = fmaf(da[ij], w[ij], acc);
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if (lane == 0) dtb[(int64_t)v * K + k] = accumulate ? dtb[(int64_t)v * K + k] + acc : acc;
+}
+
+// ---------------------------------------------------------------------------------------
 // a7 backward (models/layers.py:142-156).  Forward per row, c = [h|agg]:
 //   z = sig(c Wz + bz); r = sig(c Wr + br); t = tanh([r*h|agg] Wh + bh); n = (1-z) h + z t;
 //   x = (n - mean) * inv; out = gamma x + beta + h
@@ -2034,6 +2116,48 @@ int launch_model_head_bwd(int kind, const float* pc, const float* pa, const floa
   const int groups = (B + kHdSPB - 1) / kHdSPB;  // bounded grid: every workgroup flushes ~|weights| atomics once
   model_head_bwd_kernel<<<groups < 512 ? groups : 512, 256, lds, s>>>(kind, pc, pa, T, ht, dout, dpc, dpa, B, D, F, Mx);
   return check_launch("model_head_bwd");
+}
+
+int launch_bond_type_matrices_multi(const float* tb, const float* const* W, float* const* out, int n, int Vb, int K,
+                                    int D, hipStream_t s) {
+  const int DD = D * D;
+  for (int p0 = 0; p0 < n; p0 += kBtmMax) {
+    BtmBatch bt{};
+    bt.n = n - p0 < kBtmMax ? n - p0 : kBtmMax;
+    for (int q = 0; q < bt.n; ++q) {
+      if (!W[p0 + q] || !out[p0 + q]) return fail(IMPNN_E_BADARG, "bond_type_matrices_multi: null tensor %d", p0 + q);
+      bt.W[q] = W[p0 + q];
+      bt.out[q] = out[p0 + q];
+    }
+    bond_type_matrices_multi_kernel<<<dim3((DD + kBlock - 1) / kBlock, Vb, bt.n), kBlock, 0, s>>>(tb, bt, Vb, K, DD);
+    if (int rc = check_launch("bond_type_matrices_multi")) return rc;
+  }
+  return IMPNN_OK;
+}
+
+int launch_bond_type_matrices_multi_bwd(const float* tb, const float* const* W, const float* const* dA,
+                                        float* const* dW, float* dtb, int n, int Vb, int K, int D, int accumulate,
+                                        hipStream_t s) {
+  const int DD = D * D;
+  for (int p0 = 0; p0 < n; p0 += kBtmMax) {
+    BtmBatch bt{};
+    bt.n = n - p0 < kBtmMax ? n - p0 : kBtmMax;
+    for (int q = 0; q < bt.n; ++q) {
+      if (!W[p0 + q] || !dA[p0 + q] || !dW[p0 + q])
+        return fail(IMPNN_E_BADARG, "bond_type_matrices_multi_bwd: null tensor %d", p0 + q);
+      bt.W[q] = W[p0 + q];
+      bt.dA[q] = dA[p0 + q];
+      bt.out[q] = dW[p0 + q];
+    }
+    bond_type_matrices_multi_bwd_w_kernel<<<dim3((DD + kBlock - 1) / kBlock, K, bt.n), kBlock, 0, s>>>(tb, bt, Vb, K, DD,
+                                                                                                     accumulate);
+    if (int rc = check_launch("bond_type_matrices_multi_bwd_w")) return rc;
+    const int64_t waves = (int64_t)Vb * K;
+    bond_type_matrices_multi_bwd_t_kernel<<<(int)((waves * 64 + kBlock - 1) / kBlock), kBlock, 0, s>>>(
+        bt, dtb, Vb, K, DD, (accumulate || p0 > 0) ? 1 : 0);
+    if (int rc = check_launch("bond_type_matrices_multi_bwd_t")) return rc;
+  }
+  return IMPNN_OK;
 }
 
 }  // namespace impnn

@@ -251,7 +251,18 @@ class MPNNModel:
     def fused_supported(self, N, E):
         return ops.encoder_fused_supported(N, E, self.atom_dim, self.bond_dim, self.num_steps, self.bond_vocab_size)
 
-    def encode_layered(self, prefix, atom_ids, bond_ids, conn, trace=None, typed=True):
+    def _all_type_matrices(self):
+        """Training: the type matrices of every message layer from one node (3 launches per step instead of 3 per
+        layer); None where the per-layer entries are the better fit (bond_dim >= 64 is GEMM-shaped)."""
+        if self.bond_dim >= 64 or self.num_steps == 0 or not torch.is_grad_enabled():
+            return None
+        from . import autograd
+        keys = [(p, i) for p in ("cat", "an") for i in range(self.num_steps)]
+        mats = autograd.BondTypeMatricesAll.apply(self.bond_emb.embeddings,
+                                                  *[self.branches[p]["bmm"][i].bond_transform for p, i in keys])
+        return dict(zip(keys, mats))
+
+    def encode_layered(self, prefix, atom_ids, bond_ids, conn, trace=None, typed=True, type_mats=None):
         """encode() layer at a time (train_viscosity.py:171-187) -> pooled (B,D)."""
         br = self.branches[prefix]
         h = self.atom_emb(atom_ids)
@@ -263,7 +274,8 @@ class MPNNModel:
             if one_node:
                 from . import autograd
                 m = None
-                agg = autograd.MessageReduceTyped.apply(h, bond.ids, conn, br["bmm"][i]._type_matrices(bond.table))
+                mats = type_mats[(prefix, i)] if type_mats else br["bmm"][i]._type_matrices(bond.table)
+                agg = autograd.MessageReduceTyped.apply(h, bond.ids, conn, mats)
             else:
                 m = br["bmm"][i]([h, bond, conn])
                 agg = br["reduce"][i]([m, conn[:, :, 1], h])
@@ -309,7 +321,9 @@ class MPNNModel:
             if trace is not None:
                 trace["cat/pooled"], trace["an/pooled"] = pc, pa
             return pc, pa
-        return (self.encode_layered("cat", ca, cb, cc, trace), self.encode_layered("an", aa, ab, ac, trace))
+        tm = self._all_type_matrices() if trace is None else None
+        return (self.encode_layered("cat", ca, cb, cc, trace, type_mats=tm),
+                self.encode_layered("an", aa, ab, ac, trace, type_mats=tm))
 
     def head(self, pooled_cat, pooled_an, temperature=None, trace=None, differentiable=False):
         if trace is None and not differentiable and max(self.atom_dim, self.fp_size, self.mixing_size) <= 64:

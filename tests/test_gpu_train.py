@@ -64,6 +64,38 @@ def test_message_reduce_backward(D, K):
     close(tbf.grad, tbo.grad, what="dbond_table (one node)")
 
 
+@pytest.mark.parametrize("D,K,n,sinks", [(32, 8, 6, True), (8, 4, 3, False), (16, 5, 18, True)])
+def test_type_matrices_of_all_layers_in_one_node(D, K, n, sinks):
+    """impnn_bond_type_matrices_multi[_bwd] against the per-layer entries: bitwise equal A_p, gradients equal to the
+    per-layer sums (more than 16 layers take a second launch)."""
+    from ionic_mpnn_amd import autograd
+    rng = np.random.default_rng(D + n)
+    Vb = 37
+    tb0 = rng.normal(size=(Vb, K)).astype(np.float32)
+    W0 = [(rng.normal(size=(K, D, D)) / np.sqrt(D)).astype(np.float32) for _ in range(n)]
+    go = [torch.tensor(rng.normal(size=(Vb, D, D)).astype(np.float32), device=DEV) for _ in range(n)]
+
+    def leaves():
+        tb = torch.tensor(tb0, device=DEV, requires_grad=True)
+        Ws = [torch.tensor(w, device=DEV, requires_grad=True) for w in W0]
+        if sinks:
+            for t in [tb] + Ws:
+                t.grad = torch.full_like(t, 0.25)  # the kernels must ADD to what is there
+        return tb, Ws
+
+    tb1, W1 = leaves()
+    ref = [ops.bond_type_matrices(tb1, w) for w in W1]
+    sum((r * g).sum() for r, g in zip(ref, go)).backward()
+    tb2, W2 = leaves()
+    got = autograd.BondTypeMatricesAll.apply(tb2, *W2)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    sum((r * g).sum() for r, g in zip(got, go)).backward()
+    close(tb2.grad, tb1.grad, 1e-5, "dbond_table")
+    for a, b in zip(W2, W1):
+        close(a.grad, b.grad, 1e-6, "dW")
+
+
 @pytest.mark.parametrize("D,rows", [(8, 37), (32, 301), (32, 70001), (64, 1500), (128, 19)])
 def test_gated_update_backward(D, rows):
     rng = np.random.default_rng(D + 1)
