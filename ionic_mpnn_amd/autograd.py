@@ -126,6 +126,10 @@ class BondTypeMatricesAll(torch.autograd.Function):
         ot = (C.c_void_p * len(Ws))(*[o.data_ptr() for o in outs])
         _lib_call(bond_table.device, _lib.load().impnn_bond_type_matrices_multi, ptr(bond_table), wt, ot, len(Ws), Vb, K, D)
         ctx.save_for_backward(bond_table, *Ws)
+        if any(W.requires_grad for W in Ws) or bond_table.requires_grad:
+            pool = torch.zeros(len(Ws), Vb, D, D, dtype=torch.float32, device=bond_table.device)  # one fill per step
+            for p, o in enumerate(outs):
+                o._impnn_dmats = pool[p]
         return outs
 
     @staticmethod
@@ -250,42 +254,87 @@ class GatedUpdate(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta = ctx.saved_tensors
-        D = h.shape[-1]
-        rows = h.numel() // D
-        lib = _lib.load()
-        dout = f32c(dout)
-        dh, dagg = torch.empty_like(h), torch.empty_like(agg)
-        P = int(lib.impnn_gated_update_param_floats(D))
-        wsn = int(lib.impnn_gated_update_bwd_workspace_floats(rows, D))
-        ws = torch.empty(max(wsn, 1), dtype=torch.float32, device=h.device)
-        # the eight parameter gradients leave the kernel as one block in the canonical order; when the existing
-        # .grad buffers form exactly that block (train.Adam's flat buffer does), the kernel adds into it directly
-        params = (Wz, bz, Wr, br, Wh, bh, gamma, beta)
-        sinks = [_sink(t) for t in params]
-        direct = all(g is not None for g in sinks)
-        if direct:
-            base, off = sinks[0].data_ptr(), 0
-            for t, g in zip(params, sinks):
-                direct = direct and g.data_ptr() == base + 4 * off and g.numel() == t.numel()
-                off += t.numel()
-        if direct:
-            _lib_call(h.device, lib.impnn_gated_update_bwd, ptr(h), ptr(agg), ptr(Wz), ptr(bz), ptr(Wr), ptr(br),
-                      ptr(Wh), ptr(bh), ptr(gamma), ctx.eps, ptr(dout), ptr(dh), ptr(dagg), ptr(sinks[0]), ptr(ws), wsn,
-                      rows, D, 1)
-            return (dh, dagg, *([None] * 8), None)
-        dparams = torch.empty(P, dtype=torch.float32, device=h.device)
-        _lib_call(h.device, lib.impnn_gated_update_bwd, ptr(h), ptr(agg), ptr(Wz), ptr(bz), ptr(Wr), ptr(br), ptr(Wh),
-                  ptr(bh), ptr(gamma), ctx.eps, ptr(dout), ptr(dh), ptr(dagg), ptr(dparams), ptr(ws), wsn, rows, D, 0)
-        n_w, o = 2 * D * D, 0
-        grads = []
-        for _ in range(3):
-            grads.append(dparams[o:o + n_w].view(2 * D, D))
-            grads.append(dparams[o + n_w:o + n_w + D])
-            o += n_w + D
-        grads.append(dparams[o:o + D])
-        grads.append(dparams[o + D:o + 2 * D])
-        return (dh, dagg, *grads, None)
+        return _gated_update_backward(ctx.saved_tensors, ctx.eps, dout)
+
+
+def _gated_update_backward(saved, eps, dout):
+    """(dh, dagg, 8 parameter gradients or None where the kernel added into the sink, None for eps)"""
+    h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta = saved
+    D = h.shape[-1]
+    rows = h.numel() // D
+    lib = _lib.load()
+    dout = f32c(dout)
+    dh, dagg = torch.empty_like(h), torch.empty_like(agg)
+    P = int(lib.impnn_gated_update_param_floats(D))
+    wsn = int(lib.impnn_gated_update_bwd_workspace_floats(rows, D))
+    ws = torch.empty(max(wsn, 1), dtype=torch.float32, device=h.device)
+    # the eight parameter gradients leave the kernel as one block in the canonical order; when the existing
+    # .grad buffers form exactly that block (train.Adam's flat buffer does), the kernel adds into it directly
+    params = (Wz, bz, Wr, br, Wh, bh, gamma, beta)
+    sinks = [_sink(t) for t in params]
+    direct = all(g is not None for g in sinks)
+    if direct:
+        base, off = sinks[0].data_ptr(), 0
+        for t, g in zip(params, sinks):
+            direct = direct and g.data_ptr() == base + 4 * off and g.numel() == t.numel()
+            off += t.numel()
+    if direct:
+        _lib_call(h.device, lib.impnn_gated_update_bwd, ptr(h), ptr(agg), ptr(Wz), ptr(bz), ptr(Wr), ptr(br),
+                  ptr(Wh), ptr(bh), ptr(gamma), eps, ptr(dout), ptr(dh), ptr(dagg), ptr(sinks[0]), ptr(ws), wsn,
+                  rows, D, 1)
+        return (dh, dagg, *([None] * 8), None)
+    dparams = torch.empty(P, dtype=torch.float32, device=h.device)
+    _lib_call(h.device, lib.impnn_gated_update_bwd, ptr(h), ptr(agg), ptr(Wz), ptr(bz), ptr(Wr), ptr(br), ptr(Wh),
+              ptr(bh), ptr(gamma), eps, ptr(dout), ptr(dh), ptr(dagg), ptr(dparams), ptr(ws), wsn, rows, D, 0)
+    n_w, o = 2 * D * D, 0
+    grads = []
+    for _ in range(3):
+        grads.append(dparams[o:o + n_w].view(2 * D, D))
+        grads.append(dparams[o + n_w:o + n_w + D])
+        o += n_w + D
+    grads.append(dparams[o:o + D])
+    grads.append(dparams[o + D:o + 2 * D])
+    return (dh, dagg, *grads, None)
+
+
+class MessagePassingStep(torch.autograd.Function):
+    """One message-passing step as one node (train_viscosity.py:179-186: BondMatrixMessage -> Reduce -> GatedUpdate).
+    Backward: impnn_gated_update_bwd writes dh and dagg, then impnn_message_reduce_typed_bwd ADDS the message path's
+    share into the same dh - no separate sum of the two consumers of h, no zero fill of dh; the type-matrix gradient
+    goes into a buffer BondTypeMatricesAll zeroed for all layers at once (``type_mats._impnn_dmats``) when there is one."""
+
+    @staticmethod
+    def forward(ctx, h, bond_ids, conn, type_mats, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps):
+        h, type_mats, bond_ids, conn = f32c(h), f32c(type_mats), i32c(bond_ids), i32c(conn)
+        gu = [f32c(t) for t in (Wz, bz, Wr, br, Wh, bh, gamma)]
+        m = ops.bmm_message_typed(h, bond_ids, conn, type_mats)
+        agg = ops.reduce_scatter_add(m, conn[:, :, 1], h.shape[1])
+        del m
+        out = ops.gated_update(h, agg, *gu, beta, eps)
+        ctx.save_for_backward(h, agg, *gu, beta, bond_ids, conn, type_mats)
+        ctx.eps = float(eps)
+        ctx.graph_key = (conn, bond_ids, _pass["id"])
+        ctx.dmats_buf = getattr(type_mats, "_impnn_dmats", None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved = ctx.saved_tensors
+        h, bond_ids, conn, mats = saved[0], saved[10], saved[11], saved[12]
+        dh, dagg, *dparams = _gated_update_backward(saved[:10], ctx.eps, dout)
+        B, N, D = h.shape
+        E, Vb = conn.shape[1], mats.shape[0]
+        dmats = ctx.dmats_buf if ctx.dmats_buf is not None else torch.zeros_like(mats)
+        holder, bond_obj, pass_id = ctx.graph_key
+        prev = _pass["id"]
+        _pass["id"] = pass_id
+        try:
+            ws, ready = ops.edge_sort_workspace(holder, bond_obj, B, E, Vb)
+        finally:
+            _pass["id"] = prev
+        _lib_call(h.device, _lib.load().impnn_message_reduce_typed_bwd, ptr(h), ptr(bond_ids), ptr(conn), ptr(mats),
+                  ptr(dagg), ptr(dh), ptr(dmats), ptr(ws), ws.numel(), B, N, E, D, Vb, 1 if ready else 0)
+        return (dh, None, None, dmats, *dparams)
 
 
 class GlobalSumPool(torch.autograd.Function):

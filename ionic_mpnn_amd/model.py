@@ -269,16 +269,18 @@ class MPNNModel:
         bond = self.bond_emb(bond_ids)
         if not typed:
             bond = bond.dense()
-        one_node = typed and trace is None and torch.is_grad_enabled()  # training: Reduce o Message as one node
+        one_node = typed and trace is None and torch.is_grad_enabled()  # training: a whole step as one autograd node
         for i in range(self.num_steps):
             if one_node:
                 from . import autograd
-                m = None
                 mats = type_mats[(prefix, i)] if type_mats else br["bmm"][i]._type_matrices(bond.table)
-                agg = autograd.MessageReduceTyped.apply(h, bond.ids, conn, mats)
-            else:
-                m = br["bmm"][i]([h, bond, conn])
-                agg = br["reduce"][i]([m, conn[:, :, 1], h])
+                u, w = br["update"][i], br["update"][i]._weights
+                h = autograd.MessagePassingStep.apply(
+                    h, bond.ids, conn, mats, w["dense_z/kernel"], w["dense_z/bias"], w["dense_r/kernel"],
+                    w["dense_r/bias"], w["dense_h/kernel"], w["dense_h/bias"], u.gamma, u.beta, u.epsilon)
+                continue
+            m = br["bmm"][i]([h, bond, conn])
+            agg = br["reduce"][i]([m, conn[:, :, 1], h])
             h = br["update"][i]([h, agg])
             if trace is not None:
                 trace[f"{prefix}/m{i}"], trace[f"{prefix}/agg{i}"], trace[f"{prefix}/h{i + 1}"] = m, agg, h
