@@ -1097,9 +1097,88 @@ int launch_bmm_message_typed(const float* h, const int32_t* bond_ids, const int3
   return check_launch("bmm_message_typed");
 }
 
+// a5 for small batches (training at the reference's batch 32): one molecule per workgroup and P thread groups per
+// column, group r owning the targets t with t % P == r.  The valid edges are first dealt into P lists in edge-slot
+// order (wave ballots give every edge its rank), then thread (r, column) walks list r with 16 message rows in flight.
+// Every (target, column) sum is formed by one thread in edge-slot order: bitwise equal to reduce_scatter_kernel.
+constexpr int kRsP = 8;
+__global__ __launch_bounds__(256) void reduce_scatter_small_kernel(const float* __restrict__ m,
+                                                                   const int32_t* __restrict__ tgt, int tgt_stride,
+                                                                   float* __restrict__ agg, int N, int E, int D,
+                                                                   int P) {
+  extern __shared__ __align__(16) float smem[];
+  float* acc = smem;                                            // N*D
+  uint16_t* list = reinterpret_cast<uint16_t*>(acc + (size_t)N * D);  // P lists of <= E edge slots
+  uint16_t* tg = list + (size_t)P * E;                          // target row of every edge slot (0: skipped)
+  __shared__ int cnt[kRsP][4], len[kRsP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const float* mb = m + (int64_t)b * E * D;
+  const int32_t* tb = tgt + (int64_t)b * E * tgt_stride;
+  for (int i = tid; i < N * D; i += 256) acc[i] = 0.f;
+  if (tid < kRsP) len[tid] = 0;
+  __syncthreads();
+  for (int e0 = 0; e0 < E; e0 += 256) {
+    const int e = e0 + tid;
+    const int t = e < E ? tb[(int64_t)e * tgt_stride] : 0;
+    const bool ok = t > 0 && t < N;
+    if (e < E) tg[e] = (uint16_t)(ok ? t : 0);
+    const int re = ok ? t % P : -1;
+    int rank = 0;
+    for (int r = 0; r < P; ++r) {
+      const unsigned long long mask = __ballot(re == r);
+      if (re == r) rank = __popcll(mask & ((1ull << lane) - 1ull));
+      if (lane == 0) cnt[r][wave] = __popcll(mask);
+    }
+    __syncthreads();
+    if (ok) {
+      int base = len[re];
+      for (int w = 0; w < wave; ++w) base += cnt[re][w];
+      list[(size_t)re * E + base + rank] = (uint16_t)e;
+    }
+    __syncthreads();
+    if (tid < P) len[tid] += cnt[tid][0] + cnt[tid][1] + cnt[tid][2] + cnt[tid][3];
+    __syncthreads();
+  }
+  const int r = tid / D, c = tid - r * D;
+  if (r < P) {
+    const int n = len[r];
+    const uint16_t* L = list + (size_t)r * E;
+    for (int k = 0; k < n; k += 16) {
+      float v[16];
+      int tt[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        tt[u] = -1;
+        v[u] = 0.f;
+        if (k + u < n) {
+          const int e = L[k + u];
+          v[u] = mb[(int64_t)e * D + c];
+          tt[u] = tg[e];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (tt[u] >= 0) acc[(size_t)tt[u] * D + c] += v[u];
+    }
+  }
+  __syncthreads();
+  float* ab = agg + (int64_t)b * N * D;
+  for (int i = tid; i < N * D; i += 256) ab[i] = acc[i];
+}
+
 int launch_reduce_scatter_add(const float* m, const int32_t* tgt, int tgt_stride, float* agg, int B,
                               int N, int E, int D, hipStream_t s) {
   if (B == 0) return IMPNN_OK;
+  if (B < 2048 && D <= 128 && E > 0 && E < 65536 && N < 65536) {  // too few (molecule, column) threads to hide latency
+    int P = 256 / D;
+    P = P > kRsP ? kRsP : P;
+    const size_t l = sizeof(float) * (size_t)N * D + sizeof(uint16_t) * ((size_t)P * E + E);
+    if (P >= 2 && l <= 64 * 1024) {
+      reduce_scatter_small_kernel<<<B, 256, l, s>>>(m, tgt, tgt_stride, agg, N, E, D, P);
+      return check_launch("reduce_scatter_small");
+    }
+  }
   const int cols = D < kBlock ? D : kBlock;
   const int mpb = kBlock / cols;
   size_t lds = (size_t)mpb * N * D * sizeof(float);

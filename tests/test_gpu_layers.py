@@ -220,3 +220,26 @@ def test_random_shapes_all_layers(D, K, N, E, B):
     out = ops.gated_update(dev(h), agg, g["Wz"], g["bz"], g["Wr"], g["br"], g["Wh"], g["bh"], g["gamma"], g["beta"])
     assert_close(out.cpu().numpy(), ref, what="gated_update")
     assert_close(ops.global_sum_pool(out, dev(ids)).cpu().numpy(), O.global_sum_pool(ref, ids), what="pool")
+
+
+@pytest.mark.parametrize("D,N,E", [(32, 64, 256), (64, 20, 300), (8, 33, 77), (128, 9, 513)])
+def test_reduce_small_batch_kernel_is_bitwise_the_large_batch_kernel(D, N, E):
+    """Batches under 2048 molecules take reduce_scatter_small_kernel (target-partitioned thread groups, messages in
+    flight 16 at a time); both kernels form every (target, column) sum in edge-slot order, so the first molecules of
+    a 2100-molecule call equal a small call on the same molecules bit for bit - and the sequential numpy scatter."""
+    rng = np.random.default_rng(D + E)
+    B, Bs = 2100, 37
+    m = torch.from_numpy(rng.normal(size=(B, E, D)).astype(np.float32)).to(DEV)
+    tgt = rng.integers(-1, N + 2, size=(B, E)).astype(np.int32)   # includes 0 (padding), negative and >= N (skipped)
+    tgt[:, rng.integers(0, E, size=E // 3)] = 3                    # a crowded target row
+    big = ops.reduce_scatter_add(m, dev(tgt), N)
+    small = ops.reduce_scatter_add(m[:Bs].contiguous(), dev(tgt[:Bs]), N)
+    assert torch.equal(big[:Bs], small)
+    ref = np.zeros((Bs, N, D), np.float32)
+    mh = m[:Bs].cpu().numpy()
+    for b in range(Bs):
+        for e in range(E):
+            t = tgt[b, e]
+            if 0 < t < N:
+                ref[b, t] += mh[b, e]
+    np.testing.assert_array_equal(small.cpu().numpy(), ref)
