@@ -176,6 +176,30 @@ int impnn_model_head_bwd(int32_t kind, const float* pooled_cat, const float* poo
                          float* dpooled_cat, float* dpooled_an, float* const* dweights, int32_t B,
                          int32_t D, int32_t F, int32_t Mx, impnn_stream_t stream);
 
+/* ---- the head with the training loss folded in (train_viscosity.py:189,227-230):
+ *        loss = mean_b (pred_b - y_b)^2 + sum_t l2[t] * sum(W_t^2)
+ *      keras "mse" plus the kernel_regularizer=l2(...) penalties; `l2` is a HOST array with one lambda per weight tensor
+ *      in the order of `weights` (0 for tensors without a penalty).  impnn_model_head_loss writes the scalar `loss`
+ *      (device) and, when `pred` is not null, the predictions (B); the squared errors are summed per workgroup in
+ *      sample order and by the last workgroup to arrive in workgroup order, so the value is reproducible.  `workspace`:
+ *      impnn_model_head_loss_workspace_floats(B) floats, the first 4 bytes ZERO before the first call (every call
+ *      leaves them zero); one workspace per stream in flight.
+ *      impnn_model_head_loss_bwd: `dloss` is a device scalar (the gradient of the loss value, 1 for a plain
+ *      loss.backward(), n_local/n_global on a data-parallel rank); the kernel forms 2 (pred_b - y_b) / B * dloss
+ *      itself and adds 2 l2[t] W_t dloss to the parameter gradients once.  Replaces ~25 elementwise / reduction
+ *      launches of the autograd tape per training step. */
+int64_t impnn_model_head_loss_workspace_floats(int32_t B);
+int impnn_model_head_loss(int32_t kind, const float* pooled_cat, const float* pooled_an,
+                          const float* temperature, const float* const* weights, const float* l2,
+                          const float* y, float* pred, float* loss, float* workspace,
+                          int64_t workspace_floats, int32_t B, int32_t D, int32_t F, int32_t Mx,
+                          impnn_stream_t stream);
+int impnn_model_head_loss_bwd(int32_t kind, const float* pooled_cat, const float* pooled_an,
+                              const float* temperature, const float* const* weights, const float* l2,
+                              const float* y, const float* dloss, float* dpooled_cat, float* dpooled_an,
+                              float* const* dweights, int32_t B, int32_t D, int32_t F, int32_t Mx,
+                              impnn_stream_t stream);
+
 /* ---- a9 in two halves, for callers that pipeline batches.  impnn_encoder_plan runs only the
  *      graph-dependent plan kernels (row counts, shares, chunk records) of a batch into `workspace`;
  *      impnn_encoder_run runs only the encoder kernel from a planned workspace.  The plan needs no

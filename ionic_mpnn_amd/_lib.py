@@ -45,6 +45,10 @@ SIGNATURES = {
     "impnn_model_head": (C.c_int, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "impnn_model_head_tensors": (C.c_int, [i32, vp, vp, vp, PP, vp, i32, i32, i32, i32, vp]),
     "impnn_model_head_bwd": (C.c_int, [i32, vp, vp, vp, PP, vp, vp, vp, PP, i32, i32, i32, i32, vp]),
+    "impnn_model_head_loss_workspace_floats": (i64, [i32]),
+    "impnn_model_head_loss": (C.c_int, [i32, vp, vp, vp, PP, C.POINTER(f32), vp, vp, vp, vp, i64, i32, i32, i32, i32, vp]),
+    "impnn_model_head_loss_bwd": (C.c_int, [i32, vp, vp, vp, PP, C.POINTER(f32), vp, vp, vp, vp, PP, i32, i32, i32, i32,
+                                            vp]),
     "impnn_embed_gather_bwd": (C.c_int, [vp, vp, vp, i64, i32, i32, vp]),
     "impnn_reduce_scatter_bwd": (C.c_int, [vp, vp, i32, vp, i32, i32, i32, i32, vp]),
     "impnn_global_sum_pool_bwd": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),

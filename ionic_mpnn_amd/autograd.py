@@ -397,3 +397,52 @@ class ModelHead(torch.autograd.Function):
         _lib_call(dout.device, _lib.load().impnn_model_head_bwd, kind, ptr(pooled_cat), ptr(pooled_an),
                   ptr(T) if T is not None else None, wt, ptr(dout), ptr(dpc), ptr(dpa), gt, B, D, F, Mx)
         return (None, None, None, dpc, dpa, None) + tuple(None if s is not None else g for s, g in zip(sinks, grads))
+
+
+class ModelHeadLoss(torch.autograd.Function):
+    """Head + keras "mse" + l2 penalties as one node -> the scalar loss (impnn_model_head_loss[_bwd]).  ``l2``: one
+    lambda per weight tensor; ``workspace``: a persistent float tensor whose first word is zero (the kernel's arrival
+    counter; see include/impnn.h)."""
+
+    @staticmethod
+    def forward(ctx, kind, fp_size, mixing_size, l2, workspace, pooled_cat, pooled_an, temperature, y, *weights):
+        import ctypes as C
+        pooled_cat, pooled_an, y = f32c(pooled_cat), f32c(pooled_an), f32c(y).reshape(-1)
+        weights = tuple(f32c(w) for w in weights)
+        B, D = pooled_cat.shape
+        T = f32c(temperature).reshape(-1) if kind == 0 else None
+        if y.numel() != B or (T is not None and T.numel() != B):
+            raise ValueError("y / temperature must hold one value per sample")
+        lib = _lib.load()
+        if workspace.numel() < lib.impnn_model_head_loss_workspace_floats(B):
+            raise ValueError("loss workspace too small")
+        loss = torch.empty((), dtype=torch.float32, device=pooled_cat.device)
+        lam = (C.c_float * len(weights))(*[float(v) for v in l2])
+        table = (C.c_void_p * len(weights))(*[w.data_ptr() for w in weights])
+        _lib_call(pooled_cat.device, lib.impnn_model_head_loss, kind, ptr(pooled_cat), ptr(pooled_an),
+                  ptr(T) if T is not None else None, table, lam, ptr(y), None, ptr(loss), ptr(workspace),
+                  workspace.numel(), B, D, fp_size, mixing_size)
+        ctx.save_for_backward(pooled_cat, pooled_an, y, *(() if T is None else (T,)), *weights)
+        ctx.meta = (kind, fp_size, mixing_size, tuple(float(v) for v in l2), weights)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        import ctypes as C
+        kind, F, Mx, l2, params = ctx.meta
+        saved = ctx.saved_tensors
+        pooled_cat, pooled_an, y = saved[0], saved[1], saved[2]
+        T = saved[3] if kind == 0 else None
+        weights = saved[4 if kind == 0 else 3:]
+        B, D = pooled_cat.shape
+        dloss = f32c(dloss).reshape(1)
+        sinks = [_sink(p) for p in params]
+        grads = [s if s is not None else torch.zeros_like(w) for s, w in zip(sinks, weights)]
+        dpc, dpa = torch.empty_like(pooled_cat), torch.empty_like(pooled_an)
+        lam = (C.c_float * len(weights))(*l2)
+        wt = (C.c_void_p * len(weights))(*[w.data_ptr() for w in weights])
+        gt = (C.c_void_p * len(grads))(*[g.data_ptr() for g in grads])
+        _lib_call(dloss.device, _lib.load().impnn_model_head_loss_bwd, kind, ptr(pooled_cat), ptr(pooled_an),
+                  ptr(T) if T is not None else None, wt, lam, ptr(y), ptr(dloss), ptr(dpc), ptr(dpa), gt, B, D, F, Mx)
+        return (None, None, None, None, None, dpc, dpa, None, None) + tuple(
+            None if s is not None else g for s, g in zip(sinks, grads))

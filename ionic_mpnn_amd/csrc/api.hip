@@ -299,6 +299,35 @@ int impnn_model_head_bwd(int32_t kind, const float* pooled_cat, const float* poo
                                dweights, B, D, F, Mx, as_stream(stream));
 }
 
+int64_t impnn_model_head_loss_workspace_floats(int32_t B) { return B > 0 ? model_head_loss_workspace_floats(B) : 4; }
+
+int impnn_model_head_loss(int32_t kind, const float* pooled_cat, const float* pooled_an, const float* temperature,
+                          const float* const* weights, const float* l2, const float* y, float* pred, float* loss,
+                          float* workspace, int64_t workspace_floats, int32_t B, int32_t D, int32_t F, int32_t Mx,
+                          impnn_stream_t stream) {
+  REQUIRE(kind == 0 || kind == 1, "kind must be 0 (viscosity) or 1 (melting point)");
+  REQUIRE(B > 0 && D > 0 && F > 0 && Mx > 0, "bad shape");
+  REQUIRE(pooled_cat && pooled_an && weights && l2 && y && loss && workspace && (kind == 1 || temperature),
+          "null pointer");
+  if (workspace_floats < impnn_model_head_loss_workspace_floats(B))
+    return fail(IMPNN_E_WORKSPACE, "model_head_loss: workspace of %lld floats is too small", (long long)workspace_floats);
+  return launch_model_head_tensors(kind, pooled_cat, pooled_an, temperature, weights, pred, B, D, F, Mx,
+                                   as_stream(stream), l2, y, loss, workspace);
+}
+
+int impnn_model_head_loss_bwd(int32_t kind, const float* pooled_cat, const float* pooled_an, const float* temperature,
+                              const float* const* weights, const float* l2, const float* y, const float* dloss,
+                              float* dpooled_cat, float* dpooled_an, float* const* dweights, int32_t B, int32_t D,
+                              int32_t F, int32_t Mx, impnn_stream_t stream) {
+  REQUIRE(kind == 0 || kind == 1, "kind must be 0 (viscosity) or 1 (melting point)");
+  REQUIRE(B > 0 && D > 0 && F > 0 && Mx > 0, "bad shape");
+  REQUIRE(pooled_cat && pooled_an && weights && l2 && y && dloss && dpooled_cat && dpooled_an && dweights &&
+              (kind == 1 || temperature),
+          "null pointer");
+  return launch_model_head_bwd(kind, pooled_cat, pooled_an, temperature, weights, nullptr, dpooled_cat, dpooled_an,
+                               dweights, B, D, F, Mx, as_stream(stream), l2, y, dloss);
+}
+
 int impnn_profile_enable(int32_t capacity) {
   REQUIRE(capacity > 0 && capacity <= (1 << 20), "capacity out of range");
   impnn_profile_disable();

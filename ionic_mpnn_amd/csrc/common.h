@@ -45,11 +45,14 @@ int launch_gated_update(const float* h, const float* agg, const float* Wz, const
                         int D, hipStream_t s);
 int launch_global_sum_pool(const float* h, const int32_t* ids, float* out, int B, int N, int D,
                            hipStream_t s);
+int64_t model_head_loss_workspace_floats(int B);
 int launch_model_head_tensors(int kind, const float* pc, const float* pa, const float* T, const float* const* weights,
-                              float* out, int B, int D, int F, int Mx, hipStream_t s);
+                              float* out, int B, int D, int F, int Mx, hipStream_t s, const float* l2 = nullptr,
+                              const float* y = nullptr, float* loss_out = nullptr, float* workspace = nullptr);
 int launch_model_head_bwd(int kind, const float* pc, const float* pa, const float* T, const float* const* weights,
                           const float* dout, float* dpc, float* dpa, float* const* grads, int B, int D, int F, int Mx,
-                          hipStream_t s);
+                          hipStream_t s, const float* l2 = nullptr, const float* y = nullptr,
+                          const float* dloss = nullptr);
 int launch_model_head(int kind, const float* pc, const float* pa, const float* T, const float* w, float* out, int B,
                       int D, int F, int Mx, hipStream_t s);
 int launch_validate_indices(const int32_t* conn, const int32_t* atom_ids, const int32_t* bond_ids,

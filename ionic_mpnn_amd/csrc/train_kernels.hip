@@ -1500,7 +1500,36 @@ struct HeadTensors {
   float* g[kHdTensors];
   int off[kHdTensors + 1];
   int n;
+  float l2[kHdTensors];  // keras l2(lambda) per tensor (0: none); used by the loss entries only
 };
+// loss = mean_b (pred_b - y_b)^2 + sum_t l2_t * sum(W_t^2)   (keras "mse" + kernel_regularizer, train_viscosity.py:189,229)
+struct HeadLoss {
+  const float* y;        // (B); null: the kernels behave as the plain head entries
+  const float* dloss;    // backward: device scalar, the gradient of the loss value
+  float* loss_out;       // forward: device scalar
+  float* partial;        // forward: one squared-error sum per workgroup
+  unsigned int* counter; // forward: arrival ticket, zero before the first call, left at zero by every call
+  float inv_B;
+};
+__device__ __forceinline__ float head_l2(const HeadTensors& ht, int sgm) {
+  float v = ht.l2[0];
+#pragma unroll
+  for (int q = 1; q < kHdTensors; ++q) v = sgm == q ? ht.l2[q] : v;
+  return v;
+}
+// deterministic workgroup sum of one value per thread (256 threads); result valid in every thread
+__device__ __forceinline__ float head_block_sum(float v, float* red) {
+  __syncthreads();
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float r = red[0];
+  __syncthreads();
+  return r;
+}
 __device__ __forceinline__ float softplus_stable(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
 
 __device__ __forceinline__ int head_total(const HeadTensors& ht) {
@@ -1583,8 +1612,12 @@ __device__ __forceinline__ void head_forward_mix(const float* ws, const float* x
 __global__ __launch_bounds__(256) void model_head_tensors_kernel(int kind, const float* __restrict__ pc,
                                                                  const float* __restrict__ pa,
                                                                  const float* __restrict__ T, HeadTensors ht,
-                                                                 float* __restrict__ out, int B, int D, int F, int Mx) {
+                                                                 float* __restrict__ out, int B, int D, int F, int Mx,
+                                                                 HeadLoss hl) {
   extern __shared__ __align__(16) float hsm[];
+  __shared__ float red[256];
+  __shared__ float sq[kHdSPB];
+  __shared__ int is_last;
   const int total = head_total(ht);
   float* ws = hsm;
   float* xs = ws + ((total + 3) & ~3);
@@ -1609,11 +1642,16 @@ __global__ __launch_bounds__(256) void model_head_tensors_kernel(int kind, const
       hid[sl * kHdMax + jj] = acc;
     }
     __syncthreads();
-    if (jj == 0 && live) {
-      const float* vp = hid + sl * kHdMax;
-      const float Bc = fminf(fmaxf(softplus_stable(vp[1]), 0.f), 20.f);
-      const float Cc = fminf(fmaxf(softplus_stable(vp[2]), 0.1f), 50.f);
-      out[b] = vp[0] + Bc / (T[b] / 100.0f + Cc + 1e-6f);
+    if (jj == 0) {
+      float pred = 0.f;
+      if (live) {
+        const float* vp = hid + sl * kHdMax;
+        const float Bc = fminf(fmaxf(softplus_stable(vp[1]), 0.f), 20.f);
+        const float Cc = fminf(fmaxf(softplus_stable(vp[2]), 0.1f), 50.f);
+        pred = vp[0] + Bc / (T[b] / 100.0f + Cc + 1e-6f);
+        if (out) out[b] = pred;
+      }
+      if (hl.y) sq[sl] = live ? (pred - hl.y[b]) * (pred - hl.y[b]) : 0.f;
     }
   } else {
     const float* Wh = wt;
@@ -1625,11 +1663,41 @@ __global__ __launch_bounds__(256) void model_head_tensors_kernel(int kind, const
       hid[sl * kHdMax + j] = fmaxf(acc, 0.f);
     }
     __syncthreads();
-    if (jj == 0 && live) {
+    if (jj == 0) {
       float acc = Wo[F];
       for (int j = 0; j < F; ++j) acc = fmaf(hid[sl * kHdMax + j], Wo[j], acc);
-      out[b] = acc;
+      if (live && out) out[b] = acc;
+      if (hl.y) sq[sl] = live ? (acc - hl.y[b]) * (acc - hl.y[b]) : 0.f;
     }
+  }
+  if (!hl.y) return;
+  // ---- loss: workgroup sums in sample order, then the LAST workgroup to arrive adds them in workgroup order
+  __syncthreads();
+  if (tid == 0) {
+    float sum = 0.f;
+    for (int q = 0; q < kHdSPB; ++q) sum += sq[q];
+    __hip_atomic_store(&hl.partial[blockIdx.x], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    const unsigned int ticket = atomicAdd(hl.counter, 1u);
+    is_last = ticket == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  float v = 0.f;
+  for (int i = tid; i < (int)gridDim.x; i += 256)
+    v += __hip_atomic_load(&hl.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const float se = head_block_sum(v, red);
+  float reg = 0.f;
+  for (int t = tid; t < total; t += 256) {
+    int base;
+    const float lam = head_l2(ht, head_segment(ht, t, &base));
+    reg = fmaf(lam * ws[t], ws[t], reg);
+  }
+  reg = head_block_sum(reg, red);
+  if (tid == 0) {
+    hl.loss_out[0] = se * hl.inv_B + reg;
+    *hl.counter = 0u;
   }
 }
 
@@ -1640,7 +1708,7 @@ __global__ __launch_bounds__(256) void model_head_bwd_kernel(int kind, const flo
                                                              const float* __restrict__ pa, const float* __restrict__ T,
                                                              HeadTensors ht, const float* __restrict__ dout,
                                                              float* __restrict__ dpc, float* __restrict__ dpa, int B,
-                                                             int D, int F, int Mx) {
+                                                             int D, int F, int Mx, HeadLoss hl) {
   extern __shared__ __align__(16) float hsm[];
   const int total = head_total(ht);
   const int tpad = (total + 3) & ~3;
@@ -1691,9 +1759,10 @@ __global__ __launch_bounds__(256) void model_head_bwd_kernel(int kind, const flo
       __syncthreads();
     }
     const float* mx = V(kVMix);
-    const float d = live ? dout[b] : 0.f;
+    // gradient of the prediction: given (plain head), or 2 (pred - y) / B * dloss once pred is known (loss entries)
+    const float gscale = hl.y ? 2.0f * hl.inv_B * hl.dloss[0] : 0.f;
+    float d = (live && !hl.y) ? dout[b] : 0.f;
     float* top = V(kVTop);
-    if (jj == 0) V(kVOne)[0] = d;
     // ---- top of the head: kVTop = gradient of [A,b,c] (kind 0) / of the hidden pre-activation (kind 1)
     if (kind == 0) {
       if (jj < 3) {
@@ -1706,6 +1775,8 @@ __global__ __launch_bounds__(256) void model_head_bwd_kernel(int kind, const flo
       const float sp1 = softplus_stable(vp[1]), sp2 = softplus_stable(vp[2]);
       const float Bc = fminf(fmaxf(sp1, 0.f), 20.f), Cc = fminf(fmaxf(sp2, 0.1f), 50.f);
       const float den = (live ? T[b] : 300.f) / 100.0f + Cc + 1e-6f;
+      if (hl.y && live) d = gscale * (vp[0] + Bc / den - hl.y[b]);
+      if (jj == 0) V(kVOne)[0] = d;
       float dvp[3];
       dvp[0] = d;
       dvp[1] = (sp1 >= 0.f && sp1 <= 20.f) ? d / den / (1.0f + expf(-vp[1])) : 0.f;  // clamp passes inside [min,max]
@@ -1724,8 +1795,15 @@ __global__ __launch_bounds__(256) void model_head_bwd_kernel(int kind, const flo
         float acc = ws[o_bh + j];
         for (int i = 0; i < Mx; ++i) acc = fmaf(mx[i], ws[o_t + i * F + j], acc);
         V(kVHid)[j] = fmaxf(acc, 0.f);
-        top[j] = acc > 0.f ? ws[o_wo + j] * d : 0.f;
       }
+      __syncthreads();
+      if (hl.y && live) {
+        float pred = ws[o_wo + F];
+        for (int j = 0; j < F; ++j) pred = fmaf(V(kVHid)[j], ws[o_wo + j], pred);  // as the forward kernel
+        d = gscale * (pred - hl.y[b]);
+      }
+      if (jj == 0) V(kVOne)[0] = d;
+      for (int j = jj; j < F; j += 32) top[j] = V(kVHid)[j] > 0.f ? ws[o_wo + j] * d : 0.f;
       __syncthreads();
       for (int i = jj; i < Mx; i += 32) {
         float acc = 0.f;
@@ -1788,13 +1866,12 @@ __global__ __launch_bounds__(256) void model_head_bwd_kernel(int kind, const flo
     }
   }
   __syncthreads();
+  const float reg_scale = (hl.y && blockIdx.x == 0) ? 2.0f * hl.dloss[0] : 0.f;  // d/dW of l2 * sum(W^2), added once
   for (int t = tid; t < total; t += blockDim.x) {
-    const float v = dws[t];
-    if (v != 0.f) {
-      int base;
-      const int sgm = head_segment(ht, t, &base);
-      atomicAdd(head_gptr(ht, sgm) + (t - base), v);
-    }
+    int base;
+    const int sgm = head_segment(ht, t, &base);
+    const float v = dws[t] + reg_scale * head_l2(ht, sgm) * ws[t];
+    if (v != 0.f) atomicAdd(head_gptr(ht, sgm) + (t - base), v);
   }
 }
 
@@ -2070,7 +2147,7 @@ int launch_adam_clipnorm(const void* table, const void* sizes, int n_vars, int64
 }
 
 static int head_tensor_table(int kind, const float* const* weights, float* const* grads, int D, int F, int Mx,
-                             HeadTensors* ht) {
+                             HeadTensors* ht, const float* l2 = nullptr) {
   const int sizes0[10] = {D * F, F, D * F, F, F * Mx, Mx, F * Mx, Mx, Mx * 3, 3};
   const int sizes1[12] = {D * F, F, D * F, F, F * Mx, Mx, F * Mx, Mx, Mx * F, F, F, 1};
   ht->n = kind == 0 ? 10 : 12;
@@ -2081,40 +2158,58 @@ static int head_tensor_table(int kind, const float* const* weights, float* const
     ht->g[i] = grads ? grads[i] : nullptr;
     if (grads && !grads[i]) return fail(IMPNN_E_BADARG, "model_head_bwd: null gradient tensor %d", i);
     ht->off[i] = off;
+    ht->l2[i] = l2 ? l2[i] : 0.f;
     off += kind == 0 ? sizes0[i] : sizes1[i];
   }
   ht->off[ht->n] = off;
   return IMPNN_OK;
 }
 
+int64_t model_head_loss_workspace_floats(int B) { return (B + kHdSPB - 1) / kHdSPB + 4; }
+
 int launch_model_head_tensors(int kind, const float* pc, const float* pa, const float* T, const float* const* weights,
-                              float* out, int B, int D, int F, int Mx, hipStream_t s) {
+                              float* out, int B, int D, int F, int Mx, hipStream_t s, const float* l2, const float* y,
+                              float* loss_out, float* workspace) {
   if (D > kHdMax || F > kHdMax || Mx > kHdMax)
     return fail(IMPNN_E_UNSUPPORTED, "model_head: dims D=%d F=%d Mx=%d exceed %d", D, F, Mx, kHdMax);
   HeadTensors ht{};
-  if (int rc = head_tensor_table(kind, weights, nullptr, D, F, Mx, &ht)) return rc;
+  if (int rc = head_tensor_table(kind, weights, nullptr, D, F, Mx, &ht, l2)) return rc;
+  HeadLoss hl{};
+  if (y) {  // workspace: [0] arrival counter (zero between calls) | [4...] one partial per workgroup
+    hl.y = y;
+    hl.loss_out = loss_out;
+    hl.counter = reinterpret_cast<unsigned int*>(workspace);
+    hl.partial = workspace + 4;
+    hl.inv_B = 1.0f / (float)B;
+  }
   const size_t lds = sizeof(float) * (((size_t)ht.off[ht.n] + 3) / 4 * 4 + (size_t)kHdSPB * 8 * kHdMax);
   if (lds > 64 * 1024) return fail(IMPNN_E_UNSUPPORTED, "model_head: weights do not fit LDS");
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)model_head_tensors_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  model_head_tensors_kernel<<<(B + kHdSPB - 1) / kHdSPB, 256, lds, s>>>(kind, pc, pa, T, ht, out, B, D, F, Mx);
+  model_head_tensors_kernel<<<(B + kHdSPB - 1) / kHdSPB, 256, lds, s>>>(kind, pc, pa, T, ht, out, B, D, F, Mx, hl);
   return check_launch("model_head_tensors");
 }
 
 int launch_model_head_bwd(int kind, const float* pc, const float* pa, const float* T, const float* const* weights,
                           const float* dout, float* dpc, float* dpa, float* const* grads, int B, int D, int F, int Mx,
-                          hipStream_t s) {
+                          hipStream_t s, const float* l2, const float* y, const float* dloss) {
   if (D > kHdMax || F > kHdMax || Mx > kHdMax)
     return fail(IMPNN_E_UNSUPPORTED, "model_head_bwd: dims D=%d F=%d Mx=%d exceed %d", D, F, Mx, kHdMax);
   HeadTensors ht{};
-  if (int rc = head_tensor_table(kind, weights, grads, D, F, Mx, &ht)) return rc;
+  if (int rc = head_tensor_table(kind, weights, grads, D, F, Mx, &ht, l2)) return rc;
+  HeadLoss hl{};
+  if (y) {
+    hl.y = y;
+    hl.dloss = dloss;
+    hl.inv_B = 1.0f / (float)B;
+  }
   const size_t lds =
       sizeof(float) * (2 * (((size_t)ht.off[ht.n] + 3) / 4 * 4) + (size_t)kHdSPB * (kHdVecs + 4) * kHdMax);
   if (lds > 160 * 1024) return fail(IMPNN_E_UNSUPPORTED, "model_head_bwd: weights do not fit LDS");
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)model_head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int groups = (B + kHdSPB - 1) / kHdSPB;  // bounded grid: every workgroup flushes ~|weights| atomics once
-  model_head_bwd_kernel<<<groups < 512 ? groups : 512, 256, lds, s>>>(kind, pc, pa, T, ht, dout, dpc, dpa, B, D, F, Mx);
+  model_head_bwd_kernel<<<groups < 512 ? groups : 512, 256, lds, s>>>(kind, pc, pa, T, ht, dout, dpc, dpa, B, D, F, Mx, hl);
   return check_launch("model_head_bwd");
 }
 

@@ -389,9 +389,29 @@ class MPNNModel:
             ks.append(self.mp_hidden.kernel)
         return self.fp_l2 * sum((k * k).sum() for k in ks)
 
+    def _head_l2(self):
+        """keras l2 lambda per head tensor, in the order of _head_tensors() (see regularization_loss)."""
+        lam = [self.fp_l2, 0.0, self.fp_l2, 0.0, 0.0, 0.0, 0.0, 0.0]
+        return lam + ([0.0, 0.0] if self.kind == "viscosity" else [self.fp_l2, 0.0, 0.0, 0.0])
+
     def _loss(self, inputs, y, training):
         from . import train
         y = torch.as_tensor(y, dtype=torch.float32).to(self.device).reshape(-1, 1)
+        if training and torch.is_grad_enabled() and y.shape[0] > 0 \
+                and max(self.atom_dim, self.fp_size, self.mixing_size) <= 64:
+            # head, mse and the l2 penalties as ONE node (impnn_model_head_loss): ~25 launches fewer per step
+            from . import autograd
+            inputs = self._to_device(inputs)
+            need = int(ops._lib.load().impnn_model_head_loss_workspace_floats(int(y.shape[0])))
+            ws = getattr(self, "_loss_ws", None)
+            if ws is None or ws.numel() < need:
+                ws = self._loss_ws = torch.zeros(max(need, 1024), dtype=torch.float32, device=self.device)
+            with autograd.training_pass():
+                pc, pa = self.encode_pooled(inputs, fused=False)
+                T = inputs.get("temperature") if self.kind == "viscosity" else None
+                return autograd.ModelHeadLoss.apply({"viscosity": 0, "melting_point": 1}[self.kind], self.fp_size,
+                                                    self.mixing_size, self._head_l2(), ws, pc, pa, T, y,
+                                                    *self._head_tensors())
         pred = self(inputs, training=True) if training else self(inputs)
         if training:
             return train.mse(y, pred) + self.regularization_loss()

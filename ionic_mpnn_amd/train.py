@@ -124,8 +124,7 @@ class GraphedTrainStep:
 
     def _step(self):
         m = self.model
-        pred = m(self.static_in, training=True)
-        loss = mse(self.static_y, pred) + m.regularization_loss()
+        loss = m._loss(self.static_in, self.static_y, training=True)
         loss.backward()
         m.optimizer.apply_gradients()
         m.optimizer.zero_grad()

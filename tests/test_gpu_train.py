@@ -237,6 +237,50 @@ def test_head_node_matches_the_layer_by_layer_head(kind, sinks):
         close(a, b, 1e-4, f"head gradient {i}")
 
 
+@pytest.mark.parametrize("kind", ["viscosity", "melting_point"])
+def test_loss_node_matches_mse_plus_penalties(kind):
+    """impnn_model_head_loss[_bwd] (head + keras mse + l2 penalties in one launch each) against the torch composition
+    of the layer-by-layer head, train.mse and regularization_loss(); the loss gradient arrives as a device scalar
+    (0.37 here, as on a data-parallel rank); repeated calls reuse the workspace (arrival counter back at zero)."""
+    from ionic_mpnn_amd import autograd
+    Va, Vb, D, K, B = 11, 6, 16, 4, 203
+    build = MM.build_model if kind == "viscosity" else MM.build_melting_point_model
+    kw = dict(atom_dim=D, fp_size=12, mixing_size=10, num_steps=1, device=DEV)
+    if kind == "viscosity":
+        kw["bond_dim"] = K
+    m = build(Va, Vb, **kw)
+    m.load_weights(weights.init_weights(kind, Va, Vb, atom_dim=D, bond_dim=K if kind == "viscosity" else D * D,
+                                        fp_size=12, mixing_size=10, num_steps=1, seed=9, perturb=True))
+    m.fp_l2 = 0.03  # large enough to matter next to the data term
+    g = torch.Generator(device="cpu").manual_seed(3)
+    pc = (torch.randn(B, D, generator=g) * 2).to(DEV).requires_grad_(True)
+    pa = (torch.randn(B, D, generator=g) * 2).to(DEV).requires_grad_(True)
+    T = (torch.rand(B, 1, generator=g) * 150 + 250).to(DEV)
+    y = torch.randn(B, 1, generator=g).to(DEV)
+    params = m._head_tensors()
+    for t in params:
+        t.requires_grad_(True)
+        t.grad = None
+    ref = train.mse(y, m.head(pc, pa, T, trace={}, differentiable=True)) + m.regularization_loss()
+    (ref * 0.37).backward()
+    want = [t.grad.clone() for t in params] + [pc.grad.clone(), pa.grad.clone()]
+    pc.grad = pa.grad = None
+    for t in params:
+        t.grad = None
+    ws = torch.zeros(1024, device=DEV)
+    k = {"viscosity": 0, "melting_point": 1}[kind]
+    losses = []
+    for rep in range(3):
+        loss = autograd.ModelHeadLoss.apply(k, 12, 10, m._head_l2(), ws, pc, pa, T if k == 0 else None, y, *params)
+        losses.append(loss.detach().clone())
+    assert torch.equal(losses[0], losses[1]) and torch.equal(losses[1], losses[2])
+    close(loss, ref, 1e-5, "loss")
+    (loss * 0.37).backward()
+    have = [t.grad for t in params] + [pc.grad, pa.grad]
+    for i, (a, b) in enumerate(zip(have, want)):
+        close(a, b, 1e-4, f"loss-node gradient {i}")
+
+
 def test_config5_shape_trains_without_nonfinite_gradients():
     """D=128, S=6 (SURVEY config 5): untrained pre-activations of the viscosity head exceed 88, where a naive
     log1p(exp(x)) differentiates to NaN."""
