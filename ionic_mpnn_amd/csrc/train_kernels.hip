@@ -178,6 +178,71 @@ __global__ __launch_bounds__(kBlock) void edge_type_scatter_kernel(const int32_t
   }
 }
 
+// The whole sort in ONE workgroup for small batches (the reference trains with 32 pairs: 8 K edge slots): every
+// thread keeps the types of its <= 16 slots in registers between the histogram and the scatter, the scan over the
+// types runs one type per thread.  Replaces four launches (zero, hist, prefix, scatter).
+constexpr int kSortSmallPer = 16;
+__global__ __launch_bounds__(1024) void edge_type_sort_small_kernel(const int32_t* __restrict__ conn,
+                                                                    const int32_t* __restrict__ bond_ids,
+                                                                    int32_t* __restrict__ cnt, int32_t* __restrict__ start,
+                                                                    int32_t* __restrict__ cursor,
+                                                                    int32_t* __restrict__ segbase,
+                                                                    int32_t* __restrict__ order, int BE, int N, int Vb) {
+  __shared__ int32_t lh[1024];  // counts, then the next free position of every type's run
+  __shared__ int32_t wc[16], wsg[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  lh[tid] = 0;
+  __syncthreads();
+  int ty[kSortSmallPer];
+#pragma unroll
+  for (int u = 0; u < kSortSmallPer; ++u) {
+    const int be = tid + u * 1024;
+    ty[u] = be < BE ? edge_type_or_neg(conn, bond_ids, be, N, Vb) : -1;
+  }
+#pragma unroll
+  for (int u = 0; u < kSortSmallPer; ++u)
+    if (ty[u] >= 0) atomicAdd(&lh[ty[u]], 1);
+  __syncthreads();
+  const int c = tid < Vb ? lh[tid] : 0;
+  const int sg = (c + kSeg - 1) / kSeg;
+  int ic = c, is = sg;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int uc = __shfl_up(ic, o), us = __shfl_up(is, o);
+    if (lane >= o) {
+      ic += uc;
+      is += us;
+    }
+  }
+  if (lane == 63) {
+    wc[wave] = ic;
+    wsg[wave] = is;
+  }
+  __syncthreads();
+  int oc = 0, os = 0;
+  for (int w = 0; w < wave; ++w) {
+    oc += wc[w];
+    os += wsg[w];
+  }
+  ic += oc;
+  is += os;
+  if (tid < Vb) {
+    cnt[tid] = c;
+    start[tid] = ic - c;
+    cursor[tid] = ic - c;
+    segbase[tid] = is - sg;
+    lh[tid] = ic - c;
+  }
+  if (tid == 1023) {  // threads past Vb carry zeros: the last inclusive value is the total
+    start[Vb] = ic;
+    segbase[Vb] = is;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < kSortSmallPer; ++u)
+    if (ty[u] >= 0) order[atomicAdd(&lh[ty[u]], 1)] = tid + u * 1024;
+}
+
 template <int ACC>  // ACC = ceil(D*D / blockDim.x) accumulators per thread
 __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_kernel(
     const float* __restrict__ h, const int32_t* __restrict__ conn, const float* __restrict__ A,
@@ -1917,6 +1982,10 @@ static int launch_edge_type_sort(const int32_t* bond_ids, const int32_t* conn, i
   int32_t* cursor = start + (Vb + 1);
   int32_t* segbase = cursor + (Vb + 1);
   int32_t* order = segbase + (Vb + 1);
+  if (BE <= 1024 * kSortSmallPer && Vb <= 1024) {
+    edge_type_sort_small_kernel<<<1, 1024, 0, s>>>(conn, bond_ids, cnt, start, cursor, segbase, order, (int)BE, N, Vb);
+    return check_launch("edge_type_sort_small");
+  }
   // (a kernel, not hipMemsetAsync: the call must behave the same inside a captured hipGraph)
   zero_ints_kernel<<<grid_for(Vb + 1), kBlock, 0, s>>>(cnt, Vb + 1);
   if (int rc = check_launch("zero_ints")) return rc;
