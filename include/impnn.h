@@ -242,6 +242,14 @@ int impnn_batch_assemble(int32_t n_ions, const int32_t* sample_idx, int32_t B, i
                          int32_t* const* atom_ids, int32_t* const* bond_ids, int32_t* const* conn,
                          const float* t_flat, float* t_out, impnn_stream_t stream);
 
+/*  Mini-batch gather from a device-resident, already padded data set (model.fit over the arrays of
+ *  train_viscosity.py:288-314): row rows[r] of tensor t -> row r of dst[t], for up to 8 tensors in one launch.
+ *  src / dst / row_bytes are HOST arrays (device pointers, bytes per row: positive multiples of 4); `rows` is a device
+ *  int64 array of n_rows indices, not range-checked (the caller built them from a permutation of the data set).
+ *  As the first node of a captured training step the host only refreshes `rows` between replays. */
+int impnn_gather_rows(int32_t n_tensors, const void* const* src, void* const* dst, const int64_t* row_bytes,
+                      const int64_t* rows, int32_t n_rows, impnn_stream_t stream);
+
 /* ---- f4: backward of the layer-at-a-time path and the optimizer step - what Keras autodiff and
  *      keras.optimizers.Adam(1e-3, clipnorm=1.0) do inside model.fit (train_viscosity.py:227-230,328-338;
  *      train_melting_point.py:205-208).  Every kernel is the adjoint of the forward entry of the same name,

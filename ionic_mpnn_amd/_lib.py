@@ -65,6 +65,7 @@ SIGNATURES = {
     "impnn_adam_clipnorm_step": (C.c_int, [vp, vp, i32, i64, f32, f32, f32, f32, f32, vp]),
     "impnn_adam_clipnorm_step_counted": (C.c_int, [vp, vp, i32, vp, f32, f32, f32, f32, f32, vp]),
     "impnn_batch_assemble": (C.c_int, [i32, vp, i32, i32, PP, PP, PP, PP, PP, i32, i32, i32, PP, PP, PP, vp, vp, vp]),
+    "impnn_gather_rows": (C.c_int, [i32, PP, PP, C.POINTER(i64), vp, i32, vp]),
     "impnn_validate_indices": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "impnn_profile_enable": (C.c_int, [i32]),
     "impnn_profile_collect": (C.c_int, [C.POINTER(C.c_float), i32, C.POINTER(i32)]),

@@ -328,6 +328,14 @@ int impnn_model_head_loss_bwd(int32_t kind, const float* pooled_cat, const float
                                dweights, B, D, F, Mx, as_stream(stream), l2, y, dloss);
 }
 
+int impnn_gather_rows(int32_t n_tensors, const void* const* src, void* const* dst, const int64_t* row_bytes,
+                      const int64_t* rows, int32_t n_rows, impnn_stream_t stream) {
+  REQUIRE(n_tensors >= 0 && n_rows >= 0, "bad shape");
+  if (n_tensors == 0 || n_rows == 0) return IMPNN_OK;
+  REQUIRE(src && dst && row_bytes && rows, "null pointer");
+  return launch_gather_rows(n_tensors, src, dst, row_bytes, rows, n_rows, as_stream(stream));
+}
+
 int impnn_profile_enable(int32_t capacity) {
   REQUIRE(capacity > 0 && capacity <= (1 << 20), "capacity out of range");
   impnn_profile_disable();

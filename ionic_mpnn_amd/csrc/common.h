@@ -53,6 +53,8 @@ int launch_model_head_bwd(int kind, const float* pc, const float* pa, const floa
                           const float* dout, float* dpc, float* dpa, float* const* grads, int B, int D, int F, int Mx,
                           hipStream_t s, const float* l2 = nullptr, const float* y = nullptr,
                           const float* dloss = nullptr);
+int launch_gather_rows(int n, const void* const* src, void* const* dst, const int64_t* row_bytes, const int64_t* rows,
+                       int n_rows, hipStream_t s);
 int launch_model_head(int kind, const float* pc, const float* pa, const float* T, const float* w, float* out, int B,
                       int D, int F, int Mx, hipStream_t s);
 int launch_validate_indices(const int32_t* conn, const int32_t* atom_ids, const int32_t* bond_ids,

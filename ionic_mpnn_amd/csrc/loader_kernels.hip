@@ -64,6 +64,33 @@ __global__ __launch_bounds__(kUnitsPerBlock* kWave) void batch_assemble_kernel(A
   if (g == 0 && p.t_out && lane == 0) p.t_out[b] = present ? p.t_flat[s] : 0.0f;
 }
 
+// ---------------------------------------------------------------------------------------
+// Mini-batch gather from a device-resident, already padded data set (model.fit over the arrays that
+// train_viscosity.py:288-314 builds once): rows `rows[r]` of up to 8 tensors -> row r of their batch buffers, one
+// launch.  Inside a captured training step this is the first node: the host then only refreshes `rows`.
+// ---------------------------------------------------------------------------------------
+constexpr int kGatherMax = 8;
+struct GatherRows {
+  const uint32_t* src[kGatherMax];
+  uint32_t* dst[kGatherMax];
+  int words[kGatherMax];  // 32-bit words per row
+  int n;
+};
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherRows g, const int64_t* __restrict__ rows, int n_rows) {
+  const int t = blockIdx.y;  // uniform: constant-index selects stay scalar
+  const uint32_t* src = g.src[0];
+  uint32_t* dst = g.dst[0];
+  int words = g.words[0];
+#pragma unroll
+  for (int q = 1; q < kGatherMax; ++q)
+    if (t == q) src = g.src[q], dst = g.dst[q], words = g.words[q];
+  for (int r = blockIdx.x; r < n_rows; r += gridDim.x) {
+    const uint32_t* s = src + rows[r] * (int64_t)words;
+    uint32_t* d = dst + (int64_t)r * words;
+    for (int i = threadIdx.x; i < words; i += 256) d[i] = s[i];
+  }
+}
+
 }  // namespace
 
 int launch_batch_assemble(int n_ions, const int32_t* sample_idx, int B, int M, const int32_t* const* atom_flat,
@@ -84,6 +111,25 @@ int launch_batch_assemble(int n_ions, const int32_t* sample_idx, int B, int M, c
   hipLaunchKernelGGL(batch_assemble_kernel, dim3((units + kUnitsPerBlock - 1) / kUnitsPerBlock),
                      dim3(kUnitsPerBlock * kWave), 0, s, p);
   return check_launch("batch_assemble");
+}
+
+int launch_gather_rows(int n, const void* const* src, void* const* dst, const int64_t* row_bytes, const int64_t* rows,
+                       int n_rows, hipStream_t s) {
+  if (n > kGatherMax) return fail(IMPNN_E_UNSUPPORTED, "gather_rows: %d tensors > %d", n, kGatherMax);
+  GatherRows g{};
+  g.n = n;
+  for (int t = 0; t < n; ++t) {
+    if (!src[t] || !dst[t]) return fail(IMPNN_E_BADARG, "gather_rows: null tensor %d", t);
+    if (row_bytes[t] <= 0 || row_bytes[t] % 4 != 0 || row_bytes[t] / 4 > 0x7fffffff)
+      return fail(IMPNN_E_BADARG, "gather_rows: row size of tensor %d must be a positive multiple of 4 bytes", t);
+    if ((reinterpret_cast<uintptr_t>(src[t]) | reinterpret_cast<uintptr_t>(dst[t])) & 3u)
+      return fail(IMPNN_E_BADARG, "gather_rows: tensor %d is not 4-byte aligned", t);
+    g.src[t] = static_cast<const uint32_t*>(src[t]);
+    g.dst[t] = static_cast<uint32_t*>(dst[t]);
+    g.words[t] = (int)(row_bytes[t] / 4);
+  }
+  gather_rows_kernel<<<dim3(n_rows < 4096 ? n_rows : 4096, n), 256, 0, s>>>(g, rows, n_rows);
+  return check_launch("gather_rows");
 }
 
 }  // namespace impnn

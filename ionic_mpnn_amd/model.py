@@ -475,20 +475,23 @@ class MPNNModel:
         from . import dist as idist
         graphed = None
         use_graph = bool(graph) and not idist.is_distributed() and n >= batch_size
+        y_dev = torch.from_numpy(y).to(self.device).reshape(-1, 1)
         for epoch in range(int(epochs)):
             order = rng.permutation(n) if shuffle else np.arange(n)
+            order_dev = torch.from_numpy(order).to(self.device)  # one upload per epoch
             tot = torch.zeros((), dtype=torch.float64, device=self.device)
             for lo in range(0, n, batch_size):
                 idx = order[lo:lo + batch_size]
-                tidx = torch.from_numpy(idx).to(self.device)
-                xb = {k: v[tidx] for k, v in x.items()}
+                tidx = order_dev[lo:lo + batch_size]
                 if use_graph and len(idx) == batch_size:
                     if graphed is None:
-                        graphed = train.GraphedTrainStep(self, xb, y[idx])
-                    loss = graphed(xb, y[idx])
+                        x = {k: v.contiguous() for k, v in x.items()}
+                        graphed = train.GraphedTrainStep(self, {k: v[tidx] for k, v in x.items()}, y[idx],
+                                                         resident=(x, y_dev))
+                    loss = graphed.step_on_rows(x, y_dev, tidx)
                 else:
-                    loss = self.train_on_batch(xb, y[idx])
-                tot += loss.double() * len(idx)
+                    loss = self.train_on_batch({k: v[tidx] for k, v in x.items()}, y_dev[tidx])
+                tot.add_(loss, alpha=len(idx))
             logs = {"loss": float(tot) / max(n, 1)}
             if validation_data is not None:
                 vx, vy = validation_data

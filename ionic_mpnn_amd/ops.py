@@ -486,6 +486,28 @@ class EncoderPipeline:
         return pooled
 
 
+def gather_rows(srcs, dsts, rows):
+    """dsts[t][r] = srcs[t][rows[r]] for up to 8 tensors in one launch (impnn_gather_rows): the mini-batch gather
+    of model.fit from a device-resident data set.  rows: device int64; tensors: contiguous, 4-byte elements."""
+    require_gpu(rows, *srcs, *dsts)
+    if rows.dtype != torch.int64 or not rows.is_contiguous():
+        raise TypeError("rows must be a contiguous int64 tensor")
+    n_rows = rows.numel()
+    rb = []
+    for sx, dx in zip(srcs, dsts):
+        if not (sx.is_contiguous() and dx.is_contiguous()) or sx.dtype != dx.dtype or sx.element_size() != 4:
+            raise TypeError("gather_rows needs contiguous tensors of one 4-byte dtype per pair")
+        if tuple(sx.shape[1:]) != tuple(dx.shape[1:]) or dx.shape[0] != n_rows:
+            raise ValueError(f"gather_rows: shapes {tuple(sx.shape)} -> {tuple(dx.shape)} for {n_rows} rows")
+        rb.append(sx[0].numel() * 4 if sx.shape[0] else 4)
+    n = len(rb)
+    st = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    dt = (C.c_void_p * n)(*[t.data_ptr() for t in dsts])
+    bt = (C.c_int64 * n)(*rb)
+    with torch.cuda.device(rows.device):
+        check(_lib.load().impnn_gather_rows(n, st, dt, bt, ptr(rows), n_rows, stream_ptr()))
+
+
 def model_head(kind, pooled_cat, pooled_an, temperature, head_weights, fp_size, mixing_size):
     """Everything after GlobalSumPool in one launch (impnn_model_head): kind "viscosity" or "melting_point"."""
     require_gpu(pooled_cat, pooled_an, head_weights)

@@ -97,12 +97,25 @@ class GraphedTrainStep:
     Inputs are copied into static buffers; every kernel argument that changes between steps lives in device
     memory (the Adam step counter)."""
 
-    def __init__(self, model, inputs, y):
+    def __init__(self, model, inputs, y, resident=None):
+        """``resident=(x, y_dev)``: the whole padded training set lives on the device; the captured step then starts
+        with the gather of the rows in ``self.static_rows`` (impnn_gather_rows) and ``step_on_rows`` only refreshes
+        those 8*batch bytes between replays."""
         self.model = model
         dev = model.device
         self.static_in = {k: v.clone() for k, v in model._to_device(inputs).items()}
         self.static_y = torch.as_tensor(np.asarray(y, np.float32)).to(dev).reshape(-1, 1).clone()
         self.batch = int(self.static_y.shape[0])
+        self.resident = None
+        if resident is not None:
+            x, y_dev = resident
+            keys = list(self.static_in)
+            ok = len(keys) + 1 <= 8 and all(
+                x[k].is_contiguous() and x[k].dtype == self.static_in[k].dtype and x[k].element_size() == 4
+                for k in keys) and y_dev.is_contiguous() and y_dev.dtype == torch.float32
+            if ok:
+                self.resident = ([x[k] for k in keys] + [y_dev], [self.static_in[k] for k in keys] + [self.static_y])
+                self.static_rows = torch.zeros(self.batch, dtype=torch.int64, device=dev)
         opt = model.optimizer
         saved_w = [t.detach().clone() for _, t in model.trainable_variables()]
         saved_o = opt.state()
@@ -124,6 +137,9 @@ class GraphedTrainStep:
 
     def _step(self):
         m = self.model
+        if self.resident is not None:
+            from . import ops
+            ops.gather_rows(self.resident[0], self.resident[1], self.static_rows)
         loss = m._loss(self.static_in, self.static_y, training=True)
         loss.backward()
         m.optimizer.apply_gradients()
@@ -132,6 +148,20 @@ class GraphedTrainStep:
 
     def matches(self, inputs):
         return all(tuple(inputs[k].shape) == tuple(v.shape) for k, v in self.static_in.items())
+
+    def step_on_rows(self, x, y_dev, rows):
+        """One step on the mini-batch ``rows`` (device int64 tensor, len = batch) of a device-resident data set:
+        the rows are gathered straight into the static buffers (one index_select per tensor, no staging copy, no
+        host round trip)."""
+        if self.resident is not None and x[next(iter(self.static_in))] is self.resident[0][0]:
+            self.static_rows.copy_(rows)  # the gather is the first node of the graph
+        else:
+            for k, v in self.static_in.items():
+                torch.index_select(x[k], 0, rows, out=v)
+            torch.index_select(y_dev, 0, rows, out=self.static_y)
+        self.graph.replay()
+        self.model.invalidate_packed_weights()
+        return self.static_loss
 
     def __call__(self, inputs, y):
         for k, v in self.static_in.items():

@@ -330,6 +330,30 @@ def test_fit_reduces_the_loss_and_early_stopping_restores_the_best_weights():
     close(a, b, 1e-5, "fused vs layered after training")
 
 
+def test_gather_rows_and_resident_fit_follow_the_eager_fit():
+    """impnn_gather_rows is bit-exact index_select for the 8 batch tensors in one launch; fit(graph=True) - the gather
+    as first node of the captured step, only the row indices refreshed per replay - walks the trajectory of the
+    eager fit (same shuffles)."""
+    rng = np.random.default_rng(2)
+    srcs = [torch.tensor(rng.integers(0, 99, size=(57, 10)), dtype=torch.int32, device=DEV),
+            torch.tensor(rng.integers(0, 99, size=(57, 16, 2)), dtype=torch.int32, device=DEV),
+            torch.tensor(rng.normal(size=(57, 1)), dtype=torch.float32, device=DEV)]
+    rows = torch.tensor(rng.integers(0, 57, size=23), dtype=torch.int64, device=DEV)
+    dsts = [torch.empty((23,) + tuple(t.shape[1:]), dtype=t.dtype, device=DEV) for t in srcs]
+    ops.gather_rows(srcs, dsts, rows)
+    for sx, dx in zip(srcs, dsts):
+        assert torch.equal(dx, sx[rows])
+    hist = {}
+    for graph in (False, True):
+        m, w, inp, y = _tiny_model()
+        big = synthetic.make_batch(72, max_atoms=10, max_edges=16, atom_vocab_size=11, bond_vocab_size=6, min_atoms=3,
+                                   seed=8)
+        yb = np.random.default_rng(8).normal(1.0, 0.5, size=72).astype(np.float32)
+        m.compile(train.Adam(1e-3, clipnorm=1.0))
+        hist[graph] = m.fit(big, yb, epochs=3, batch_size=24, seed=5, graph=graph).history["loss"]
+    np.testing.assert_allclose(hist[True], hist[False], rtol=2e-4)
+
+
 def test_graphed_train_step_follows_the_eager_trajectory():
     """The captured hipGraph of (forward, backward, Adam) must walk the same path as eager steps: same losses and
     same weights after several different mini-batches (float atomics in the embedding / message backward allow
