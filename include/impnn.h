@@ -167,6 +167,7 @@ int impnn_model_head(int32_t kind, const float* pooled_cat, const float* pooled_
  *      parameter gradients to dweights[i] (same order and shapes as weights[i]; float atomics, so the sum order
  *      over workgroups is not fixed - fp32 rounding-level run-to-run differences in these ~5k values).
  *      Gradient of clip follows tf.clip_by_value / torch.clamp: passes where min <= x <= max.
+ *      D <= 128, F, Mx <= 64 (these entries and the loss entries below).
  *      Replaces the autograd tape of train_viscosity.py:189-214 / train_melting_point.py:173-198. */
 int impnn_model_head_tensors(int32_t kind, const float* pooled_cat, const float* pooled_an,
                              const float* temperature, const float* const* weights, float* out,

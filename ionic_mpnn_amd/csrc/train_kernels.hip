@@ -1560,6 +1560,7 @@ __global__ __launch_bounds__(1024) void adam_clipnorm_kernel(const unsigned long
 // summed in LDS per workgroup and ADDED to the individual gradient buffers with float atomics.
 // ---------------------------------------------------------------------------------------
 constexpr int kHdMax = 64, kHdSPB = 8, kHdTensors = 12;
+constexpr int kHdXMax = 128;  // widest pooled state (config 5: atom_dim 128); fp_size and mixing_size stay <= kHdMax
 struct HeadTensors {
   const float* w[kHdTensors];
   float* g[kHdTensors];
@@ -1655,7 +1656,7 @@ __device__ __forceinline__ void head_forward_mix(const float* ws, const float* x
   for (int g = 0; g < 2; ++g)
     for (int j = jj; j < F; j += 32) {
       float acc = Wfp[g][D * F + j];
-      const float* x = xs + (sl * 2 + g) * kHdMax;
+      const float* x = xs + (sl * 2 + g) * kHdXMax;
       for (int i = 0; i < D; ++i) acc = fmaf(x[i], Wfp[g][i * F + j], acc);
       fpre[(sl * 2 + g) * kHdMax + j] = acc;
     }
@@ -1686,7 +1687,7 @@ __global__ __launch_bounds__(256) void model_head_tensors_kernel(int kind, const
   const int total = head_total(ht);
   float* ws = hsm;
   float* xs = ws + ((total + 3) & ~3);
-  float* fpre = xs + kHdSPB * 2 * kHdMax;
+  float* fpre = xs + kHdSPB * 2 * kHdXMax;
   float* ppre = fpre + kHdSPB * 2 * kHdMax;
   float* mix = ppre + kHdSPB * 2 * kHdMax;
   float* hid = mix + kHdSPB * kHdMax;
@@ -1695,7 +1696,7 @@ __global__ __launch_bounds__(256) void model_head_tensors_kernel(int kind, const
   const bool live = b < B;
   head_load_weights(ht, ws);
   for (int g = 0; g < 2; ++g)
-    for (int i = jj; i < D; i += 32) xs[(sl * 2 + g) * kHdMax + i] = live ? (g == 0 ? pc : pa)[(int64_t)b * D + i] : 0.f;
+    for (int i = jj; i < D; i += 32) xs[(sl * 2 + g) * kHdXMax + i] = live ? (g == 0 ? pc : pa)[(int64_t)b * D + i] : 0.f;
   __syncthreads();
   head_forward_mix(ws, xs, fpre, ppre, mix, sl, jj, D, F, Mx);
   const float* wt = ws + 2 * (D * F + F) + 2 * (F * Mx + Mx);
@@ -1768,6 +1769,10 @@ __global__ __launch_bounds__(256) void model_head_tensors_kernel(int kind, const
 
 // per-sample vectors of the backward, kHdMax floats each, in LDS: the parameter gradients are outer products of these
 enum { kVX0, kVX1, kVFp0, kVFp1, kVDfp0, kVDfp1, kVDpr0, kVDpr1, kVMix, kVTop, kVHid, kVOne, kHdVecs };
+constexpr int kHdVecStride = 2 * kHdXMax + (kHdVecs - 2) * kHdMax;
+__device__ __forceinline__ int head_vec_off(int which) {
+  return which < 2 ? which * kHdXMax : 2 * kHdXMax + (which - 2) * kHdMax;
+}
 
 __global__ __launch_bounds__(256) void model_head_bwd_kernel(int kind, const float* __restrict__ pc,
                                                              const float* __restrict__ pa, const float* __restrict__ T,
@@ -1779,12 +1784,12 @@ __global__ __launch_bounds__(256) void model_head_bwd_kernel(int kind, const flo
   const int tpad = (total + 3) & ~3;
   float* ws = hsm;
   float* dws = ws + tpad;  // parameter-gradient sums of this workgroup; element t is owned by thread t % 256
-  float* vec = dws + tpad;  // [kHdSPB][kHdVecs][kHdMax]
-  float* fpre = vec + kHdSPB * kHdVecs * kHdMax;
+  float* vec = dws + tpad;  // [kHdSPB][kHdVecStride]: the two pooled states (kHdXMax each), then 10 vectors of kHdMax
+  float* fpre = vec + kHdSPB * kHdVecStride;
   float* ppre = fpre + kHdSPB * 2 * kHdMax;
   const int tid = threadIdx.x, sl = tid >> 5, jj = tid & 31;
-  float* my = vec + sl * kHdVecs * kHdMax;
-  auto V = [&](int which) { return my + which * kHdMax; };
+  float* my = vec + sl * kHdVecStride;
+  auto V = [&](int which) { return my + head_vec_off(which); };
   head_load_weights(ht, ws);
   for (int t = tid; t < tpad; t += blockDim.x) dws[t] = 0.f;
   const int o_fp[2] = {0, D * F + F};
@@ -1921,11 +1926,11 @@ __global__ __launch_bounds__(256) void model_head_bwd_kernel(int kind, const flo
       float acc = 0.f;
       if (va < 0) {
 #pragma unroll
-        for (int q = 0; q < kHdSPB; ++q) acc += vec[(q * kHdVecs + vb) * kHdMax + j];
+        for (int q = 0; q < kHdSPB; ++q) acc += vec[q * kHdVecStride + head_vec_off(vb) + j];
       } else {
 #pragma unroll
         for (int q = 0; q < kHdSPB; ++q)
-          acc = fmaf(vec[(q * kHdVecs + va) * kHdMax + i], vec[(q * kHdVecs + vb) * kHdMax + j], acc);
+          acc = fmaf(vec[q * kHdVecStride + head_vec_off(va) + i], vec[q * kHdVecStride + head_vec_off(vb) + j], acc);
       }
       dws[t] += acc;
     }
@@ -2239,8 +2244,8 @@ int64_t model_head_loss_workspace_floats(int B) { return (B + kHdSPB - 1) / kHdS
 int launch_model_head_tensors(int kind, const float* pc, const float* pa, const float* T, const float* const* weights,
                               float* out, int B, int D, int F, int Mx, hipStream_t s, const float* l2, const float* y,
                               float* loss_out, float* workspace) {
-  if (D > kHdMax || F > kHdMax || Mx > kHdMax)
-    return fail(IMPNN_E_UNSUPPORTED, "model_head: dims D=%d F=%d Mx=%d exceed %d", D, F, Mx, kHdMax);
+  if (D > kHdXMax || F > kHdMax || Mx > kHdMax)
+    return fail(IMPNN_E_UNSUPPORTED, "model_head: dims D=%d (<= %d) F=%d Mx=%d (<= %d)", D, kHdXMax, F, Mx, kHdMax);
   HeadTensors ht{};
   if (int rc = head_tensor_table(kind, weights, nullptr, D, F, Mx, &ht, l2)) return rc;
   HeadLoss hl{};
@@ -2251,8 +2256,9 @@ int launch_model_head_tensors(int kind, const float* pc, const float* pa, const 
     hl.partial = workspace + 4;
     hl.inv_B = 1.0f / (float)B;
   }
-  const size_t lds = sizeof(float) * (((size_t)ht.off[ht.n] + 3) / 4 * 4 + (size_t)kHdSPB * 8 * kHdMax);
-  if (lds > 64 * 1024) return fail(IMPNN_E_UNSUPPORTED, "model_head: weights do not fit LDS");
+  const size_t lds =
+      sizeof(float) * (((size_t)ht.off[ht.n] + 3) / 4 * 4 + (size_t)kHdSPB * (2 * kHdXMax + 6 * kHdMax));
+  if (lds > 156 * 1024) return fail(IMPNN_E_UNSUPPORTED, "model_head: weights do not fit LDS");
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)model_head_tensors_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   model_head_tensors_kernel<<<(B + kHdSPB - 1) / kHdSPB, 256, lds, s>>>(kind, pc, pa, T, ht, out, B, D, F, Mx, hl);
@@ -2262,8 +2268,8 @@ int launch_model_head_tensors(int kind, const float* pc, const float* pa, const 
 int launch_model_head_bwd(int kind, const float* pc, const float* pa, const float* T, const float* const* weights,
                           const float* dout, float* dpc, float* dpa, float* const* grads, int B, int D, int F, int Mx,
                           hipStream_t s, const float* l2, const float* y, const float* dloss) {
-  if (D > kHdMax || F > kHdMax || Mx > kHdMax)
-    return fail(IMPNN_E_UNSUPPORTED, "model_head_bwd: dims D=%d F=%d Mx=%d exceed %d", D, F, Mx, kHdMax);
+  if (D > kHdXMax || F > kHdMax || Mx > kHdMax)
+    return fail(IMPNN_E_UNSUPPORTED, "model_head_bwd: dims D=%d (<= %d) F=%d Mx=%d (<= %d)", D, kHdXMax, F, Mx, kHdMax);
   HeadTensors ht{};
   if (int rc = head_tensor_table(kind, weights, grads, D, F, Mx, &ht, l2)) return rc;
   HeadLoss hl{};
@@ -2273,8 +2279,8 @@ int launch_model_head_bwd(int kind, const float* pc, const float* pa, const floa
     hl.inv_B = 1.0f / (float)B;
   }
   const size_t lds =
-      sizeof(float) * (2 * (((size_t)ht.off[ht.n] + 3) / 4 * 4) + (size_t)kHdSPB * (kHdVecs + 4) * kHdMax);
-  if (lds > 160 * 1024) return fail(IMPNN_E_UNSUPPORTED, "model_head_bwd: weights do not fit LDS");
+      sizeof(float) * (2 * (((size_t)ht.off[ht.n] + 3) / 4 * 4) + (size_t)kHdSPB * (kHdVecStride + 4 * kHdMax));
+  if (lds > 156 * 1024) return fail(IMPNN_E_UNSUPPORTED, "model_head_bwd: weights do not fit LDS");
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)model_head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int groups = (B + kHdSPB - 1) / kHdSPB;  // bounded grid: every workgroup flushes ~|weights| atomics once

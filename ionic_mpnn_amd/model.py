@@ -331,7 +331,7 @@ class MPNNModel:
         if trace is None and not differentiable and max(self.atom_dim, self.fp_size, self.mixing_size) <= 64:
             return ops.model_head(self.kind, pooled_cat, pooled_an, temperature, self._packed_head(), self.fp_size,
                                   self.mixing_size)  # one launch
-        if trace is None and differentiable and max(self.atom_dim, self.fp_size, self.mixing_size) <= 64 \
+        if trace is None and differentiable and self.atom_dim <= 128 and max(self.fp_size, self.mixing_size) <= 64 \
                 and torch.is_grad_enabled():
             from . import autograd
             T = temperature if self.kind == "viscosity" else None
@@ -398,7 +398,7 @@ class MPNNModel:
         from . import train
         y = torch.as_tensor(y, dtype=torch.float32).to(self.device).reshape(-1, 1)
         if training and torch.is_grad_enabled() and y.shape[0] > 0 \
-                and max(self.atom_dim, self.fp_size, self.mixing_size) <= 64:
+                and self.atom_dim <= 128 and max(self.fp_size, self.mixing_size) <= 64:
             # head, mse and the l2 penalties as ONE node (impnn_model_head_loss): ~25 launches fewer per step
             from . import autograd
             inputs = self._to_device(inputs)

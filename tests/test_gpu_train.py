@@ -237,13 +237,13 @@ def test_head_node_matches_the_layer_by_layer_head(kind, sinks):
         close(a, b, 1e-4, f"head gradient {i}")
 
 
-@pytest.mark.parametrize("kind", ["viscosity", "melting_point"])
-def test_loss_node_matches_mse_plus_penalties(kind):
+@pytest.mark.parametrize("kind,D", [("viscosity", 16), ("melting_point", 16), ("viscosity", 128)])
+def test_loss_node_matches_mse_plus_penalties(kind, D):
     """impnn_model_head_loss[_bwd] (head + keras mse + l2 penalties in one launch each) against the torch composition
     of the layer-by-layer head, train.mse and regularization_loss(); the loss gradient arrives as a device scalar
     (0.37 here, as on a data-parallel rank); repeated calls reuse the workspace (arrival counter back at zero)."""
     from ionic_mpnn_amd import autograd
-    Va, Vb, D, K, B = 11, 6, 16, 4, 203
+    Va, Vb, K, B = 11, 6, 4, 203
     build = MM.build_model if kind == "viscosity" else MM.build_melting_point_model
     kw = dict(atom_dim=D, fp_size=12, mixing_size=10, num_steps=1, device=DEV)
     if kind == "viscosity":
