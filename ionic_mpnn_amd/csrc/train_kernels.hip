@@ -1417,6 +1417,60 @@ __global__ __launch_bounds__(kBlock) void strided_gemm_splitk_kernel(GemmProblem
   // exact-f32 MFMA: wave w owns output rows m = 16w .. 16w+15 of the 64 x 32 tile (two 16 x 16 tiles);
   // contraction rows on K: lane (a, q) feeds A[row 4s+q][16w + a] and B[row 4s+q][16t + a] straight from the tiles
   f32x4_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  // Fast path (the GatedUpdate weight gradients: both operands row-major, whole tiles): 16-byte loads, the next
+  // kGR rows in flight in registers under the MFMAs of the current ones.
+  const bool fast = a_cs == 1 && b_cs == 1 && tm0 + kGM <= M && tn0 + kGN <= N && (Mh & 3) == 0 && (a_rs & 3) == 0 &&
+                    (b_rs & 3) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(A1) | reinterpret_cast<uintptr_t>(A2) | reinterpret_cast<uintptr_t>(B)) & 15u) == 0;
+  if (fast) {
+    constexpr int kA4 = kGR * kGM / 4 / kBlock, kB4 = kGR * kGN / 4 / kBlock;  // float4 per thread: 2 and 1
+    static_assert(kA4 * kBlock * 4 == kGR * kGM && kB4 * kBlock * 4 == kGR * kGN, "tile / block mismatch");
+    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t ra[kA4], rb[kB4];
+    const float* ap[kA4];
+    const float* bp[kB4];
+    int ar[kA4], br_[kB4], ao[kA4], bo[kB4];
+#pragma unroll
+    for (int i = 0; i < kA4; ++i) {
+      const int t = tid + kBlock * i, r = t / (kGM / 4), m = tm0 + 4 * (t % (kGM / 4));
+      ar[i] = r;
+      ao[i] = r * kLA + 4 * (t % (kGM / 4));
+      ap[i] = (m < Mh ? A1 + m : A2 + (m - Mh)) + (int64_t)r * a_rs;
+    }
+#pragma unroll
+    for (int i = 0; i < kB4; ++i) {
+      const int t = tid + kBlock * i, r = t / (kGN / 4), n = tn0 + 4 * (t % (kGN / 4));
+      br_[i] = r;
+      bo[i] = r * kLB + 4 * (t % (kGN / 4));
+      bp[i] = B + n + (int64_t)r * b_rs;
+    }
+    auto fetch = [&](int64_t r0) {
+      const int nr = (int)((r_hi - r0) < kGR ? (r_hi - r0) : kGR);
+#pragma unroll
+      for (int i = 0; i < kA4; ++i)
+        ra[i] = ar[i] < nr ? *reinterpret_cast<const f32x4_t*>(ap[i] + r0 * a_rs) : zero4;
+#pragma unroll
+      for (int i = 0; i < kB4; ++i)
+        rb[i] = br_[i] < nr ? *reinterpret_cast<const f32x4_t*>(bp[i] + r0 * b_rs) : zero4;
+    };
+    if (r_lo < r_hi) fetch(r_lo);
+    for (int64_t r0 = r_lo; r0 < r_hi; r0 += kGR) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < kA4; ++i) *reinterpret_cast<f32x4_t*>(As + ao[i]) = ra[i];
+#pragma unroll
+      for (int i = 0; i < kB4; ++i) *reinterpret_cast<f32x4_t*>(Bs + bo[i]) = rb[i];
+      __syncthreads();
+      if (r0 + kGR < r_hi) fetch(r0 + kGR);
+#pragma unroll
+      for (int st = 0; st < kGR / 4; ++st) {
+        const float av = As[(4 * st + q) * kLA + 16 * wave + a];
+        const float b0 = Bs[(4 * st + q) * kLB + a], b1 = Bs[(4 * st + q) * kLB + 16 + a];
+        acc0 = mfma_f32(av, b0, acc0);
+        acc1 = mfma_f32(av, b1, acc1);
+      }
+    }
+  } else
   for (int64_t r0 = r_lo; r0 < r_hi; r0 += kGR) {
     const int nr = (int)((r_hi - r0) < kGR ? (r_hi - r0) : kGR);
     __syncthreads();
