@@ -1,7 +1,10 @@
 """Autograd nodes of the layer-at-a-time path: each forward is the libimpnn entry of
 the reference layer, each backward the matching ``impnn_*_bwd`` entry (csrc/train_kernels.hip).
 ``ops.*`` routes through these nodes whenever an input requires grad and grad mode is on; with no grad
-the calls are the plain forward entries.  torch.autograd only keeps the graph - no torch op computes here."""
+the calls are the plain forward entries.  torch.autograd only keeps the graph - no torch op computes here.
+A model's training pass uses the larger nodes at the end of this file (a batch-32 step is bound by the number of
+launches): BondTypeMatricesAll (every layer's type matrices), MessagePassingStep (message -> Reduce -> GatedUpdate)
+and ModelHeadLoss (head + mse + l2 penalties); the per-layer nodes serve the drop-in layers called one by one."""
 from __future__ import annotations
 
 import torch

@@ -4,8 +4,9 @@ Adam(1e-3, clipnorm=1.0) + MSE (+ the l2(1e-4) penalty of the fingerprint Dense 
 (train_viscosity.py:189,227-230,328-338; train_melting_point.py:173,205-208,300-311).
 
 Forward and backward of the message-passing layers run in libimpnn (ionic_mpnn_amd.autograd); the
-optimizer step of all variables is one launch (impnn_adam_clipnorm_step).  The tiny head layers after
-GlobalSumPool differentiate through torch autograd.  Multi-GPU: one process per GPU, every rank takes
+optimizer step of all variables is one launch (impnn_adam_clipnorm_step); the head after GlobalSumPool, the
+mse and the l2 penalties are one node too (impnn_model_head_loss[_bwd]) - torch.autograd only keeps the graph, no
+torch arithmetic kernel runs in a step.  Multi-GPU: one process per GPU, every rank takes
 its contiguous shard of each mini-batch, and the flat gradient buffer is averaged with ONE all-reduce
 per step (RCCL; gloo in the CPU tests) before the replicated optimizer step."""
 from __future__ import annotations
