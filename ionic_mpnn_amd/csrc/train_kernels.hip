@@ -36,10 +36,25 @@ __global__ void embed_gather_bwd_kernel(const int32_t* __restrict__ ids, const f
     // contiguous slice of rows per workgroup
     const int64_t per = (total + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < total ? lo + per : total;
-    for (int64_t t = lo + threadIdx.x; t < hi; t += blockDim.x) {
-      const int64_t r = t / dim;
-      const int id = ids[r];
-      if ((unsigned)id < (unsigned)vocab) atomicAdd(&smem[id * dim + (int)(t - r * dim)], dout[t]);
+    constexpr int kU = 8;  // independent (id, value) loads in flight per thread
+    for (int64_t t0 = lo + threadIdx.x; t0 < hi; t0 += (int64_t)kU * blockDim.x) {
+      float v[kU];
+      int at[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int64_t t = t0 + (int64_t)u * blockDim.x;
+        at[u] = -1;
+        v[u] = 0.f;
+        if (t < hi) {
+          const int64_t r = t / dim;
+          const int id = ids[r];
+          v[u] = dout[t];
+          if ((unsigned)id < (unsigned)vocab) at[u] = id * dim + (int)(t - r * dim);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kU; ++u)
+        if (at[u] >= 0) atomicAdd(&smem[at[u]], v[u]);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < tsize; t += blockDim.x) {
