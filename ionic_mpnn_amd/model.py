@@ -13,6 +13,8 @@ The few Dense head layers are torch addmm on the same stream (SURVEY.md k13, 8 f
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -20,6 +22,12 @@ from . import layers as L
 from . import ops
 
 INPUT_NAMES = ["cat_atom", "cat_bond", "cat_connectivity", "an_atom", "an_bond", "an_connectivity", "temperature"]
+
+
+# largest batch whose two ion chains run on two HIP streams in the layer-at-a-time path (MPNNModel._encode_two_streams).
+# Measured on MI355X (training step, D=32): faster at every batch size, 0.47 -> 0.37 ms at 32 and 2.19 -> 1.88 ms at
+# 4096; IMPNN_TWO_STREAM_MAX_BATCH=0 in the environment switches it off.
+TWO_STREAM_MAX_BATCH = 1 << 30
 
 
 class MPNNModel:
@@ -324,8 +332,59 @@ class MPNNModel:
                 trace["cat/pooled"], trace["an/pooled"] = pc, pa
             return pc, pa
         tm = self._all_type_matrices() if trace is None else None
+        if trace is None and getattr(self, "two_streams", True) and ca.is_cuda \
+                and ca.shape[0] <= int(os.environ.get("IMPNN_TWO_STREAM_MAX_BATCH", TWO_STREAM_MAX_BATCH)):
+            return self._encode_two_streams((ca, cb, cc), (aa, ab, ac), tm)
         return (self.encode_layered("cat", ca, cb, cc, trace, type_mats=tm),
                 self.encode_layered("an", aa, ab, ac, trace, type_mats=tm))
+
+    def _encode_two_streams(self, cat, an, tm):
+        """Layer-at-a-time path: the two ions' chains are independent until the head, and most of their kernels
+        leave part of the chip idle (a batch-32 kernel nearly all of it) - the anion chain runs on a second HIP stream
+        (in training: a parallel branch of the captured hipGraph; autograd replays each node's backward on the stream
+        of its forward).  Tensors allocated on
+        the current stream and read by the side stream are recorded there, so the caching allocator does not reuse
+        them before the side stream is done.  ``join_training_streams`` after backward() orders the gradient sinks
+        written on the side stream before the optimizer step."""
+        cur = torch.cuda.current_stream(self.device)
+        side = getattr(self, "_side_stream", None)
+        if side is None:
+            side = self._side_stream = torch.cuda.Stream(device=self.device)
+            # leaves reached from the side chain through AccumulateGrad (bond_dim >= 64 keeps per-layer type-matrix
+            # nodes) see a producer on another stream than their own: intended here, torch syncs the two
+            quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if quiet is not None:
+                quiet(False)
+        for (p, _), mats in (tm or {}).items():
+            if p == "an":
+                mats.record_stream(side)
+                pool = getattr(mats, "_impnn_dmats", None)
+                if pool is not None:
+                    pool.record_stream(side)
+        for t in an:
+            t.record_stream(side)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            pa = self.encode_layered("an", *an, None, type_mats=tm)
+        pc = self.encode_layered("cat", *cat, None, type_mats=tm)
+        cur.wait_stream(side)
+        pa.record_stream(cur)
+        self._side_stream_used = True
+        if pa.requires_grad:
+            # whoever calls backward(): when the gradient reaches the anion chain, queue the join for the end of that
+            # backward pass (runs on the calling thread, so "current stream" is the caller's)
+            def _queue_join(grad):
+                torch.autograd.Variable._execution_engine.queue_callback(self.join_training_streams)
+                return grad
+            pa.register_hook(_queue_join)
+        return pc, pa
+
+    def join_training_streams(self):
+        """After loss.backward(): the current stream waits for the side stream of _encode_two_streams (its backward
+        kernels add into the gradient buffers in place, which torch's own end-of-backward sync does not see)."""
+        if getattr(self, "_side_stream_used", False):
+            torch.cuda.current_stream(self.device).wait_stream(self._side_stream)
+            self._side_stream_used = False
 
     def head(self, pooled_cat, pooled_an, temperature=None, trace=None, differentiable=False):
         if trace is None and not differentiable and max(self.atom_dim, self.fp_size, self.mixing_size) <= 64:
@@ -433,9 +492,11 @@ class MPNNModel:
             weight, _ = idist.shard_loss_weight(n_local, opt.flat_grad.device, group)
             if loss is not None:
                 (loss * weight).backward()
+            self.join_training_streams()
             idist.all_reduce_flat_gradients_(opt.flat_grad, group)
         elif loss is not None:
             loss.backward()
+            self.join_training_streams()
         opt.apply_gradients()   # clips, updates, and leaves the gradients in place ...
         opt.zero_grad()         # ... so clear them for the next accumulation
         self.invalidate_packed_weights()

@@ -143,6 +143,7 @@ class GraphedTrainStep:
             ops.gather_rows(self.resident[0], self.resident[1], self.static_rows)
         loss = m._loss(self.static_in, self.static_y, training=True)
         loss.backward()
+        m.join_training_streams()
         m.optimizer.apply_gradients()
         m.optimizer.zero_grad()
         return loss.detach()

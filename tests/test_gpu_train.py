@@ -354,6 +354,27 @@ def test_gather_rows_and_resident_fit_follow_the_eager_fit():
     np.testing.assert_allclose(hist[True], hist[False], rtol=2e-4)
 
 
+def test_melting_point_fit_graphed_follows_eager():
+    """bond_dim = atom_dim^2 keeps the per-layer type-matrix nodes (GEMM-shaped) whose gradients reach the leaves
+    through AccumulateGrad from the side stream of the anion chain: the captured step must still follow the eager one."""
+    import warnings
+    Va, Vb, D = 9, 5, 8
+    w = weights.init_weights("melting_point", Va, Vb, atom_dim=D, bond_dim=D * D, fp_size=12, mixing_size=10,
+                             num_steps=2, seed=4, perturb=True)
+    x = synthetic.make_batch(96, max_atoms=9, max_edges=14, atom_vocab_size=Va, bond_vocab_size=Vb, min_atoms=3, seed=4,
+                             with_temperature=False)
+    y = np.random.default_rng(4).normal(0.0, 1.0, size=96).astype(np.float32)
+    hist = {}
+    for graph in (False, True):
+        m = MM.build_melting_point_model(Va, Vb, atom_dim=D, fp_size=12, mixing_size=10, num_steps=2, device=DEV)
+        m.load_weights(w)
+        m.compile(train.Adam(1e-3, clipnorm=1.0))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")  # torch notes the (intended) stream of the side chain's AccumulateGrad
+            hist[graph] = m.fit(x, y, epochs=3, batch_size=32, seed=0, graph=graph).history["loss"]
+    np.testing.assert_allclose(hist[True], hist[False], rtol=2e-4)
+
+
 def test_graphed_train_step_follows_the_eager_trajectory():
     """The captured hipGraph of (forward, backward, Adam) must walk the same path as eager steps: same losses and
     same weights after several different mini-batches (float atomics in the embedding / message backward allow
