@@ -26,8 +26,9 @@ INPUT_NAMES = ["cat_atom", "cat_bond", "cat_connectivity", "an_atom", "an_bond",
 
 # largest batch whose two ion chains run on two HIP streams in the layer-at-a-time path (MPNNModel._encode_two_streams).
 # Measured on MI355X (training step, D=32): faster at every batch size, 0.47 -> 0.37 ms at 32 and 2.19 -> 1.88 ms at
-# 4096; IMPNN_TWO_STREAM_MAX_BATCH=0 in the environment switches it off.
-TWO_STREAM_MAX_BATCH = 1 << 30
+# 4096; layered inference 7.7 -> 8.5 M pairs/s at 4096 and D=128 forward 9.8 -> 9.4 ms, but 1.12 -> 1.18 ms at batch
+# 8192 (config 3), where every kernel already fills the chip.  IMPNN_TWO_STREAM_MAX_BATCH=0 switches it off.
+TWO_STREAM_MAX_BATCH = 4096
 
 
 class MPNNModel:
@@ -259,10 +260,14 @@ class MPNNModel:
     def fused_supported(self, N, E):
         return ops.encoder_fused_supported(N, E, self.atom_dim, self.bond_dim, self.num_steps, self.bond_vocab_size)
 
+    def _builds_graph(self):
+        """True when this call is differentiated: grad mode on and some variable asks for a gradient."""
+        return torch.is_grad_enabled() and any(t.requires_grad for _, t in self.trainable_variables())
+
     def _all_type_matrices(self):
         """Training: the type matrices of every message layer from one node (3 launches per step instead of 3 per
         layer); None where the per-layer entries are the better fit (bond_dim >= 64 is GEMM-shaped)."""
-        if self.bond_dim >= 64 or self.num_steps == 0 or not torch.is_grad_enabled():
+        if self.bond_dim >= 64 or self.num_steps == 0 or not self._builds_graph():
             return None
         from . import autograd
         keys = [(p, i) for p in ("cat", "an") for i in range(self.num_steps)]
@@ -277,7 +282,7 @@ class MPNNModel:
         bond = self.bond_emb(bond_ids)
         if not typed:
             bond = bond.dense()
-        one_node = typed and trace is None and torch.is_grad_enabled()  # training: a whole step as one autograd node
+        one_node = typed and trace is None and self._builds_graph()  # training: a whole step as one autograd node
         for i in range(self.num_steps):
             if one_node:
                 from . import autograd
