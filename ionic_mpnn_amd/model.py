@@ -8,8 +8,9 @@ Two execution schedules, both on the HIP library:
   * ``fused=True`` (default when the shape is covered): one impnn_encoder_fused launch computes
     both ions' encode() up to GlobalSumPool (SURVEY.md 8 a9);
   * ``fused=False``: layer at a time through the drop-in layers (a1..a8), tensor boundaries
-    identical to the reference's.
-The few Dense head layers are torch addmm on the same stream.
+    identical to the reference's; the two ions' chains run on two HIP streams (batches up to 4096).
+Everything after GlobalSumPool is one launch (impnn_model_head); training goes through the larger
+autograd nodes of ionic_mpnn_amd.autograd (f4), the torch-op head remains for traces and widths the kernels do not cover.
 """
 from __future__ import annotations
 
@@ -510,11 +511,12 @@ class MPNNModel:
     def evaluate(self, inputs, y, batch_size=32):
         """model.evaluate: sample-weighted mean of the batch losses (MSE + penalties)."""
         n = len(inputs["cat_atom"])
-        tot = 0.0
+        tot = torch.zeros((), dtype=torch.float64, device=self.device)
         for lo in range(0, n, batch_size):
             sl = slice(lo, min(n, lo + batch_size))
-            tot += float(self._loss({k: v[sl] for k, v in inputs.items()}, y[sl], training=False)) * (sl.stop - sl.start)
-        return tot / max(n, 1)
+            loss = self._loss({k: v[sl] for k, v in inputs.items()}, y[sl], training=False)
+            tot.add_(loss, alpha=sl.stop - sl.start)  # summed on the device: one host sync per evaluate()
+        return float(tot) / max(n, 1)
 
     def fit(self, x, y, validation_data=None, epochs=1, batch_size=32, callbacks=None, shuffle=True, verbose=0,
             seed=None, graph=True):
@@ -542,6 +544,7 @@ class MPNNModel:
         graphed = None
         use_graph = bool(graph) and not idist.is_distributed() and n >= batch_size
         y_dev = torch.from_numpy(y).to(self.device).reshape(-1, 1)
+        val_dev = None
         for epoch in range(int(epochs)):
             order = rng.permutation(n) if shuffle else np.arange(n)
             order_dev = torch.from_numpy(order).to(self.device)  # one upload per epoch
@@ -560,8 +563,11 @@ class MPNNModel:
                 tot.add_(loss, alpha=len(idx))
             logs = {"loss": float(tot) / max(n, 1)}
             if validation_data is not None:
-                vx, vy = validation_data
-                logs["val_loss"] = self.evaluate(self._to_device(vx), np.asarray(vy, np.float32), batch_size)
+                if val_dev is None:  # uploaded once, not per epoch
+                    val_dev = (self._to_device(validation_data[0]),
+                               torch.from_numpy(np.asarray(validation_data[1], np.float32)).to(self.device))
+                # the sample-weighted mean does not depend on how the set is cut: large forward-only batches
+                logs["val_loss"] = self.evaluate(val_dev[0], val_dev[1], max(batch_size, 4096))
             hist._log(epoch, logs)
             if verbose:
                 print(f"Epoch {epoch + 1}/{epochs} - " + " - ".join(f"{k}: {v:.4f}" for k, v in logs.items()), flush=True)
