@@ -39,6 +39,8 @@
 // index on a valid edge).  Rows >= r_b can never send (no valid edge names them) and are masked
 // by the pool, so dropping them cannot change the output; the kept set is closed under
 // "is a source of", which makes the skip exact, not approximate.
+#include <cstdlib>
+
 #include "encoder_layout.h"
 
 namespace impnn {
@@ -573,8 +575,20 @@ static int compute_units() {
 
 // One persistent workgroup per CU; for very large batches a multiple of that, so that a share never
 // holds more molecules than plan_chunks resolves in LDS (the extra workgroups simply run in rounds).
+static int g_reserved_cus = -1;  // CUs left free for kernels of other streams (the next batch's plan); -1: read the env
+int encoder_set_reserved_cus(int n) {
+  const int prev = g_reserved_cus < 0 ? 0 : g_reserved_cus;
+  g_reserved_cus = n < 0 ? 0 : n;
+  return prev;
+}
 static int encoder_workgroups(int n_ions, int B) {
-  const int cus = compute_units();
+  if (g_reserved_cus < 0) {
+    const char* e = getenv("IMPNN_ENCODER_RESERVE_CUS");
+    g_reserved_cus = e ? atoi(e) : 0;
+    if (g_reserved_cus < 0) g_reserved_cus = 0;
+  }
+  int cus = compute_units() - g_reserved_cus;
+  if (cus < 16) cus = 16;
   int f = 1;
   while ((int64_t)2 * n_ions * B / ((int64_t)cus * f) + 64 > enc::kECap) ++f;
   return cus * f;
