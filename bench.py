@@ -188,9 +188,9 @@ def main():
     for _ in range(args.steps):
         pc, pa = step()
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0  # this rank's K steps; the job time is the MAX over ranks (below)
     if world > 1:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
 
     # epilogue collective (outside the per-sample data path): global fingerprint checksum
     local_sum = torch.stack([pc.double().sum() + pa.double().sum(),
