@@ -282,7 +282,10 @@ _workspaces = {}
 
 
 def _workspace(device, nbytes):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """Encoder workspace of the CURRENT stream of `device`: calls on one stream reuse it in stream order; calls in
+    flight on different streams (a caller overlapping consecutive batches) must not share one."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

@@ -356,3 +356,24 @@ def test_fused_encoder_fuzz_against_the_oracle(seed):
     ra = O.encode(w, "an", inp["an_atom"], inp["an_bond"], inp["an_connectivity"], pooled_only=True)
     assert_close(pc.cpu().numpy(), rc, what=f"cat pooled (N={N} E={E} K={K} S={S} B={B} Va={Va} Vb={Vb})")
     assert_close(pa.cpu().numpy(), ra, what="an pooled")
+
+
+def test_batches_in_flight_on_two_streams_do_not_share_a_workspace():
+    """bench.py sends consecutive batches to two HIP streams: every stream has its own encoder workspace
+    (ops._workspace), so two different batches in flight give exactly the results of running them one after the other."""
+    Va, Vb = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB
+    m = MM.build_model(Va, Vb, device=DEV)
+    m.load_weights(weights.init_weights("viscosity", Va, Vb, seed=3, perturb=True))
+    batches = [{k: torch.from_numpy(v).to(DEV) for k, v in synthetic.make_batch(1536, seed=s).items()} for s in (1, 2)]
+    ref = [tuple(t.clone() for t in m.encode_pooled(b, fused=True)) for b in batches]
+    torch.cuda.synchronize()
+    lanes = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    for rep in range(20):
+        outs = []
+        for i in (0, 1):
+            with torch.cuda.stream(lanes[i]):
+                outs.append(m.encode_pooled(batches[i], fused=True))
+        torch.cuda.synchronize()
+        for i in (0, 1):
+            assert torch.equal(outs[i][0], ref[i][0]) and torch.equal(outs[i][1], ref[i][1])
+    assert len({k for k in ops._workspaces if k[1] in (lanes[0].cuda_stream, lanes[1].cuda_stream)}) == 2
