@@ -587,11 +587,28 @@ class MPNNModel:
         Keras default batch is 32; here the whole set is one batch unless batch_size is given."""
         n = len(inputs["cat_atom"])
         bs = n if not batch_size else int(batch_size)
+        if n == 0:
+            return np.zeros((0, 1), np.float32)
+        if n <= bs:
+            return self(inputs, fused=fused).detach().cpu().numpy()
+        # several chunks: consecutive chunks on two HIP streams (their kernels overlap, see bench.py --streams), one
+        # host synchronisation at the end instead of one per chunk
+        cur = torch.cuda.current_stream(self.device)
+        lanes = getattr(self, "_predict_lanes", None)
+        if lanes is None:
+            lanes = self._predict_lanes = [torch.cuda.Stream(device=self.device) for _ in range(2)]
+        for ln in lanes:
+            ln.wait_stream(cur)
         outs = []
-        for lo in range(0, n, bs):
+        for i, lo in enumerate(range(0, n, bs)):
             chunk = {k: v[lo:lo + bs] for k, v in inputs.items()}
-            outs.append(self(chunk, fused=fused).detach().cpu().numpy())
-        return np.concatenate(outs, axis=0) if outs else np.zeros((0, 1), np.float32)
+            with torch.cuda.stream(lanes[i % 2]):
+                outs.append(self(chunk, fused=fused).detach())
+        for ln in lanes:
+            cur.wait_stream(ln)
+        for o in outs:
+            o.record_stream(cur)
+        return torch.cat(outs, dim=0).cpu().numpy()
 
     def _to_device(self, inputs):
         out = {}

@@ -377,3 +377,17 @@ def test_batches_in_flight_on_two_streams_do_not_share_a_workspace():
         for i in (0, 1):
             assert torch.equal(outs[i][0], ref[i][0]) and torch.equal(outs[i][1], ref[i][1])
     assert len({k for k in ops._workspaces if k[1] in (lanes[0].cuda_stream, lanes[1].cuda_stream)}) == 2
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_predict_in_chunks_equals_predict_at_once(fused):
+    """model.predict(x, batch_size) sends consecutive chunks to two streams and synchronises once."""
+    Va, Vb = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB
+    m = MM.build_model(Va, Vb, device=DEV)
+    m.load_weights(weights.init_weights("viscosity", Va, Vb, seed=5, perturb=True))
+    inp = synthetic.make_batch(203, seed=11)
+    whole = m.predict(inp, fused=fused)
+    for bs in (32, 100):
+        parts = m.predict(inp, batch_size=bs, fused=fused)
+        assert parts.shape == whole.shape
+        np.testing.assert_allclose(parts, whole, rtol=1e-6, atol=1e-6)
