@@ -116,9 +116,13 @@ def main():
                     help="enqueue the plan kernels of step i+1 on a side stream before the encoder of step i "
                          "(default: plan and encode every batch back to back on one stream, which is faster on "
                          "MI355X: the encoder fills every CU's register file, see include/impnn.h)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams that take consecutive batches in turn (fused schedule; 1: every launch on one "
-                         "stream).  Measured on MI355X: 39.2 M pairs/s with 1, 44.2 M with 2, 45.4 M with 3")
+                         "stream).  Measured on MI355X (M pairs/s): 1 stream x 256 workgroups 39.2, 2 x 256 44.2, "
+                         "3 x 256 45.4, 2 x 192 47.0, 3 x 128 49.0-49.5, 3 x 160 47.7, 3 x 96 47.4, 4 x 128 39.1")
+    ap.add_argument("--encoder-workgroups", type=int, default=None,
+                    help="persistent workgroups per encoder launch (impnn_encoder_set_workgroups; 0 = one per CU). "
+                         "Default: 128 with 3 or more streams, else 0")
     ap.add_argument("--ramp-ms", type=float, default=150.0,
                     help="untimed clock ramp before the W warm-up steps: the same step() repeated for this many "
                          "milliseconds (0 disables)")
@@ -127,7 +131,7 @@ def main():
                          "range bound holds, else exact f32")
     args = ap.parse_args()
 
-    from ionic_mpnn_amd import _lib, dist as idist, model, synthetic, weights
+    from ionic_mpnn_amd import _lib, dist as idist, model, ops, synthetic, weights
 
     rank, local_rank, world = idist.env_world()
     if world != args.gpus:
@@ -161,6 +165,10 @@ def main():
 
     # --streams n: consecutive batches go to n HIP streams in turn, so the plan kernels and the uneven tail of one
     # batch's persistent encoder overlap the next batch's kernels; every step still plans and encodes one full batch
+    enc_wgs = args.encoder_workgroups
+    if enc_wgs is None:
+        enc_wgs = 128 if (args.streams >= 3 and args.schedule == "fused" and not args.pipeline) else 0
+    ops.set_encoder_workgroups(enc_wgs)
     lanes = ([torch.cuda.Stream(device=dev) for _ in range(args.streams)]
              if args.streams > 1 and fused and not pipelined else [])
     for ln in lanes:
@@ -245,6 +253,7 @@ def main():
     # the event-bracketed duration of a launch includes the time it shares the chip with the other batch's kernels.
     exclusive_ms = None
     if fused and lanes and rank == 0:
+        ops.set_encoder_workgroups(0)  # alone on the chip: one workgroup per CU
         _lib.check(lib.impnn_profile_enable(args.steps))
         for _ in range(args.steps):
             m.encode_pooled(d_in, fused=True)
@@ -255,6 +264,7 @@ def main():
         lib.impnn_profile_disable()
         if n.value:
             exclusive_ms = float(np.mean(np.frombuffer(buf, dtype=np.float32, count=n.value)))
+        ops.set_encoder_workgroups(enc_wgs)
 
     if rank != 0:
         if world > 1:
@@ -282,7 +292,8 @@ def main():
                    "pipeline": ("plan kernels of step i+1 run on a side stream under the encoder of step i; every "
                                 "step still plans and encodes one full batch") if pipelined else "none",
                    "streams": (f"{len(lanes)} HIP streams take consecutive batches in turn (each batch: plan + encoder in "
-                               "stream order on its own workspace); kernels of neighbouring batches overlap") if lanes
+                               "stream order on its own workspace); kernels of neighbouring batches overlap; "
+                               f"{enc_wgs or 'one per CU:'} persistent workgroups per encoder launch") if lanes
                    else "1 (every launch on one stream)",
                    "global_batch": int(total_pairs), "molecule_graphs_per_s": 2.0 * value, "parallelism": f"batch-sharded x{world}, weights replicated, "
                    "no data-path collective; one all-reduce of the fingerprint checksum after the timed region",
@@ -309,8 +320,9 @@ def main():
                            "overlap": (None if not lanes else {
                                "streams": len(lanes),
                                "note": "kernel_ms / achieved / frac above are per launch as HIP events and rocprofv3 see "
-                                       "it while a neighbouring batch's kernels share the chip; `exclusive` is the same "
-                                       "kernel on one stream (K untimed extra steps of this run); `whole_step` divides "
+                                       "it while neighbouring batches' kernels share the chip; `exclusive` is the same "
+                                       "kernel alone on one stream with one workgroup per CU (K untimed extra steps of "
+                                       "this run); `whole_step` divides "
                                        "the algorithmic flops by ms_per_step (plan kernels included)",
                                "exclusive": (None if not exclusive_ms else {
                                    "kernel_ms": exclusive_ms,

@@ -118,6 +118,15 @@ int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, i
  *               |h|, |agg|, |G| < 4094 and |weights| < 255 - the caller's static bound
  *               (ionic_mpnn_amd.model checks it when weights are packed and uses mode 0 otherwise). */
 int impnn_encoder_set_mode(int32_t mode);
+
+/*  Persistent workgroups per encoder launch: 0 (default) = one per CU; n = min(max(n, 16), CUs).  Process-wide, read by
+ *  impnn_encoder_workspace_bytes / _plan / _run / _fused[_prepared] - change it only between batches (a workspace planned
+ *  with one value must be run with the same value) and re-query the workspace size afterwards.  Returns the previous
+ *  value.  Why: a caller that keeps several batches in flight on several streams gets more out of the chip with fewer,
+ *  longer-running workgroups per launch - on MI355X at batch 4096: 1 stream x 256 workgroups 38-39 M pairs/s,
+ *  2 x 256: 44 M, 3 x 128: 49 M (bench.py --streams 3 --encoder-workgroups 128): each launch then fills half the CUs
+ *  and its workgroups run 6-7 chunks instead of 3-4, so the uneven tail is a smaller part of the run. */
+int impnn_encoder_set_workgroups(int32_t n);
 int64_t impnn_encoder_step_floats(int32_t D, int32_t K);
 int impnn_encoder_workspace_bytes(int32_t n_ions, int32_t B, int32_t N, int32_t E, int32_t D,
                                   int32_t K, int32_t S, int32_t Vb, size_t* bytes);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "impnn_profile_disable": (C.c_int, []),
     "impnn_debug_set_stamp_buffer": (C.c_int, [vp, sz]),
     "impnn_encoder_set_mode": (C.c_int, [i32]),
+    "impnn_encoder_set_workgroups": (C.c_int, [i32]),
 }
 
 ABI_VERSION = 1

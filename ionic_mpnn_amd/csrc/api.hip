@@ -387,6 +387,11 @@ int impnn_encoder_set_mode(int32_t mode) {
   return prev;
 }
 
+int impnn_encoder_set_workgroups(int32_t n) {
+  if (n < 0) return fail(IMPNN_E_BADARG, "impnn_encoder_set_workgroups: n must be >= 0 (0: one workgroup per CU)");
+  return encoder_set_workgroups(n);
+}
+
 int impnn_debug_set_stamp_buffer(void* device_buffer, size_t bytes) {
   g_stamp_ptr = device_buffer;
   g_stamp_bytes = device_buffer ? bytes : 0;

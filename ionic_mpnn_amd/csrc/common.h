@@ -127,6 +127,7 @@ struct EncoderArgs {
 bool encoder_fused_supported(int N, int E, int D, int K, int S, int Vb);
 size_t encoder_fused_workspace_bytes(int n_ions, int B, int N, int E, int D, int K, int S, int Vb);
 int launch_encoder_fused(const EncoderArgs& a, hipStream_t s);
+int encoder_set_workgroups(int n);
 int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase);
 size_t encoder_prepared_bytes(int S);
 int launch_encoder_prepare(const float* weights, int D, int K, int S, int mode, void* prepared, hipStream_t s);

@@ -575,20 +575,20 @@ static int compute_units() {
 
 // One persistent workgroup per CU; for very large batches a multiple of that, so that a share never
 // holds more molecules than plan_chunks resolves in LDS (the extra workgroups simply run in rounds).
-static int g_reserved_cus = -1;  // CUs left free for kernels of other streams (the next batch's plan); -1: read the env
-int encoder_set_reserved_cus(int n) {
-  const int prev = g_reserved_cus < 0 ? 0 : g_reserved_cus;
-  g_reserved_cus = n < 0 ? 0 : n;
+static int g_encoder_wgs = -1;  // persistent workgroups per encoder launch; 0: one per CU; -1: read the environment once
+int encoder_set_workgroups(int n) {
+  const int prev = g_encoder_wgs < 0 ? 0 : g_encoder_wgs;
+  g_encoder_wgs = n < 0 ? 0 : n;
   return prev;
 }
 static int encoder_workgroups(int n_ions, int B) {
-  if (g_reserved_cus < 0) {
-    const char* e = getenv("IMPNN_ENCODER_RESERVE_CUS");
-    g_reserved_cus = e ? atoi(e) : 0;
-    if (g_reserved_cus < 0) g_reserved_cus = 0;
+  if (g_encoder_wgs < 0) {
+    const char* e = getenv("IMPNN_ENCODER_WORKGROUPS");
+    g_encoder_wgs = e ? atoi(e) : 0;
+    if (g_encoder_wgs < 0) g_encoder_wgs = 0;
   }
-  int cus = compute_units() - g_reserved_cus;
-  if (cus < 16) cus = 16;
+  int cus = compute_units();
+  if (g_encoder_wgs > 0) cus = g_encoder_wgs < 16 ? 16 : (g_encoder_wgs > cus ? cus : g_encoder_wgs);
   int f = 1;
   while ((int64_t)2 * n_ions * B / ((int64_t)cus * f) + 64 > enc::kECap) ++f;
   return cus * f;

@@ -293,6 +293,16 @@ def _workspace(device, nbytes):
     return ws
 
 
+def set_encoder_workgroups(n):
+    """Persistent workgroups per encoder launch (impnn_encoder_set_workgroups; 0 = one per CU) -> previous value.
+    Process-wide; change it only between batches.  Fewer workgroups per launch pay when several batches are in flight
+    on several streams (bench.py: 3 streams x 128 workgroups)."""
+    prev = _lib.load().impnn_encoder_set_workgroups(int(n))
+    if prev < 0:
+        check(prev)
+    return prev
+
+
 def encoder_fused_supported(N, E, D, K, S, Vb):
     out = C.c_size_t(0)
     rc = _lib.load().impnn_encoder_workspace_bytes(1, 1, N, E, D, K, S, Vb, C.byref(out))

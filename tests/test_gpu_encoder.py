@@ -377,6 +377,16 @@ def test_batches_in_flight_on_two_streams_do_not_share_a_workspace():
         for i in (0, 1):
             assert torch.equal(outs[i][0], ref[i][0]) and torch.equal(outs[i][1], ref[i][1])
     assert len({k for k in ops._workspaces if k[1] in (lanes[0].cuda_stream, lanes[1].cuda_stream)}) == 2
+    # fewer persistent workgroups per launch (what bench.py uses with three streams): same results bit for bit
+    for wgs in (128, 48, 1000):
+        prev = ops.set_encoder_workgroups(wgs)
+        try:
+            for i in (0, 1):
+                pc, pa = m.encode_pooled(batches[i], fused=True)
+                assert torch.equal(pc, ref[i][0]) and torch.equal(pa, ref[i][1])
+        finally:
+            ops.set_encoder_workgroups(prev)
+    assert ops.set_encoder_workgroups(0) == 0
 
 
 @pytest.mark.parametrize("fused", [True, False])

@@ -1,5 +1,5 @@
 """Do the plan kernels of one batch overlap the encoder kernel of another?  Times N x encoder alone, N x plan alone and
-N x both (independent workspaces, two streams).  IMPNN_ENCODER_RESERVE_CUS leaves CUs free for the plan kernels."""
+N x both (independent workspaces, two streams).  IMPNN_ENCODER_WORKGROUPS=224 leaves 32 CUs free for the plan kernels."""
 import json, sys, time
 from pathlib import Path
 import torch
