@@ -230,6 +230,8 @@ def main():
 
     # extra (not `value`): the whole model forward = hot path + impnn_model_head, same batch
     full_ms = None
+    if fused and lanes:
+        ops.set_encoder_workgroups(0)  # the single-stream extras below run alone on the chip: one workgroup per CU
     if fused and world == 1:
         for _ in range(3):
             y = m(d_in, fused=True)
@@ -253,7 +255,6 @@ def main():
     # the event-bracketed duration of a launch includes the time it shares the chip with the other batch's kernels.
     exclusive_ms = None
     if fused and lanes and rank == 0:
-        ops.set_encoder_workgroups(0)  # alone on the chip: one workgroup per CU
         _lib.check(lib.impnn_profile_enable(args.steps))
         for _ in range(args.steps):
             m.encode_pooled(d_in, fused=True)
@@ -264,7 +265,7 @@ def main():
         lib.impnn_profile_disable()
         if n.value:
             exclusive_ms = float(np.mean(np.frombuffer(buf, dtype=np.float32, count=n.value)))
-        ops.set_encoder_workgroups(enc_wgs)
+    ops.set_encoder_workgroups(enc_wgs)
 
     if rank != 0:
         if world > 1:
