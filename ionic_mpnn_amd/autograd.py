@@ -7,14 +7,14 @@ launches): BondTypeMatricesAll (every layer's type matrices), MessagePassingStep
 and ModelHeadLoss (head + mse + l2 penalties); the per-layer nodes serve the drop-in layers called one by one."""
 from __future__ import annotations
 
+import ctypes as C
+import itertools
+import threading
+
 import torch
 
 from . import _lib, ops
 from ._lib import check, f32c, i32c, ptr, stream_ptr
-
-
-import itertools
-import threading
 
 
 class _PassState(threading.local):  # one scope stack per host thread
@@ -119,7 +119,6 @@ class BondTypeMatricesAll(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, bond_table, *Ws):
-        import ctypes as C
         bond_table = f32c(bond_table)
         Ws = tuple(f32c(W) for W in Ws)
         Vb, K = bond_table.shape
@@ -137,7 +136,6 @@ class BondTypeMatricesAll(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *dmats):
-        import ctypes as C
         bond_table, *Ws = ctx.saved_tensors
         Vb, K = bond_table.shape
         D = Ws[0].shape[-1]
@@ -367,7 +365,6 @@ class ModelHead(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, kind, fp_size, mixing_size, pooled_cat, pooled_an, temperature, *weights):
-        import ctypes as C
         pooled_cat, pooled_an = f32c(pooled_cat), f32c(pooled_an)
         weights = tuple(f32c(w) for w in weights)
         B, D = pooled_cat.shape
@@ -384,7 +381,6 @@ class ModelHead(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        import ctypes as C
         kind, F, Mx, params = ctx.meta
         saved = ctx.saved_tensors
         pooled_cat, pooled_an = saved[0], saved[1]
@@ -409,7 +405,6 @@ class ModelHeadLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, kind, fp_size, mixing_size, l2, workspace, pooled_cat, pooled_an, temperature, y, *weights):
-        import ctypes as C
         pooled_cat, pooled_an, y = f32c(pooled_cat), f32c(pooled_an), f32c(y).reshape(-1)
         weights = tuple(f32c(w) for w in weights)
         B, D = pooled_cat.shape
@@ -431,7 +426,6 @@ class ModelHeadLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloss):
-        import ctypes as C
         kind, F, Mx, l2, params = ctx.meta
         saved = ctx.saved_tensors
         pooled_cat, pooled_an, y = saved[0], saved[1], saved[2]
