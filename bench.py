@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--ramp-ms", type=float, default=150.0,
                     help="untimed clock ramp before the W warm-up steps: the same step() repeated for this many "
                          "milliseconds (0 disables)")
-    ap.add_argument("--mode", choices=["auto", "f32", "f16x2"], default="auto",
+    ap.add_argument("--mode", choices=["auto", "f32t", "f32", "f16x2"], default="auto",
                     help="GEMM arithmetic of the fused encoder (include/impnn.h); auto = f16x2 when the static "
                          "range bound holds, else exact f32")
     args = ap.parse_args()
@@ -156,19 +156,19 @@ def main():
     m = model.build_model(synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, atom_dim=D, bond_dim=K, num_steps=S, device=dev)
     m.load_weights(w)
     m.encoder_mode = args.mode
-    mode_used = m.resolve_encoder_mode(E) if args.schedule == "fused" else "layered"
+    mode_used = m.resolve_encoder_mode(N, E) if args.schedule == "fused" else "layered"
     d_in = {k: torch.from_numpy(v).to(dev) for k, v in inputs.items()}  # resident in HBM before timing
     fused = args.schedule == "fused"
 
     pipelined = fused and args.pipeline and S > 0
-    state = {"plan": m.plan_batch(d_in) if pipelined else None}
 
     # --streams n: consecutive batches go to n HIP streams in turn, so the plan kernels and the uneven tail of one
     # batch's persistent encoder overlap the next batch's kernels; every step still plans and encodes one full batch
     enc_wgs = args.encoder_workgroups
     if enc_wgs is None:
         enc_wgs = 128 if (args.streams >= 3 and args.schedule == "fused" and not args.pipeline) else 0
-    ops.set_encoder_workgroups(enc_wgs)
+    m.encoder_workgroups = enc_wgs
+    state = {"plan": m.plan_batch(d_in) if pipelined else None}
     lanes = ([torch.cuda.Stream(device=dev) for _ in range(args.streams)]
              if args.streams > 1 and fused and not pipelined else [])
     for ln in lanes:
@@ -231,7 +231,7 @@ def main():
     # extra (not `value`): the whole model forward = hot path + impnn_model_head, same batch
     full_ms = None
     if fused and lanes:
-        ops.set_encoder_workgroups(0)  # the single-stream extras below run alone on the chip: one workgroup per CU
+        m.encoder_workgroups = 0  # the single-stream extras below run alone on the chip: one workgroup per CU
     if fused and world == 1:
         for _ in range(3):
             y = m(d_in, fused=True)
@@ -265,7 +265,7 @@ def main():
         lib.impnn_profile_disable()
         if n.value:
             exclusive_ms = float(np.mean(np.frombuffer(buf, dtype=np.float32, count=n.value)))
-    ops.set_encoder_workgroups(enc_wgs)
+    m.encoder_workgroups = enc_wgs
 
     if rank != 0:
         if world > 1:
@@ -287,7 +287,9 @@ def main():
                    "arithmetic": {"f16x2": "f32 in/out/accumulate; every f32 GEMM product formed from fp16 hi/lo splits "
                                            "(3 v_mfma_f32_16x16x32_f16 per f32 product, error ~2^-21; parity <=1e-5 vs "
                                            "fp64 oracle in tests/test_gpu_encoder.py)",
-                                  "f32": "exact f32 products on v_mfma_f32_16x16x4_f32",
+                                  "f32": "exact f32 products on v_mfma_f32_16x16x4_f32 (pull form)",
+                                  "f32t": "exact f32 products: per-bond-type messages on v_mfma_f32_4x4x1_16b_f32, "
+                                          "GatedUpdate on v_mfma_f32_16x16x4_f32",
                                   "layered": "f32 VALU, one launch per reference layer"}[mode_used],
                    "mode": mode_used,
                    "pipeline": ("plan kernels of step i+1 run on a side stream under the encoder of step i; every "

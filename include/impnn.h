@@ -17,6 +17,9 @@
  *     allocate, free, synchronise or retain pointers past return (hipGraph-capturable);
  *   - return value: 0 = ok, negative = error (IMPNN_E_*); impnn_last_error_string() gives the
  *     thread-local text of the last failure.  No C++ exception crosses this boundary;
+ *   - re-entrant: results depend on the arguments only.  The library's only mutable state is thread-local
+ *     (last error text, the opt-in event profiler and debug stamp buffer of the calling thread) plus write-once
+ *     per-device caches of device attributes;
  *   - indices are never trusted: an edge whose src or tgt is outside [0,N) is treated as a
  *     padding edge (contributes nothing), an embedding id outside [0,V) yields a zero row -
  *     the behaviour of TF's GPU gather/scatter kernels; tf-CPU's "raise" behaviour is
@@ -41,7 +44,7 @@ extern "C" {
 typedef void* impnn_stream_t; /* hipStream_t */
 
 /* library identity: returns IMPNN_ABI_VERSION */
-#define IMPNN_ABI_VERSION 1
+#define IMPNN_ABI_VERSION 2
 int impnn_abi_version(void);
 /* text of the calling thread's last error ("" if none) */
 const char* impnn_last_error_string(void);
@@ -111,48 +114,57 @@ int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, i
  *  impnn_encoder_step_floats(D,K) returns that per-step count.
  *
  *  The arrays of pointers are HOST arrays of device pointers (length n_ions, n_ions <= 2). */
-/*  Arithmetic mode of the encoder's GEMMs (thread-local, default 1); returns the previous mode.
- *    0 "f32":   v_mfma_f32_16x16x4_f32, exact f32 products;
- *    1 "f16x2": each f32 operand split into two fp16 numbers, 3 fp16 MFMA products per f32
- *               product, f32 accumulation (error ~ f32's own; see encoder_fused.hip).  Valid while
- *               |h|, |agg|, |G| < 4094 and |weights| < 255 - the caller's static bound
- *               (ionic_mpnn_amd.model checks it when weights are packed and uses mode 0 otherwise). */
-int impnn_encoder_set_mode(int32_t mode);
-
-/*  Persistent workgroups per encoder launch: 0 (default) = one per CU; n = min(max(n, 16), CUs).  Process-wide, read by
- *  impnn_encoder_workspace_bytes / _plan / _run / _fused[_prepared] - change it only between batches (a workspace planned
- *  with one value must be run with the same value) and re-query the workspace size afterwards.  Returns the previous
- *  value.  Why: a caller that keeps several batches in flight on several streams gets more out of the chip with fewer,
- *  longer-running workgroups per launch - on MI355X at batch 4096: 1 stream x 256 workgroups 38-39 M pairs/s,
- *  2 x 256: 44 M, 3 x 128: 49 M (bench.py --streams 3 --encoder-workgroups 128): each launch then fills half the CUs
- *  and its workgroups run 6-7 chunks instead of 3-4, so the uneven tail is a smaller part of the run. */
-int impnn_encoder_set_workgroups(int32_t n);
+/*  `mode` - schedule and arithmetic of the encoder (an argument of every encoder entry; the library keeps no
+ *  encoder state between calls):
+ *    IMPNN_ENCODER_F32 (0):       "pull" form (agg = sum_k W_k G_k), v_mfma_f32_16x16x4_f32, exact f32 products;
+ *                                 atom_dim 32, bond_dim <= 8.
+ *    IMPNN_ENCODER_F16X2 (1):     pull form with each f32 operand split into two fp16 numbers, 3 fp16 MFMA products
+ *                                 per f32 product, f32 accumulation (product error ~2^-21; narrower than f32).  Valid
+ *                                 while |h|, |agg|, |G| < 4094 and |weights| < 255 - the caller's static bound
+ *                                 (ionic_mpnn_amd.model checks it when weights are packed).
+ *    IMPNN_ENCODER_F32_TYPED (2): per-bond-type form, the reference's own order of operations
+ *                                 (models/layers.py:108-112): m_e = A[bond id of e] h[src_e] with
+ *                                 A[v] = sum_k bond_table[v,k] W[k], on v_mfma_f32_4x4x1_16b_f32, exact f32 products;
+ *                                 in-edge messages summed in edge-slot order.  atom_dim 32, ANY bond_dim (K = D^2 of
+ *                                 train_melting_point.py:146 included), Vb <= 256, E <= 255.
+ *  `workgroups` - persistent workgroups of the launch: 0 = default (environment IMPNN_ENCODER_WORKGROUPS if set, else
+ *  one per compute unit), n = min(max(n, 16), CUs).  It fixes the workspace layout, so the size query, the plan and
+ *  the run of one batch must agree - impnn_encoder_plan returns what it used in its plan info and impnn_encoder_run
+ *  takes it from there.  Why it is a knob: a caller that keeps several batches in flight on several streams gets more
+ *  out of the chip with fewer, longer-running workgroups per launch (bench.py --streams 3: 128). */
+#define IMPNN_ENCODER_F32 0
+#define IMPNN_ENCODER_F16X2 1
+#define IMPNN_ENCODER_F32_TYPED 2
 int64_t impnn_encoder_step_floats(int32_t D, int32_t K);
 int impnn_encoder_workspace_bytes(int32_t n_ions, int32_t B, int32_t N, int32_t E, int32_t D,
-                                  int32_t K, int32_t S, int32_t Vb, size_t* bytes);
+                                  int32_t K, int32_t S, int32_t Vb, int32_t mode, int32_t workgroups,
+                                  size_t* bytes);
 int impnn_encoder_fused(int32_t n_ions, const int32_t* const* atom_ids,
                         const int32_t* const* bond_ids, const int32_t* const* conn,
                         const float* atom_table, int32_t Va, const float* bond_table, int32_t Vb,
-                        const float* const* weights, float* const* pooled, int32_t B, int32_t N,
-                        int32_t E, int32_t D, int32_t K, int32_t S, float ln_eps, void* workspace,
-                        size_t workspace_bytes, impnn_stream_t stream);
+                        const float* const* weights, int32_t mode, float* const* pooled, int32_t B,
+                        int32_t N, int32_t E, int32_t D, int32_t K, int32_t S, float ln_eps,
+                        int32_t workgroups, void* workspace, size_t workspace_bytes,
+                        impnn_stream_t stream);
 
-/* ---- a9 with weights prepared once.  The kernel-side weight image (transposed / padded f32 for
- *      mode 0, pre-split fp16 hi/lo blocks for mode 1) depends on the weights only, so a caller
- *      whose weights are fixed between calls (inference; every step of an epoch's evaluation) builds
- *      it once per ion and per mode and passes it to impnn_encoder_fused_prepared, which then
- *      launches only the two plan kernels and the encoder.  impnn_encoder_fused (above) takes the
- *      canonical weights and rebuilds the image in the workspace on every call (training).
- *      `prepared`: device buffer of impnn_encoder_prepared_bytes(S) bytes, 16B aligned. */
-size_t impnn_encoder_prepared_bytes(int32_t S);
-int impnn_encoder_prepare_weights(const float* weights, int32_t D, int32_t K, int32_t S, int32_t mode,
-                                  void* prepared, size_t prepared_bytes, impnn_stream_t stream);
+/* ---- a9 with weights prepared once.  The kernel-side weight image (mode 0: transposed / padded f32; mode 1:
+ *      pre-split fp16 hi/lo blocks; mode 2: the Vb per-bond-type matrices of every step in MFMA operand order plus
+ *      the transposed GatedUpdate kernels) depends on the weights only, so a caller whose weights are fixed between
+ *      calls (inference; every step of an epoch's evaluation) builds it once per ion and per mode and passes it to
+ *      impnn_encoder_fused_prepared, which then launches only the two plan kernels and the encoder.
+ *      impnn_encoder_fused (above) takes the canonical weights and rebuilds the image in the workspace on every call.
+ *      `prepared`: device buffer of impnn_encoder_prepared_bytes(S, Vb, mode) bytes, 16B aligned;
+ *      `bond_table` (Vb,K) is read by mode 2 only (may be NULL otherwise). */
+size_t impnn_encoder_prepared_bytes(int32_t S, int32_t Vb, int32_t mode);
+int impnn_encoder_prepare_weights(const float* weights, const float* bond_table, int32_t D, int32_t K,
+                                  int32_t S, int32_t Vb, int32_t mode, void* prepared,
+                                  size_t prepared_bytes, impnn_stream_t stream);
 int impnn_encoder_fused_prepared(int32_t n_ions, const int32_t* const* atom_ids,
                                  const int32_t* const* bond_ids, const int32_t* const* conn,
                                  const float* atom_table, int32_t Va, const float* bond_table,
                                  int32_t Vb, const void* const* prepared, int32_t mode,
                                  float* const* pooled, int32_t B, int32_t N, int32_t E, int32_t D,
-                                 int32_t K, int32_t S, float ln_eps, void* workspace,
+                                 int32_t K, int32_t S, float ln_eps, int32_t workgroups, void* workspace,
                                  size_t workspace_bytes, impnn_stream_t stream);
 
 /* ---- f1: everything after GlobalSumPool in one launch.
@@ -214,20 +226,26 @@ int impnn_model_head_loss_bwd(int32_t kind, const float* pooled_cat, const float
  *      graph-dependent plan kernels (row counts, shares, chunk records) of a batch into `workspace`;
  *      impnn_encoder_run runs only the encoder kernel from a planned workspace.  The plan needs no
  *      weights, so a caller may plan batch i+1 (any stream) before or while batch i is encoded and
- *      order the two with events; every batch in flight needs its own workspace.  Measured on
- *      MI355X: the encoder's 16 waves x 128 VGPRs fill the register file of every CU, so plan kernels
- *      enqueued beside it mostly wait for a CU to drain - the split buys ordering freedom (e.g. planning
- *      on an idle queue during host work), not overlap with the encoder itself.
+ *      order the two with events; every batch in flight needs its own workspace.
+ *      impnn_encoder_plan fills `info` (host memory, plain data) with the shape, record kind and workgroup count
+ *      it planned for; impnn_encoder_run takes its launch geometry from `info` and returns IMPNN_E_BADARG when its
+ *      own shape arguments or the record kind of `mode` (modes 0/1 share one, mode 2 has its own) differ.  The
+ *      workspace itself starts with the same facts (device side): an encoder kernel that finds a plan made for
+ *      another geometry writes NaN to `pooled` instead of reading records at wrong offsets.
  *      impnn_encoder_fused_prepared(...) == impnn_encoder_plan(...) then impnn_encoder_run(...). */
+typedef struct impnn_encoder_plan_info {
+  int32_t v[12];
+} impnn_encoder_plan_info;
 int impnn_encoder_plan(int32_t n_ions, const int32_t* const* atom_ids, const int32_t* const* bond_ids,
                        const int32_t* const* conn, int32_t B, int32_t N, int32_t E, int32_t D,
-                       int32_t K, int32_t S, int32_t Va, int32_t Vb, void* workspace, size_t workspace_bytes,
-                       impnn_stream_t stream);
+                       int32_t K, int32_t S, int32_t Va, int32_t Vb, int32_t mode, int32_t workgroups,
+                       void* workspace, size_t workspace_bytes, impnn_stream_t stream,
+                       impnn_encoder_plan_info* info);
 int impnn_encoder_run(int32_t n_ions, const int32_t* const* atom_ids, const float* atom_table,
                       int32_t Va, const float* bond_table, int32_t Vb, const void* const* prepared,
                       int32_t mode, float* const* pooled, int32_t B, int32_t N, int32_t E, int32_t D,
-                      int32_t K, int32_t S, float ln_eps, void* workspace, size_t workspace_bytes,
-                      impnn_stream_t stream);
+                      int32_t K, int32_t S, float ln_eps, const impnn_encoder_plan_info* info,
+                      void* workspace, size_t workspace_bytes, impnn_stream_t stream);
 
 /* ---- f2: batch assembly on the GPU - the step before the path.  Replaces, per batch, the host list
  *      handling of train_viscosity.py:291-314: np.array(list)[idx] of id lists shifted by +1
@@ -345,7 +363,7 @@ int impnn_adam_clipnorm_step_counted(const void* var_table, const int64_t* sizes
                                      int64_t* step_counter, float lr, float beta1, float beta2, float eps,
                                      float clipnorm, impnn_stream_t stream);
 
-/* ---- measurement: HIP-event timing of the dominant kernel (encoder_fused_kernel), recorded on the
+/* ---- measurement: HIP-event timing of the dominant kernel (encoder_fused_kernel / encoder_typed_kernel), recorded on the
  *      stream the kernel is launched on.  After impnn_profile_enable(capacity) every
  *      impnn_encoder_fused call of this thread records one (start, stop) event pair around that
  *      kernel alone (the two small plan kernels are outside the pair) until `capacity` pairs exist.

@@ -29,18 +29,19 @@ SIGNATURES = {
     "impnn_gated_update": (C.c_int, [vp] * 10 + [f32, vp, i64, i32, vp]),
     "impnn_global_sum_pool": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "impnn_encoder_step_floats": (i64, [i32, i32]),
-    "impnn_encoder_workspace_bytes": (C.c_int, [i32] * 8 + [C.POINTER(sz)]),
+    "impnn_encoder_workspace_bytes": (C.c_int, [i32] * 10 + [C.POINTER(sz)]),
     "impnn_encoder_fused": (C.c_int, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, i32, vp, i32,
-                                      C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i32, i32, f32, vp, sz, vp]),
-    "impnn_encoder_prepared_bytes": (sz, [i32]),
-    "impnn_encoder_prepare_weights": (C.c_int, [vp, i32, i32, i32, i32, vp, sz, vp]),
+                                      C.POINTER(vp), i32, C.POINTER(vp), i32, i32, i32, i32, i32, i32, f32, i32, vp,
+                                      sz, vp]),
+    "impnn_encoder_prepared_bytes": (sz, [i32, i32, i32]),
+    "impnn_encoder_prepare_weights": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
     "impnn_encoder_fused_prepared": (C.c_int, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, i32, vp, i32,
                                                C.POINTER(vp), i32, C.POINTER(vp), i32, i32, i32, i32, i32, i32, f32,
-                                               vp, sz, vp]),
+                                               i32, vp, sz, vp]),
     "impnn_encoder_plan": (C.c_int, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, i32, i32, i32, i32, i32,
-                                     i32, i32, vp, sz, vp]),
+                                     i32, i32, i32, i32, vp, sz, vp, vp]),
     "impnn_encoder_run": (C.c_int, [i32, C.POINTER(vp), vp, i32, vp, i32, C.POINTER(vp), i32, C.POINTER(vp), i32, i32,
-                                    i32, i32, i32, i32, f32, vp, sz, vp]),
+                                    i32, i32, i32, i32, f32, vp, vp, sz, vp]),
     "impnn_model_head_floats": (i64, [i32, i32, i32, i32]),
     "impnn_model_head": (C.c_int, [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "impnn_model_head_tensors": (C.c_int, [i32, vp, vp, vp, PP, vp, i32, i32, i32, i32, vp]),
@@ -71,12 +72,15 @@ SIGNATURES = {
     "impnn_profile_collect": (C.c_int, [C.POINTER(C.c_float), i32, C.POINTER(i32)]),
     "impnn_profile_disable": (C.c_int, []),
     "impnn_debug_set_stamp_buffer": (C.c_int, [vp, sz]),
-    "impnn_encoder_set_mode": (C.c_int, [i32]),
-    "impnn_encoder_set_workgroups": (C.c_int, [i32]),
 }
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 IMPNN_E_UNSUPPORTED = -2
+
+
+class PlanInfo(C.Structure):
+    """impnn_encoder_plan_info: what impnn_encoder_plan planned for (host-side plain data)."""
+    _fields_ = [("v", i32 * 12)]
 
 
 class ImpnnError(RuntimeError):

@@ -13,7 +13,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libimpnn.so"
-SOURCES = ["api.hip", "layer_kernels.hip", "loader_kernels.hip", "train_kernels.hip", "encoder_plan.hip", "encoder_fused.hip"]
+SOURCES = ["api.hip", "layer_kernels.hip", "loader_kernels.hip", "train_kernels.hip", "encoder_plan.hip", "encoder_fused.hip", "encoder_typed.hip"]
 ARCH = "gfx950"
 
 
@@ -28,7 +28,7 @@ def needs_build():
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "encoder_layout.h",
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "common.h", CSRC / "encoder_layout.h", CSRC / "encoder_device.h",
                                            CSRC.parent.parent / "include" / "impnn.h"]
     return any(d.stat().st_mtime > t for d in deps)
 

@@ -33,10 +33,6 @@ namespace {
 thread_local void* g_stamp_ptr = nullptr;
 thread_local size_t g_stamp_bytes = 0;
 }  // namespace
-namespace {
-thread_local int g_encoder_mode = 1;
-}
-int encoder_mode() { return g_encoder_mode; }
 
 void* debug_stamp_buffer(size_t* bytes) {
   *bytes = g_stamp_bytes;
@@ -147,15 +143,23 @@ int64_t impnn_encoder_step_floats(int32_t D, int32_t K) {
   return k * d * d + 3 * (2 * d * d + d) + 2 * d;
 }
 
+namespace {
+constexpr int32_t kInfoMagic = 0x706c616e;  // "plan"
+// impnn_encoder_plan_info.v: magic, mode class (0 pull records / 1 typed records), n_ions, B, N, E, S, Vb, nwg
+inline int mode_class(int mode) { return mode == 2 ? 1 : 0; }
+}  // namespace
+
 int impnn_encoder_workspace_bytes(int32_t n_ions, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K,
-                                  int32_t S, int32_t Vb, size_t* bytes) {
+                                  int32_t S, int32_t Vb, int32_t mode, int32_t workgroups, size_t* bytes) {
   REQUIRE(bytes, "null pointer");
   REQUIRE(n_ions >= 1 && n_ions <= 2 && B >= 0 && N > 0 && E >= 0 && D > 0 && K > 0 && S >= 0 && Vb > 0,
           "bad shape");
-  if (!encoder_fused_supported(N, E, D, K, S, Vb))
-    return fail(IMPNN_E_UNSUPPORTED, "encoder_fused: shape N=%d E=%d D=%d K=%d S=%d Vb=%d not covered", N, E, D,
-                K, S, Vb);
-  *bytes = encoder_fused_workspace_bytes(n_ions, B, N, E, D, K, S, Vb);
+  REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (f32), 1 (f16x2) or 2 (f32 typed)");
+  REQUIRE(workgroups >= 0, "workgroups must be >= 0 (0: default)");
+  if (!encoder_fused_supported(mode, N, E, D, K, S, Vb))
+    return fail(IMPNN_E_UNSUPPORTED, "encoder_fused: mode=%d shape N=%d E=%d D=%d K=%d S=%d Vb=%d not covered", mode,
+                N, E, D, K, S, Vb);
+  *bytes = encoder_fused_workspace_bytes(mode, n_ions, B, N, E, S, Vb, encoder_workgroups(n_ions, B, workgroups));
   return IMPNN_OK;
 }
 
@@ -163,26 +167,45 @@ static int encoder_common(const char* fn, int32_t n_ions, const int32_t* const* 
                           const int32_t* const* bond_ids, const int32_t* const* conn, const float* atom_table,
                           int32_t Va, const float* bond_table, int32_t Vb, const float* const* weights,
                           const void* const* prepared, int32_t mode, float* const* pooled, int32_t B, int32_t N,
-                          int32_t E, int32_t D, int32_t K, int32_t S, float ln_eps, void* workspace,
+                          int32_t E, int32_t D, int32_t K, int32_t S, float ln_eps, int32_t workgroups,
+                          const impnn_encoder_plan_info* info_in, impnn_encoder_plan_info* info_out, void* workspace,
                           size_t workspace_bytes, impnn_stream_t stream, int phases = 3) {
 #define REQ(cond, what)                                           \
   do {                                                            \
     if (!(cond)) return fail(IMPNN_E_BADARG, "%s: %s", fn, what); \
   } while (0)
   REQ(n_ions >= 1 && n_ions <= 2, "n_ions must be 1 or 2");
-  REQ(mode == 0 || mode == 1, "mode must be 0 (f32) or 1 (f16x2)");
+  REQ(mode >= 0 && mode <= 2, "mode must be 0 (f32), 1 (f16x2) or 2 (f32 typed)");
+  REQ(workgroups >= 0, "workgroups must be >= 0 (0: default)");
   REQ(B >= 0 && N > 0 && E >= 0 && D > 0 && K > 0 && S >= 0 && Va > 0 && Vb > 0, "bad shape");
   const bool planning = (phases & 1) != 0, running = (phases & 2) != 0;
   REQ(atom_ids && (!planning || (bond_ids && conn)), "null pointer");
   REQ(!running || ((weights || prepared) && pooled && atom_table && bond_table), "null pointer");
-  if (!encoder_fused_supported(N, E, D, K, S, Vb))
-    return fail(IMPNN_E_UNSUPPORTED, "encoder_fused: shape N=%d E=%d D=%d K=%d S=%d Vb=%d not covered", N, E, D,
-                K, S, Vb);
+  if (!encoder_fused_supported(mode, N, E, D, K, S, Vb))
+    return fail(IMPNN_E_UNSUPPORTED, "encoder_fused: mode=%d shape N=%d E=%d D=%d K=%d S=%d Vb=%d not covered", mode,
+                N, E, D, K, S, Vb);
+  int nwg = encoder_workgroups(n_ions, B, workgroups);
+  if (info_in) {  // run half: the plan's geometry is authoritative, and must be the geometry of this call
+    const int32_t* v = info_in->v;
+    REQ(v[0] == kInfoMagic, "plan info was not filled by impnn_encoder_plan");
+    if (v[1] != mode_class(mode) || v[2] != n_ions || v[3] != B || v[4] != N || v[5] != E || v[6] != S || v[7] != Vb)
+      return fail(IMPNN_E_BADARG, "%s: the workspace was planned for another batch shape or record kind "
+                  "(planned: kind %d, n_ions %d, B %d, N %d, E %d, S %d, Vb %d)", fn, v[1], v[2], v[3], v[4], v[5],
+                  v[6], v[7]);
+    nwg = v[8];
+  }
+  if (info_out) {
+    int32_t* v = info_out->v;
+    for (int i = 0; i < 12; ++i) v[i] = 0;
+    v[0] = kInfoMagic; v[1] = mode_class(mode); v[2] = n_ions; v[3] = B; v[4] = N; v[5] = E; v[6] = S; v[7] = Vb;
+    v[8] = nwg;
+  }
   if (B == 0) return IMPNN_OK;
   EncoderArgs a{};
   a.n_ions = n_ions;
   a.mode = mode;
   a.phases = phases;
+  a.nwg = nwg;
   for (int g = 0; g < n_ions; ++g) {
     const bool have_w = !running || S == 0 || (prepared && prepared[g]) || (weights && weights[g]);
     REQ(atom_ids[g] && have_w, "null per-ion pointer");
@@ -202,7 +225,7 @@ static int encoder_common(const char* fn, int32_t n_ions, const int32_t* const* 
   a.ln_eps = ln_eps;
   a.workspace = workspace;
   a.workspace_bytes = workspace_bytes;
-  const size_t need = encoder_fused_workspace_bytes(n_ions, B, N, E, D, K, S, Vb);
+  const size_t need = encoder_fused_workspace_bytes(mode, n_ions, B, N, E, S, Vb, nwg);
   if (need > 0 && (!workspace || workspace_bytes < need))
     return fail(IMPNN_E_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, workspace_bytes, need);
   return launch_encoder_fused(a, as_stream(stream));
@@ -210,53 +233,66 @@ static int encoder_common(const char* fn, int32_t n_ions, const int32_t* const* 
 
 int impnn_encoder_fused(int32_t n_ions, const int32_t* const* atom_ids, const int32_t* const* bond_ids,
                         const int32_t* const* conn, const float* atom_table, int32_t Va,
-                        const float* bond_table, int32_t Vb, const float* const* weights,
+                        const float* bond_table, int32_t Vb, const float* const* weights, int32_t mode,
                         float* const* pooled, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K, int32_t S,
-                        float ln_eps, void* workspace, size_t workspace_bytes, impnn_stream_t stream) {
+                        float ln_eps, int32_t workgroups, void* workspace, size_t workspace_bytes,
+                        impnn_stream_t stream) {
   return encoder_common(__func__, n_ions, atom_ids, bond_ids, conn, atom_table, Va, bond_table, Vb, weights, nullptr,
-                        encoder_mode(), pooled, B, N, E, D, K, S, ln_eps, workspace, workspace_bytes, stream);
+                        mode, pooled, B, N, E, D, K, S, ln_eps, workgroups, nullptr, nullptr, workspace,
+                        workspace_bytes, stream);
 }
 
 int impnn_encoder_plan(int32_t n_ions, const int32_t* const* atom_ids, const int32_t* const* bond_ids,
                        const int32_t* const* conn, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K, int32_t S,
-                       int32_t Va, int32_t Vb, void* workspace, size_t workspace_bytes, impnn_stream_t stream) {
-  return encoder_common(__func__, n_ions, atom_ids, bond_ids, conn, nullptr, Va, nullptr, Vb, nullptr, nullptr, 0,
-                        nullptr, B, N, E, D, K, S, 0.f, workspace, workspace_bytes, stream, 1);
+                       int32_t Va, int32_t Vb, int32_t mode, int32_t workgroups, void* workspace,
+                       size_t workspace_bytes, impnn_stream_t stream, impnn_encoder_plan_info* info) {
+  REQUIRE(info, "null plan info");
+  return encoder_common(__func__, n_ions, atom_ids, bond_ids, conn, nullptr, Va, nullptr, Vb, nullptr, nullptr, mode,
+                        nullptr, B, N, E, D, K, S, 0.f, workgroups, nullptr, info, workspace, workspace_bytes, stream,
+                        1);
 }
 
 int impnn_encoder_run(int32_t n_ions, const int32_t* const* atom_ids, const float* atom_table, int32_t Va,
                       const float* bond_table, int32_t Vb, const void* const* prepared, int32_t mode,
                       float* const* pooled, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K, int32_t S,
-                      float ln_eps, void* workspace, size_t workspace_bytes, impnn_stream_t stream) {
+                      float ln_eps, const impnn_encoder_plan_info* info, void* workspace, size_t workspace_bytes,
+                      impnn_stream_t stream) {
+  REQUIRE(info, "null plan info");
   return encoder_common(__func__, n_ions, atom_ids, nullptr, nullptr, atom_table, Va, bond_table, Vb, nullptr,
-                        prepared, mode, pooled, B, N, E, D, K, S, ln_eps, workspace, workspace_bytes, stream, 2);
+                        prepared, mode, pooled, B, N, E, D, K, S, ln_eps, 0, info, nullptr, workspace,
+                        workspace_bytes, stream, 2);
 }
 
-size_t impnn_encoder_prepared_bytes(int32_t S) { return encoder_prepared_bytes(S); }
+size_t impnn_encoder_prepared_bytes(int32_t S, int32_t Vb, int32_t mode) {
+  if (mode < 0 || mode > 2 || Vb <= 0) return 0;
+  return encoder_prepared_bytes(mode, S, Vb);
+}
 
-int impnn_encoder_prepare_weights(const float* weights, int32_t D, int32_t K, int32_t S, int32_t mode,
-                                  void* prepared, size_t prepared_bytes, impnn_stream_t stream) {
-  REQUIRE(D > 0 && K > 0 && S >= 0, "bad shape");
-  REQUIRE(mode == 0 || mode == 1, "mode must be 0 (f32) or 1 (f16x2)");
-  if (!encoder_fused_supported(1, 0, D, K, S, 1))
-    return fail(IMPNN_E_UNSUPPORTED, "encoder_prepare_weights: D=%d K=%d not covered", D, K);
+int impnn_encoder_prepare_weights(const float* weights, const float* bond_table, int32_t D, int32_t K, int32_t S,
+                                  int32_t Vb, int32_t mode, void* prepared, size_t prepared_bytes,
+                                  impnn_stream_t stream) {
+  REQUIRE(D > 0 && K > 0 && S >= 0 && Vb > 0, "bad shape");
+  REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (f32), 1 (f16x2) or 2 (f32 typed)");
+  if (!encoder_fused_supported(mode, 1, 0, D, K, S, mode == 2 ? Vb : 1))
+    return fail(IMPNN_E_UNSUPPORTED, "encoder_prepare_weights: mode=%d D=%d K=%d Vb=%d not covered", mode, D, K, Vb);
   if (S == 0) return IMPNN_OK;
-  REQUIRE(weights && prepared, "null pointer");
+  REQUIRE(weights && prepared && (mode != 2 || bond_table), "null pointer");
   REQUIRE(aligned16(prepared), "prepared buffer must be 16B aligned");
-  if (prepared_bytes < encoder_prepared_bytes(S))
+  if (prepared_bytes < encoder_prepared_bytes(mode, S, Vb))
     return fail(IMPNN_E_WORKSPACE, "encoder_prepare_weights: buffer %zu < %zu bytes", prepared_bytes,
-                encoder_prepared_bytes(S));
-  return launch_encoder_prepare(weights, D, K, S, mode, prepared, as_stream(stream));
+                encoder_prepared_bytes(mode, S, Vb));
+  return launch_encoder_prepare(weights, bond_table, D, K, S, Vb, mode, prepared, as_stream(stream));
 }
 
 int impnn_encoder_fused_prepared(int32_t n_ions, const int32_t* const* atom_ids, const int32_t* const* bond_ids,
                                  const int32_t* const* conn, const float* atom_table, int32_t Va,
                                  const float* bond_table, int32_t Vb, const void* const* prepared, int32_t mode,
                                  float* const* pooled, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K,
-                                 int32_t S, float ln_eps, void* workspace, size_t workspace_bytes,
+                                 int32_t S, float ln_eps, int32_t workgroups, void* workspace, size_t workspace_bytes,
                                  impnn_stream_t stream) {
   return encoder_common(__func__, n_ions, atom_ids, bond_ids, conn, atom_table, Va, bond_table, Vb, nullptr, prepared,
-                        mode, pooled, B, N, E, D, K, S, ln_eps, workspace, workspace_bytes, stream);
+                        mode, pooled, B, N, E, D, K, S, ln_eps, workgroups, nullptr, nullptr, workspace,
+                        workspace_bytes, stream);
 }
 
 int64_t impnn_model_head_floats(int32_t kind, int32_t D, int32_t F, int32_t Mx) {
@@ -378,18 +414,6 @@ int impnn_profile_disable(void) {
   g_prof.enabled = false;
   g_prof.open = false;
   return IMPNN_OK;
-}
-
-int impnn_encoder_set_mode(int32_t mode) {
-  if (mode != 0 && mode != 1) return fail(IMPNN_E_BADARG, "impnn_encoder_set_mode: mode must be 0 (f32) or 1 (f16x2)");
-  const int prev = g_encoder_mode;
-  g_encoder_mode = mode;
-  return prev;
-}
-
-int impnn_encoder_set_workgroups(int32_t n) {
-  if (n < 0) return fail(IMPNN_E_BADARG, "impnn_encoder_set_workgroups: n must be >= 0 (0: one workgroup per CU)");
-  return encoder_set_workgroups(n);
 }
 
 int impnn_debug_set_stamp_buffer(void* device_buffer, size_t bytes) {

@@ -103,10 +103,9 @@ int launch_batch_assemble(int n_ions, const int32_t* sample_idx, int B, int M, c
 void profile_record_start(hipStream_t s);
 void profile_record_stop(hipStream_t s);
 
-int encoder_mode();  // thread-local arithmetic mode of the fused encoder (api.hip): 0 f32, 1 f16x2 split
 void* debug_stamp_buffer(size_t* bytes);  // thread-local diagnostics buffer (api.hip), usually null
 
-// ---- fused encoder (encoder_fused.hip)
+// ---- fused encoders (encoder_fused.hip: pull form, modes 0/1; encoder_typed.hip: per-bond-type form, mode 2)
 struct EncoderArgs {
   int n_ions;
   const int32_t* atom_ids[2];
@@ -114,8 +113,9 @@ struct EncoderArgs {
   const int32_t* conn[2];
   const float* weights[2];   // canonical packed step weights (used when prepared[g] is null)
   const void* prepared[2];   // impnn_encoder_prepare_weights output for `mode`, or null
-  int mode;                  // 0 f32, 1 f16x2
+  int mode;                  // 0 f32, 1 f16x2, 2 f32 typed
   int phases;                // bit 0: plan kernels, bit 1: encoder kernel
+  int nwg;                   // resolved persistent workgroups (encoder_workgroups), same for plan and run
   float* pooled[2];
   const float* atom_table;
   const float* bond_table;
@@ -124,12 +124,14 @@ struct EncoderArgs {
   void* workspace;
   size_t workspace_bytes;
 };
-bool encoder_fused_supported(int N, int E, int D, int K, int S, int Vb);
-size_t encoder_fused_workspace_bytes(int n_ions, int B, int N, int E, int D, int K, int S, int Vb);
+bool encoder_fused_supported(int mode, int N, int E, int D, int K, int S, int Vb);
+int encoder_workgroups(int n_ions, int B, int requested);
+size_t encoder_fused_workspace_bytes(int mode, int n_ions, int B, int N, int E, int S, int Vb, int nwg);
 int launch_encoder_fused(const EncoderArgs& a, hipStream_t s);
-int encoder_set_workgroups(int n);
 int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase);
-size_t encoder_prepared_bytes(int S);
-int launch_encoder_prepare(const float* weights, int D, int K, int S, int mode, void* prepared, hipStream_t s);
+size_t encoder_prepared_bytes(int mode, int S, int Vb);
+int launch_encoder_prepare(const float* weights, const float* bond_table, int D, int K, int S, int Vb, int mode,
+                           void* prepared, hipStream_t s);
+int ensure_lds_limit(const void* kern, int slot);
 
 }  // namespace impnn

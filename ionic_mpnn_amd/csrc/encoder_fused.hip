@@ -39,61 +39,16 @@
 // index on a valid edge).  Rows >= r_b can never send (no valid edge names them) and are masked
 // by the pool, so dropping them cannot change the output; the kept set is closed under
 // "is a source of", which makes the skip exact, not approximate.
+#include <atomic>
 #include <cstdlib>
 
+#include "encoder_device.h"
 #include "encoder_layout.h"
 
 namespace impnn {
 namespace enc {
 
 namespace {
-
-__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-// Keeps a quad assembled from scalar results in one register tuple (no instruction is emitted): without
-// it the compiler splits the following vector arithmetic back into scalar v_add / v_mul.
-__device__ __forceinline__ f32x4 as_tuple(f32x4 v) {
-  asm("" : "+v"(v));
-  return v;
-}
-// Activations on whole accumulator quads, written as vector arithmetic so that the multiplies / adds
-// around the quarter-rate v_exp_f32 / v_rcp_f32 become packed v_pk_{mul,add,fma}_f32 (two lanes of work
-// per instruction).  SCALED: the accumulator carries the mode-1 scale kAcc (folded into the constant).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// A splat constant held in an SGPR pair: packed-f32 instructions cannot encode a 32-bit literal, so with a
-// literal the compiler falls back to one scalar multiply per element.
-__device__ __forceinline__ f32x4 splat_sgpr(float c) {
-  f32x2 v = {c, c};
-  asm("" : "+s"(v));
-  return __builtin_shufflevector(v, v, 0, 1, 0, 1);
-}
-template <bool SCALED>
-__device__ __forceinline__ f32x4 sigmoid4(f32x4 x) {
-  const f32x4 a = x * splat_sgpr(SCALED ? -1.44269504088896f / kAcc : -1.44269504088896f);
-  f32x4 e;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(a[i]);
-  const f32x4 d = as_tuple(as_tuple(e) + 1.0f);
-  f32x4 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_rcpf(d[i]);
-  return as_tuple(r);
-}
-template <bool SCALED>
-__device__ __forceinline__ f32x4 tanh4(f32x4 x) {
-  const f32x4 a = x * splat_sgpr(SCALED ? 2.88539008177793f / kAcc : 2.88539008177793f);
-  f32x4 e;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(a[i]);
-  const f32x4 d = as_tuple(as_tuple(e) + 1.0f);
-  f32x4 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_rcpf(d[i]);
-  return 1.0f - 2.0f * as_tuple(r);
-}
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 struct H8 {
   half8 hi, lo;
@@ -171,6 +126,17 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
   const int a = lane & 15, q = lane >> 4;
   unsigned long long* stamp = p.stamps ? p.stamps + (size_t)blockIdx.x * 32 : nullptr;
   if (stamp && tid == 0) stamp[0] = __builtin_amdgcn_s_memtime();
+  {  // the workspace must hold a plan made for this launch geometry (see encoder_typed.hip)
+    const PlanHeader hd = *p.header;
+    if (hd.magic != kPlanMagic || hd.kind != 0 || hd.nwg != (int)gridDim.x || hd.max_sub != p.max_sub ||
+        hd.B != p.B || hd.n_ions != p.n_ions) {
+      const float nan = __builtin_nanf("");
+      for (int g = 0; g < p.n_ions; ++g)
+        for (int64_t t = (int64_t)blockIdx.x * kThreads + tid; t < (int64_t)p.B * kD; t += (int64_t)gridDim.x * kThreads)
+          p.pooled[g][t] = nan;
+      return;
+    }
+  }
   const int c_begin = blockIdx.x * p.max_sub;
   const int c_end = c_begin + __builtin_amdgcn_readfirstlane(p.nsub[blockIdx.x]);
   if (c_begin >= c_end) return;
@@ -551,8 +517,16 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
 
 }  // namespace enc
 
-bool encoder_fused_supported(int N, int E, int D, int K, int S, int Vb) {
+bool encoder_typed_supported(int N, int E, int D, int S, int Vb);
+size_t encoder_typed_prepared_bytes(int S, int Vb);
+int launch_encoder_typed_prepare(const float* weights, const float* bond_table, int K, int S, int Vb, void* prepared,
+                                 hipStream_t s);
+int launch_encoder_typed_run(const EncoderArgs& a, const enc::Ws& w, hipStream_t s);
+
+bool encoder_fused_supported(int mode, int N, int E, int D, int K, int S, int Vb) {
   using namespace enc;
+  if (mode == 2) return K >= 1 && encoder_typed_supported(N, E, D, S, Vb);
+  if (mode != 0 && mode != 1) return false;
   if (D != kD || K < 1 || K > kKMax || S < 0) return false;
   if (N < 1 || N > 0xffff || E < 0) return false;
   if (Vb < 1 || Vb > 0xffff || (int64_t)Vb * kKMax > kTbCapFloats) return false;
@@ -561,48 +535,63 @@ bool encoder_fused_supported(int N, int E, int D, int K, int S, int Vb) {
   return true;
 }
 
+// Compute units of the CURRENT device (cached per device index; the value never changes).
 static int compute_units() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;  // MI355X
-    cus = n > 1024 ? 1024 : n;
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int n = cache[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;  // MI355X
+    n = n > 1024 ? 1024 : n;
+    cache[dev].store(n, std::memory_order_relaxed);
   }
-  return cus;
+  return n;
 }
 
-// One persistent workgroup per CU; for very large batches a multiple of that, so that a share never
-// holds more molecules than plan_chunks resolves in LDS (the extra workgroups simply run in rounds).
-static int g_encoder_wgs = -1;  // persistent workgroups per encoder launch; 0: one per CU; -1: read the environment once
-int encoder_set_workgroups(int n) {
-  const int prev = g_encoder_wgs < 0 ? 0 : g_encoder_wgs;
-  g_encoder_wgs = n < 0 ? 0 : n;
-  return prev;
+// 160 KB dynamic LDS opt-in, once per (kernel slot, device).
+int ensure_lds_limit(const void* kern, int slot) {
+  static std::atomic<uint64_t> done[8];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  const uint64_t bit = 1ull << dev;
+  if (done[slot].load(std::memory_order_acquire) & bit) return IMPNN_OK;
+  hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e != hipSuccess) return fail(IMPNN_E_LAUNCH, "encoder: cannot raise LDS limit: %s", hipGetErrorString(e));
+  done[slot].fetch_or(bit, std::memory_order_release);
+  return IMPNN_OK;
 }
-static int encoder_workgroups(int n_ions, int B) {
-  if (g_encoder_wgs < 0) {
-    const char* e = getenv("IMPNN_ENCODER_WORKGROUPS");
-    g_encoder_wgs = e ? atoi(e) : 0;
-    if (g_encoder_wgs < 0) g_encoder_wgs = 0;
-  }
+
+// Persistent workgroups of one encoder launch.  `requested` > 0: the caller's choice, clamped to [16, CUs];
+// 0: the default - IMPNN_ENCODER_WORKGROUPS from the environment if set, else one per CU.  For very large batches a
+// multiple of that, so that a share never holds more molecules than plan_chunks resolves in LDS (the extra
+// workgroups simply run in rounds).  A pure function of its arguments and the environment: no library state.
+int encoder_workgroups(int n_ions, int B, int requested) {
   int cus = compute_units();
-  if (g_encoder_wgs > 0) cus = g_encoder_wgs < 16 ? 16 : (g_encoder_wgs > cus ? cus : g_encoder_wgs);
+  int want = requested;
+  if (want <= 0) {
+    const char* e = getenv("IMPNN_ENCODER_WORKGROUPS");
+    want = e ? atoi(e) : 0;
+  }
+  if (want > 0) cus = want < 16 ? 16 : (want > cus ? cus : want);
   int f = 1;
   while ((int64_t)2 * n_ions * B / ((int64_t)cus * f) + 64 > enc::kECap) ++f;
   return cus * f;
 }
 
-size_t encoder_fused_workspace_bytes(int n_ions, int B, int N, int E, int D, int K, int S, int Vb) {
-  (void)D; (void)Vb;
-  return enc::ws_layout(n_ions, B, N, E, K, S, encoder_workgroups(n_ions, B)).total;
+size_t encoder_fused_workspace_bytes(int mode, int n_ions, int B, int N, int E, int S, int Vb, int nwg) {
+  return enc::ws_layout(n_ions, B, N, E, S, Vb, nwg, mode == 2).total;
 }
 
-size_t encoder_prepared_bytes(int S) { return (size_t)(S > 0 ? S : 1) * enc::kImgSlot * sizeof(float); }
+size_t encoder_prepared_bytes(int mode, int S, int Vb) {
+  if (mode == 2) return encoder_typed_prepared_bytes(S, Vb);
+  return (size_t)(S > 0 ? S : 1) * enc::kImgSlot * sizeof(float);
+}
 
-int launch_encoder_prepare(const float* weights, int D, int K, int S, int mode, void* prepared, hipStream_t s) {
+int launch_encoder_prepare(const float* weights, const float* bond_table, int D, int K, int S, int Vb, int mode,
+                           void* prepared, hipStream_t s) {
   if (S <= 0) return IMPNN_OK;
+  if (mode == 2) return launch_encoder_typed_prepare(weights, bond_table, K, S, Vb, prepared, s);
   enc::ImageParams ip{};
   ip.weights = weights;
   ip.img = static_cast<float*>(prepared);
@@ -620,11 +609,13 @@ int launch_encoder_fused(const EncoderArgs& a, hipStream_t s) {
   return IMPNN_OK;
 }
 
+// a.nwg: the resolved workgroup count (encoder_workgroups) - the same value for the plan and the run of a batch.
 int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
   using namespace enc;
-  const Ws w = ws_layout(a.n_ions, a.B, a.N, a.E, a.K, a.S, encoder_workgroups(a.n_ions, a.B));
+  const bool typed = a.mode == 2;
+  const Ws w = ws_layout(a.n_ions, a.B, a.N, a.E, a.S, a.Vb, a.nwg, typed);
   if (!aligned16(a.workspace)) return fail(IMPNN_E_BADARG, "encoder_fused: workspace must be 16B aligned");
-  if (!aligned16(a.atom_table)) return fail(IMPNN_E_BADARG, "encoder_fused: atom_table must be 16B aligned");
+  if (!plan_phase && !aligned16(a.atom_table)) return fail(IMPNN_E_BADARG, "encoder_fused: atom_table must be 16B aligned");
   char* base = static_cast<char*>(a.workspace);
   const int mode = a.mode == 1 ? 1 : 0;
   PlanParams pp{};
@@ -636,13 +627,13 @@ int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
     pp.bond_ids[g] = a.bond_ids[g];
     pp.conn[g] = a.conn[g];
     ep.pooled[g] = a.pooled[g];
-    if (plan_phase) continue;
+    if (plan_phase || typed) continue;
     if (a.prepared[g]) {
       if (!aligned16(a.prepared[g])) return fail(IMPNN_E_BADARG, "encoder_fused: prepared weights must be 16B aligned");
       ep.img[g] = static_cast<const float*>(a.prepared[g]);
     } else {  // canonical weights: build the image into the workspace first
       float* img = reinterpret_cast<float*>(base + w.img_off) + (size_t)g * (a.S > 0 ? a.S : 1) * kImgSlot;
-      if (int rc = launch_encoder_prepare(a.weights[g], a.D, a.K, a.S, mode, img, s)) return rc;
+      if (int rc = launch_encoder_prepare(a.weights[g], a.bond_table, a.D, a.K, a.S, a.Vb, mode, img, s)) return rc;
       ep.img[g] = img;
     }
   }
@@ -652,6 +643,8 @@ int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
   pp.nsub = reinterpret_cast<int32_t*>(base + w.nsub_off);
   pp.desc = reinterpret_cast<int32_t*>(base + w.desc_off);
   pp.rec = reinterpret_cast<unsigned char*>(base + w.rec_off);
+  pp.header = reinterpret_cast<PlanHeader*>(base);
+  pp.typed = typed ? 1 : 0;
   pp.n_ions = a.n_ions; pp.B = a.B; pp.N = a.N; pp.E = a.E; pp.Va = a.Va; pp.Vb = a.Vb;
   pp.grid_sub = w.max_sub < 6 ? w.max_sub : 6;  // 6 x 256 workgroups of 256 threads are resident at once on 256 CUs
   pp.nwg = w.nwg;
@@ -665,10 +658,12 @@ int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
       pp.stamps = static_cast<unsigned long long*>(sp) + (size_t)w.nwg * 32;
   }
   if (plan_phase) return launch_plan(pp, s);
+  if (typed) return launch_encoder_typed_run(a, w, s);
 
   ep.atom_table = a.atom_table;
   ep.bond_table = a.bond_table;
   ep.nsub = pp.nsub; ep.desc = pp.desc; ep.rec = pp.rec; ep.max_sub = w.max_sub;
+  ep.header = pp.header;
   ep.n_ions = a.n_ions; ep.B = a.B; ep.N = a.N; ep.K = a.K; ep.S = a.S;
   ep.Va = a.Va; ep.Vb = a.Vb; ep.ln_eps = a.ln_eps;
   ep.stamps = nullptr;
@@ -682,12 +677,7 @@ int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
                             : variant == 1 ? encoder_fused_kernel<8, false>
                             : variant == 2 ? encoder_fused_kernel<0, true>
                                            : encoder_fused_kernel<8, true>;
-  static bool attr_set[4] = {false, false, false, false};
-  if (!attr_set[variant]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return fail(IMPNN_E_LAUNCH, "encoder_fused: cannot raise LDS limit: %s", hipGetErrorString(e));
-    attr_set[variant] = true;
-  }
+  if (int rc = ensure_lds_limit((const void*)kern, variant)) return rc;
   profile_record_start(s);
   size_t lds = kLdsFixedBytes + align_up((size_t)a.Vb * kKMax * sizeof(float), 512);
   const size_t atab_bytes = ((size_t)a.Va + 1) * kHS * sizeof(float);

@@ -61,6 +61,45 @@ constexpr int kRecEnt = 3136;      // u32[kECap]    : in-edge lists in edge-slot
 constexpr int kRecBytes = 8192;
 static_assert(kRecEnt + 4 * kECap <= kRecBytes && kRecEnt % 16 == 0, "record layout");
 
+// ---- "typed" encoder (mode 2, encoder_typed.hip): the message is m_e = A[bond type of e] * h[src_e] with the
+// per-bond-type matrices A[v] = sum_k bond_table[v,k] W[k] (models/layers.py:108 evaluated once per type), so
+// bond_dim drops out of the kernel (K = D^2 of train_melting_point.py:146 included).  Edges of a chunk are grouped
+// by type in groups of <= 4 (one v_mfma_f32_4x4x1 block column each), messages land in an LDS buffer in
+// "jagged diagonal" order - slot(row, d) = jdptr[d] + row for the d-th in-edge (edge-slot order) of placed row
+// `row`; rows are placed by descending in-degree, so the rows that have a d-th in-edge are a prefix - and every
+// atom row then sums its in-edges in edge-slot order (the reference's sequential scatter_nd, models/layers.py:78-82).
+constexpr int kTECap = 512;          // valid edges per chunk (2 per virtual row)
+constexpr int kTGrpCap = 512;        // <= kTECap/4 + (Vb - 1) groups
+constexpr int kTVbMax = 256;         // bond ids travel as 8 bits
+constexpr int kTRecRowdeg = 0;       // u16[kRCap]    : in-degree of the PLACED row
+constexpr int kTRecTilemax = 528;    // u8[16]
+constexpr int kTRecMoloff = 544;     // u16[kRCap + 2]
+constexpr int kTRecMolrows = 1072;   // u16[kRCap]
+constexpr int kTRecPoolrow = 1584;   // u16[kRCap]
+constexpr int kTRecRowatom = 2096;   // i32[kRCap]
+constexpr int kTRecCounts = 3120;    // u16 groups, u16 edges, u16 max in-degree
+constexpr int kTRecJdptr = 3136;     // u16[258]      : first message slot of in-edge index d
+constexpr int kTRecGrp = 3664;       // uint4[kTGrpCap]: type | cnt << 8, 4 x u8 placed source row, 4 x u16 message slot
+constexpr int kTRecBytes = 12288;
+static_assert(kTRecGrp % 16 == 0 && kTRecGrp + 16 * kTGrpCap <= kTRecBytes, "typed record layout");
+constexpr int kTMsgFloats = kTECap * kD;  // message buffer, 128 B per slot, 16-byte units XOR-swizzled by slot
+// 16-byte unit u (0..7) of message slot s -> float offset.  16 consecutive slots x one unit cover all 16 bank quads
+// (the pull of a tile is conflict-free), and the 8 units of a slot stay a permutation of its 32 banks.
+__host__ __device__ constexpr int tmsg_off(int s, int u) { return s * kD + ((u ^ ((s >> 1) & 7)) << 2); }
+// per-step update image: gate kernels transposed (3 x 32 rows of kUpdRS) + 5 vectors, in a slot of 2 loads per thread
+constexpr int kTUpdFloats = 3 * kD * kUpdRS + 5 * kD;  // 6688
+constexpr int kTUpdSlot = 2 * kThreads * 4;             // 8192 floats
+constexpr int kTUpdLds = 6912;                          // floats kept in LDS (>= kTUpdFloats, multiple of 128)
+static_assert(kTUpdFloats <= kTUpdLds && kTUpdLds <= kTUpdSlot, "typed update image");
+// type matrices of one (ion, step): Vb x 1024 floats, each in 4x4x1-MFMA B-operand order:
+//   A[v][r][k] at v*1024 + (k >> 2)*128 + r*4 + (k & 3)   (lane r & 31 loads 8 x 16 B, one per k-quad)
+constexpr int kTMatFloats = kD * kD;
+// prepared buffer of one ion: S update slots | S x Vb type matrices | one canonical (Vb,32,32) scratch
+inline size_t typed_prepared_floats(int S, int Vb) {
+  const size_t s = S > 0 ? S : 1;
+  return s * kTUpdSlot + s * (size_t)Vb * kTMatFloats + (size_t)Vb * kTMatFloats;
+}
+
 // chunk descriptor (int4): {first molecule, molecules, 0, rows | ion << 16}
 constexpr int kPB = 16;  // molecules per plan_stats workgroup (= partial-sum granularity)
 
@@ -70,29 +109,37 @@ struct Ws {
   int nwg;      // persistent encoder workgroups (= compute units)
   int max_sub;  // chunk slots per workgroup (upper bound of chunks in one share)
   int nblk;     // 16-molecule blocks per ion
+  int rec_bytes;  // kRecBytes (pull modes) or kTRecBytes (typed)
 };
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-inline int vr_max_of(int N, int E) {
-  int v = (E + 3) / 4;
+inline int vr_max_of(int N, int E, bool typed = false) {
+  int v = typed ? (E + 1) / 2 : (E + 3) / 4;
   int m = N > v ? N : v;
   return m < 1 ? 1 : m;
 }
 
-inline Ws ws_layout(int n_ions, int B, int N, int E, int K, int S, int nwg) {
-  (void)K;
+// The first 256 bytes of a workspace are the plan header (PlanHeader): written by the plan, checked by the encoder.
+struct PlanHeader {
+  int32_t magic, kind, n_ions, B, N, E, nwg, max_sub;
+};
+constexpr int32_t kPlanMagic = 0x696d706e;  // "impn"
+
+inline Ws ws_layout(int n_ions, int B, int N, int E, int S, int Vb, int nwg, bool typed) {
   Ws w{};
-  const int vrmax = vr_max_of(N, E);
+  const int vrmax = vr_max_of(N, E, typed);
+  w.rec_bytes = typed ? kTRecBytes : kRecBytes;
   const int win = kRCap - vrmax + 1;  // a chunk closed by next-fit holds at least this many rows
   w.nwg = nwg;
   w.nblk = (B + kPB - 1) / kPB;
   // rows of one share <= 2 * (all rows) / nwg + vrmax (ion split rounds to whole workgroups)
   const int64_t share_rows = (2 * (int64_t)n_ions * B * vrmax) / nwg + vrmax;
   w.max_sub = (int)(share_rows / win) + 2;
-  size_t off = 0;
+  size_t off = 256;  // plan header
   w.img_off = off;
-  off = align_up(off + (size_t)n_ions * (S > 0 ? S : 1) * kImgSlot * sizeof(float), 256);
+  off = align_up(off + (typed ? (size_t)n_ions * typed_prepared_floats(S, Vb)
+                              : (size_t)n_ions * (S > 0 ? S : 1) * kImgSlot) * sizeof(float), 256);
   w.rows_off = off;
   off = align_up(off + (size_t)n_ions * B * sizeof(int32_t), 256);
   w.vr_off = off;
@@ -106,7 +153,7 @@ inline Ws ws_layout(int n_ions, int B, int N, int E, int K, int S, int nwg) {
   w.desc_off = off;
   off = align_up(off + (size_t)nwg * w.max_sub * 4 * sizeof(int32_t), 256);
   w.rec_off = off;
-  off = align_up(off + (size_t)nwg * w.max_sub * kRecBytes, 256);
+  off = align_up(off + (size_t)nwg * w.max_sub * w.rec_bytes, 256);
   w.total = off;
   return w;
 }
@@ -123,6 +170,8 @@ struct PlanParams {
   unsigned char* rec; // [nwg][max_sub][kRecBytes]
   int n_ions, B, N, E, Va, Vb, nwg, max_sub, nblk;
   int grid_sub;  // plan_chunks workgroups launched per share (<= max_sub)
+  int typed;     // 1: typed records (kTRecBytes), 2 valid edges per virtual row
+  PlanHeader* header;          // written by plan_stats block 0
   unsigned long long* stamps;  // diagnostics only: 16 words written by plan_chunks workgroup 0
 };
 
@@ -142,10 +191,34 @@ struct EncParams {
   const int32_t* nsub;
   const int32_t* desc;
   const unsigned char* rec;
+  const PlanHeader* header;
   int n_ions, B, N, K, S, Va, Vb, max_sub;
   int atab_lds;  // atom table copied to LDS (Va*32 floats after the bond table copy); 0: read from HBM/L2
   float ln_eps;
   unsigned long long* stamps;  // diagnostics only (impnn_debug_set_stamp_buffer): 32 words per workgroup
+};
+
+struct TImageParams {
+  const float* weights;  // S steps, canonical layout
+  const float* bond_table;
+  float* prepared;       // typed_prepared_floats(S, Vb)
+  int K, S, Vb;
+  int64_t step_floats;
+};
+
+struct TEncParams {
+  float* pooled[2];
+  const float* atom_table;
+  const float* upd[2];   // per ion: S update slots (kTUpdSlot floats each)
+  const float* tmat[2];  // per ion: S x Vb type matrices in operand order
+  const int32_t* nsub;
+  const int32_t* desc;
+  const unsigned char* rec;
+  const PlanHeader* header;
+  int n_ions, B, S, Va, Vb, max_sub;
+  int atab_lds;
+  float ln_eps;
+  unsigned long long* stamps;
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding
@@ -176,6 +249,7 @@ __device__ __forceinline__ bool edge_valid(int s, int t, int bid, int N, int Vb)
 // plan side (encoder_plan.hip)
 int launch_weight_image(const ImageParams& ip, int S, hipStream_t s);
 int launch_plan(const PlanParams& pp, hipStream_t s);
+int launch_typed_image(const TImageParams& ip, hipStream_t s);
 
 }  // namespace enc
 }  // namespace impnn

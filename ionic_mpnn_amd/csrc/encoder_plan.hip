@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64 * kPB) void plan_stats_kernel(PlanParams p) {
     rmax = rmax > res + 1 ? rmax : res + 1;
   }
   {
-    int vr = (cnt + 3) >> 2;
+    int vr = p.typed ? (cnt + 1) >> 1 : (cnt + 3) >> 2;  // edges per virtual row: 4 (pull records) or 2 (typed)
     vr = vr > rmax ? vr : rmax;
     my_vr = vr < 1 ? 1 : vr;
     if (lane == 0) {
@@ -89,6 +89,12 @@ __global__ __launch_bounds__(64 * kPB) void plan_stats_kernel(PlanParams p) {
 #pragma unroll
     for (int i = 0; i < kPB; ++i) t += vsum[i];
     p.partial[(int64_t)g * p.nblk + blk] = t;
+    if (blockIdx.x == 0) {  // what this plan was made for: the encoder refuses a workspace planned differently
+      PlanHeader h;
+      h.magic = kPlanMagic; h.kind = p.typed; h.n_ions = p.n_ions; h.B = p.B; h.N = p.N; h.E = p.E;
+      h.nwg = p.nwg; h.max_sub = p.max_sub;
+      *p.header = h;
+    }
   }
 }
 
@@ -167,6 +173,50 @@ __global__ void weight_image_kernel(ImageParams p) {
   }
 }
 
+
+// -----------------------------------------------------------------------------------------
+// typed_image: step `s` of the typed encoder's prepared buffer.  The canonical per-bond-type matrices
+// A[v] = sum_k bond_table[v,k] W[k] of the step (models/layers.py:108, computed by launch_bond_type_matrices
+// into the buffer's scratch area) are re-laid in the B-operand order of v_mfma_f32_4x4x1 (encoder_layout.h),
+// and the GatedUpdate weights of the step in the transposed / padded layout the update GEMMs read from LDS.
+// -----------------------------------------------------------------------------------------
+__global__ void typed_image_kernel(TImageParams p, int s) {
+  const int t_begin = blockIdx.x * blockDim.x + threadIdx.x, t_stride = gridDim.x * blockDim.x;
+  const int S = p.S > 0 ? p.S : 1;
+  float* upd = p.prepared + (size_t)s * kTUpdSlot;
+  float* tmat = p.prepared + (size_t)S * kTUpdSlot + (size_t)s * p.Vb * kTMatFloats;
+  const float* canon = p.prepared + (size_t)S * kTUpdSlot + (size_t)S * p.Vb * kTMatFloats;
+  const float* w = p.weights + (int64_t)s * p.step_floats;
+  const float* Wz = w + (int64_t)p.K * kD * kD;  // (64,32)
+  const float* bz = Wz + 2 * kD * kD;
+  const float* Wr = bz + kD;
+  const float* br = Wr + 2 * kD * kD;
+  const float* Wh = br + kD;
+  const float* bh = Wh + 2 * kD * kD;
+  const float* gamma = bh + kD;
+  const float* beta = gamma + kD;
+  const int nmat = p.Vb * kTMatFloats;
+  for (int t = t_begin; t < nmat; t += t_stride) {
+    // destination index: v*1024 + kq*128 + r*4 + c   <-  A[v][r][4*kq + c]
+    const int v = t >> 10, rem = t & 1023, kq = rem >> 7, r = (rem >> 2) & 31, c = rem & 3;
+    tmat[t] = canon[(size_t)v * kTMatFloats + r * kD + 4 * kq + c];
+  }
+  constexpr int nupd = 3 * kD * kUpdRS;
+  for (int t = t_begin; t < kTUpdSlot; t += t_stride) {
+    float val = 0.f;
+    if (t < nupd) {
+      const int row = t / kUpdRS, jj = t - row * kUpdRS;  // row = gate*32 + i_out
+      const int gate = row / kD, io = row - gate * kD;
+      const float* Wg = gate == 0 ? Wz : (gate == 1 ? Wr : Wh);
+      val = jj < 2 * kD ? Wg[(int64_t)jj * kD + io] : 0.f;
+    } else if (t < nupd + 5 * kD) {
+      const int v = (t - nupd) / kD, i = (t - nupd) - v * kD;
+      const float* src = v == 0 ? bz : v == 1 ? br : v == 2 ? bh : v == 3 ? gamma : beta;
+      val = src[i];
+    }
+    upd[t] = val;
+  }
+}
 
 // -----------------------------------------------------------------------------------------
 // Share of persistent encoder workgroup j, resolved by ONE WAVE from the 16-molecule partial sums
@@ -292,9 +342,27 @@ constexpr int kDegBins = 18;    // in-degree 0..15, ">= 16", and "row beyond the
 constexpr int kShareCap = kECap;  // molecules of one share resolved in LDS
 constexpr int kMaxHops = 128;     // chunks of one share (launch_plan checks max_sub against it)
 
+// Exclusive prefix sum over the 256 threads of a plan_chunks workgroup (4 waves); `total` gets the sum.
+__device__ __forceinline__ int block_excl_scan(int v, int32_t* wsum /* [4] LDS */, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int incl = wave_incl_scan(v);
+  if (lane == 63) wsum[wave] = incl;
+  lds_barrier();
+  int off = 0;
+  for (int w = 0; w < wave; ++w) off += wsum[w];
+  total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  lds_barrier();  // wsum may be reused right away
+  return off + incl - v;
+}
+
+// TYPED: records of the typed encoder (encoder_layout.h "typed"): rows placed by EXACT descending in-degree, message
+// slots in jagged-diagonal order, edges grouped by bond type.  Dynamic LDS: the group table (16 B x (128 + Vb)).
+template <bool TYPED>
 __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
   __shared__ int32_t moloff[kRCap + 2], molrows[kRCap], cnt[kRCap], place[kRCap], cursor[kRCap], rowptr[kRCap + 2];
-  __shared__ int32_t bins[48], tilemax[16], scratch[8];
+  __shared__ int32_t bins[TYPED ? 2 * kRCap + 2 : 48], tilemax[16], scratch[8];
+  __shared__ int32_t jdp[TYPED ? kRCap + 2 : 1], thist[TYPED ? kTVbMax : 1], tgb[TYPED ? kTVbMax : 1];
+  extern __shared__ uint4 grp[];  // TYPED only
   __shared__ uint16_t atomof[kRCap];  // placed row -> atom id clamped to [0, Va] (Va = the zero row)
   __shared__ uint32_t ent2[kECap + 1];
   __shared__ int32_t shst[kShareCap + 1];  // virtual-row prefix of the share's molecules (+ end)
@@ -388,7 +456,7 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
   const int32_t* conn_g = p.conn[g];
   const int32_t* bond_g = p.bond_ids[g];
   const int32_t* rows_g = p.rows + (int64_t)g * p.B;
-  unsigned char* rec = p.rec + (size_t)idx * kRecBytes;
+  unsigned char* rec = p.rec + (size_t)idx * (TYPED ? kTRecBytes : kRecBytes);
   uint16_t* r_rowptr = reinterpret_cast<uint16_t*>(rec + kRecRowptr);
   unsigned char* r_tilemax = rec + kRecTilemax;
   uint16_t* r_moloff = reinterpret_cast<uint16_t*>(rec + kRecMoloff);
@@ -426,7 +494,13 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
     }
   }
   cnt[tid] = 0;
-  if (tid < 48) bins[tid] = 0;
+  if constexpr (TYPED) {
+    bins[tid] = 0;          // [0, 256): rows per placement bin (bin = 255 - in-degree)
+    bins[kRCap + tid] = 0;  // [256, 512): fill cursors
+    thist[tid] = 0;
+  } else {
+    if (tid < 48) bins[tid] = 0;
+  }
   if (tid < 16) tilemax[tid] = 0;
   lds_barrier();
   CSTAMP(2);
@@ -459,29 +533,62 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
   lds_barrier();
   CSTAMP(3);
 
-  // P2: place rows by descending in-degree (counting sort over 18 bins) so that a tile's lanes walk
+  // P2: place rows by descending in-degree (counting sort) so that a tile's lanes walk
   //     in-edge lists of similar length.  The placement inside a bin comes from an LDS atomic and
   //     may differ run to run - harmless: no result depends on where a row sits (MFMA columns,
   //     the gather and LayerNorm are per row; the pool walks logical rows in order).
   const int my_deg = cnt[tid];
-  const int my_bin = tid >= R ? 0 : (my_deg >= 16 ? 1 : 17 - my_deg);  // bin 0 = beyond chunk (placed last)
-  atomicAdd(&bins[my_bin], 1);
-  lds_barrier();
-  CSTAMP(4);
-  if (wave == 0) {  // exclusive scan in placement order: bins 1..17, then bin 0
-    const int bidx = lane < kDegBins ? (lane == kDegBins - 1 ? 0 : lane + 1) : 0;
-    const int v = lane < kDegBins ? bins[bidx] : 0;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 32; o <<= 1) {
-      int t = __shfl_up(incl, o);
-      if (lane >= o) incl += t;
+  int pos;
+  if constexpr (TYPED) {
+    // exact bins: 255 - in-degree (in-degree <= E <= 255); rows beyond the chunk go last
+    const int dcl = my_deg > 255 ? 255 : my_deg;
+    if (tid < R) atomicAdd(&bins[255 - dcl], 1);
+    lds_barrier();
+    CSTAMP(4);
+    int tot = 0;
+    const int start = block_excl_scan(bins[tid], scratch, tot);  // rows placed before bin `tid` = rows with a larger in-degree
+    cursor[tid] = start;  // (reused below for the placed in-degrees: read back first)
+    lds_barrier();
+    // jagged-diagonal pointers: rows with in-degree > d are exactly the first cursor[255 - d] placed rows
+    const int sd = cursor[255 - tid];  // S_d for d = tid
+    int nedge = 0;
+    const int jd = block_excl_scan(sd, scratch, nedge);
+    jdp[tid] = jd;
+    if (tid == 0) jdp[kRCap] = nedge;
+    const int my_start = tid < R ? cursor[255 - dcl] : 0;
+    lds_barrier();
+    CSTAMP(5);
+    pos = tid < R ? my_start + atomicAdd(&bins[kRCap + 255 - dcl], 1) : 0;
+    // rows beyond the chunk: after the R real rows, in thread order (ballot ranks: no atomics needed)
+    {
+      const unsigned long long beyond = __ballot(tid >= R);
+      if (lane == 0) scratch[4 + wave] = __builtin_popcountll(beyond);
+      lds_barrier();
+      int before = 0;
+      for (int w = 0; w < wave; ++w) before += scratch[4 + w];
+      if (tid >= R) pos = R + before + __builtin_popcountll(beyond & ((1ull << lane) - 1));
     }
-    if (lane < kDegBins) bins[24 + bidx] = incl - v;
+  } else {
+    const int my_bin = tid >= R ? 0 : (my_deg >= 16 ? 1 : 17 - my_deg);  // bin 0 = beyond chunk (placed last)
+    atomicAdd(&bins[my_bin], 1);
+    lds_barrier();
+    CSTAMP(4);
+    if (wave == 0) {  // exclusive scan in placement order: bins 1..17, then bin 0
+      const int bidx = lane < kDegBins ? (lane == kDegBins - 1 ? 0 : lane + 1) : 0;
+      const int v = lane < kDegBins ? bins[bidx] : 0;
+      int incl = v;
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {
+        int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+      }
+      if (lane < kDegBins) bins[24 + bidx] = incl - v;
+    }
+    lds_barrier();
+    CSTAMP(5);
+    pos = bins[24 + my_bin] + atomicAdd(&bins[my_bin], -1) - 1;
   }
-  lds_barrier();
-  CSTAMP(5);
-  const int pos = bins[24 + my_bin] + atomicAdd(&bins[my_bin], -1) - 1;
+  lds_barrier();  // (typed: every thread has read its start before cursor is rewritten)
   place[tid] = pos;
   cursor[pos] = my_deg;  // in-degree per placed row (scanned below)
   if (my_deg > 0) atomicMax(&tilemax[pos >> 4], my_deg > 255 ? 255 : my_deg);
@@ -508,10 +615,17 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
     const int excl = off + incl - my_cnt;
     rowptr[tid] = excl;
     cursor[tid] = excl;
-    r_rowptr[tid] = (uint16_t)excl;
-    if (tid == kRCap - 1) {
-      rowptr[kRCap] = excl + my_cnt;
-      r_rowptr[kRCap] = (uint16_t)(excl + my_cnt);
+    if constexpr (TYPED) {
+      r_rowptr[tid] = (uint16_t)my_cnt;  // kTRecRowdeg: the encoder needs the in-degree, not the CSR offset
+      reinterpret_cast<uint16_t*>(rec + kTRecJdptr)[tid] = (uint16_t)jdp[tid];
+      if (tid == kRCap - 1) rowptr[kRCap] = excl + my_cnt;
+      if (tid < 2) reinterpret_cast<uint16_t*>(rec + kTRecJdptr)[kRCap + tid] = (uint16_t)jdp[kRCap];
+    } else {
+      r_rowptr[tid] = (uint16_t)excl;
+      if (tid == kRCap - 1) {
+        rowptr[kRCap] = excl + my_cnt;
+        r_rowptr[kRCap] = (uint16_t)(excl + my_cnt);
+      }
     }
     if (tid < 16) r_tilemax[tid] = (unsigned char)tilemax[tid];
   }
@@ -526,6 +640,7 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
       const int mo = moloff[sm[k]];
       const int at = atomicAdd(&cursor[place[mo + sst[k].y]], 1);
       ent2[at] = ((uint32_t)se[k] << 16) | ((uint32_t)sbid[k] << 8) | (uint32_t)place[mo + sst[k].x];
+      if constexpr (TYPED) atomicAdd(&thist[sbid[k]], 1);
     }
   for (int slot = tid + kSC * kRCap; slot < n_slots; slot += kRCap) {
     const int m = slot / E, e = slot - m * E;
@@ -536,13 +651,56 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
       const int mo = moloff[m];
       const int at = atomicAdd(&cursor[place[mo + st.y]], 1);
       ent2[at] = ((uint32_t)e << 16) | ((uint32_t)bid << 8) | (uint32_t)place[mo + st.x];
+      if constexpr (TYPED) atomicAdd(&thist[bid], 1);
     }
   }
   lds_barrier();
   CSTAMP(9);
 
   // P5: every row's in-edge list in edge-slot order: entry-parallel rank sort, straight into the record
-  {
+  if constexpr (TYPED) {
+    // groups of <= 4 edges of one bond type: group base per type, zeroed table, headers
+    int ngrp = 0;
+    const int n_t = thist[tid];
+    const int gb = block_excl_scan((n_t + 3) >> 2, scratch, ngrp);
+    tgb[tid] = gb;
+    thist[tid] = 0;  // becomes the fill cursor of the type
+    for (int i = tid; i < ngrp; i += kRCap) grp[i] = make_uint4(0u, 0u, 0u, 0u);
+    lds_barrier();
+    for (int jg = 0; jg * 4 < n_t; ++jg) {
+      const int c = n_t - 4 * jg;
+      grp[gb + jg].x = (uint32_t)tid | ((uint32_t)(c < 4 ? c : 4) << 8);
+    }
+    if (tid == 0) {
+      uint16_t* cw = reinterpret_cast<uint16_t*>(rec + kTRecCounts);
+      int md = 0;
+      for (int t = 0; t < 16; ++t) md = md > tilemax[t] ? md : tilemax[t];
+      cw[0] = (uint16_t)ngrp;
+      cw[1] = (uint16_t)rowptr[kRCap];
+      cw[2] = (uint16_t)md;
+    }
+    const int total = rowptr[kRCap];
+    for (int i = tid; i < total; i += kRCap) {
+      int lo = 0, hi = kRCap - 1;  // largest row with rowptr[row] <= i
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (rowptr[mid] <= i) lo = mid; else hi = mid - 1;
+      }
+      const int b0 = rowptr[lo], b1 = rowptr[lo + 1];
+      const uint32_t v = ent2[i];
+      int rank = 0;
+      for (int jx = b0; jx < b1; ++jx) rank += ent2[jx] < v;
+      const uint32_t srow = v & 0xffu, bid = (v >> 8) & 0xffu;
+      const uint32_t mslot = (uint32_t)(jdp[rank] + lo);  // jagged diagonal: d-th in-edge of placed row lo
+      const int idx = atomicAdd(&thist[bid], 1);
+      unsigned char* ge = reinterpret_cast<unsigned char*>(&grp[tgb[bid] + (idx >> 2)]);
+      ge[4 + (idx & 3)] = (unsigned char)srow;
+      reinterpret_cast<uint16_t*>(ge + 8)[idx & 3] = (uint16_t)mslot;
+    }
+    lds_barrier();
+    uint4* r_grp = reinterpret_cast<uint4*>(rec + kTRecGrp);
+    for (int i = tid; i < ngrp; i += kRCap) r_grp[i] = grp[i];
+  } else {
     const int total = rowptr[kRCap];
     for (int i = tid; i < total; i += kRCap) {
       int lo = 0, hi = kRCap - 1;  // largest row with rowptr[row] <= i
@@ -577,6 +735,20 @@ int launch_weight_image(const ImageParams& ip, int S, hipStream_t s) {
   return check_launch("weight_image");
 }
 
+int launch_typed_image(const TImageParams& ip, hipStream_t s) {
+  const int S = ip.S > 0 ? ip.S : 1;
+  float* canon = ip.prepared + (size_t)S * kTUpdSlot + (size_t)S * ip.Vb * kTMatFloats;
+  for (int st = 0; st < ip.S; ++st) {
+    if (int rc = launch_bond_type_matrices(ip.bond_table, ip.weights + (int64_t)st * ip.step_floats, canon, ip.Vb, ip.K,
+                                           kD, s))
+      return rc;
+    typed_image_kernel<<<(ip.Vb * kTMatFloats + kTUpdSlot + 255) / 256 < 256 ? (ip.Vb * kTMatFloats + kTUpdSlot + 255) / 256 : 256,
+                         256, 0, s>>>(ip, st);
+    if (int rc = check_launch("typed_image")) return rc;
+  }
+  return IMPNN_OK;
+}
+
 int launch_plan(const PlanParams& pp, hipStream_t s) {
   plan_stats_kernel<<<pp.n_ions * pp.nblk, 64 * kPB, 0, s>>>(pp);
   if (int rc = check_launch("plan_stats")) return rc;
@@ -584,7 +756,10 @@ int launch_plan(const PlanParams& pp, hipStream_t s) {
     return fail(IMPNN_E_UNSUPPORTED, "encoder plan: batch of %d molecules per ion is too large", pp.B);
   if (pp.max_sub > kMaxHops)
     return fail(IMPNN_E_UNSUPPORTED, "encoder plan: %d chunk slots per workgroup", pp.max_sub);
-  plan_chunks_kernel<<<pp.nwg * pp.grid_sub, kRCap, 0, s>>>(pp);
+  if (pp.typed)
+    plan_chunks_kernel<true><<<pp.nwg * pp.grid_sub, kRCap, sizeof(uint4) * (kTECap / 4 + pp.Vb), s>>>(pp);
+  else
+    plan_chunks_kernel<false><<<pp.nwg * pp.grid_sub, kRCap, 0, s>>>(pp);
   return check_launch("plan_chunks");
 }
 

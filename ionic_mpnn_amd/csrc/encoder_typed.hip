@@ -1,0 +1,453 @@
+// Fused message-passing encoder, per-bond-type form (mode 2 "f32t"), gfx950 / MI355X: encode() of
+// train_viscosity.py:166-187 and train_melting_point.py:152-171 up to and including GlobalSumPool, both ions in
+// one launch, atom_dim 32, ANY bond_dim (K = 8 of the viscosity model, K = D^2 = 1024 of the melting-point model).
+//
+// Same frame as encoder_fused.hip - persistent 1024-thread workgroups, chunks of <= 256 packed atom rows whose
+// graph structure arrives as a record built by the plan kernels, node state h in LDS for all S steps, GatedUpdate
+// as transposed f32-MFMA GEMMs with atoms on the MFMA N dimension - but the message is computed the way the
+// reference orders it (models/layers.py:108-112): A_e = sum_k bond_state[e,k] W[k], then m_e = A_e h[src_e].
+// bond_state is always an Embedding lookup (train_viscosity.py:172), so A_e is one of Vb matrices
+// A[v] = sum_k bond_table[v,k] W[k], prepared once per weight version (encoder_plan.hip: typed_image).
+//
+//   message phase (all 16 waves): the chunk's valid edges are grouped by bond type in groups of <= 4.  One
+//     v_mfma_f32_4x4x1_16b_f32 has 16 independent 4x4 blocks; block b = (group half << 3) | feature quad computes
+//     D_b[i][j] += h[src of edge i][k] * A[type][4*(b&7) + j][k].  The edge operand is supplied by ONE block per
+//     half-wave and broadcast to the other seven by the instruction's CBSZ/ABID fields (8 lanes read LDS, not 64);
+//     the matrix operand is a lane's row of A[type] (32 floats = 8 x 16 B straight from L2, operand order).
+//     32 instructions (k = 0..31, two accumulator chains) give two groups' messages: exact f32 products, the
+//     reference's summation order over j.  Messages are written to an LDS buffer in jagged-diagonal order.
+//   atom phase (one 16-atom tile per wave): agg[a] = sum of the row's in-edge messages in edge-slot order (the
+//     reference's sequential scatter_nd, models/layers.py:78-82; slot(row, d) = jdptr[d] + row, so a tile's reads
+//     of one d are 16 consecutive slots: conflict-free), then GatedUpdate (models/layers.py:142-156) exactly as in
+//     encoder_fused.hip's f32 mode, h updated in place.
+//
+// MFMA work per row is 12 D^2 (update) + 2 D^2 per in-edge, against (12 + 2 K) D^2 per row in the pull form:
+// 2.7 kflop instead of 28.7 kflop per row for the message at bond_dim 8 and 1.7 in-edges per row.
+#include "encoder_device.h"
+#include "encoder_layout.h"
+
+namespace impnn {
+namespace enc {
+
+namespace {
+
+__device__ __forceinline__ f32x4 mfma1(float a, float b, f32x4 c) {
+  // CBSZ = 3, ABID = 0: blocks 0-7 take A from block 0 (lanes 0-3), blocks 8-15 from block 8 (lanes 32-35)
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 3, 0, 0);
+}
+// A value the compiler treats as defined without emitting an instruction: the A operand of the lanes whose
+// block is not a broadcast source is never read by the hardware.
+__device__ __forceinline__ f32x4 any4() {
+  f32x4 v;
+  asm volatile("" : "=v"(v));
+  return v;
+}
+
+constexpr int kOffUpd = 0;
+constexpr int kOffH = kOffUpd + kTUpdLds;
+constexpr int kOffMsg = kOffH + kRCap * kHS;
+constexpr int kOffRec = kOffMsg + kTMsgFloats;
+constexpr int kOffTab = kOffRec + kTRecBytes / 4;
+constexpr size_t kTLdsFixedBytes = sizeof(float) * (size_t)kOffTab;
+static_assert(kTLdsFixedBytes <= 160 * 1024, "LDS budget");
+static_assert(kTRecBytes == 12 * kThreads, "record prefetch: 8 + 4 bytes per thread");
+
+__global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel(TEncParams p) {
+  extern __shared__ __align__(16) float smem[];
+  float* const wupd = smem + kOffUpd;
+  float* const wvec = wupd + 3 * kD * kUpdRS;
+  float* const hbuf = smem + kOffH;
+  float* const msg = smem + kOffMsg;
+  unsigned char* const recl = reinterpret_cast<unsigned char*>(smem + kOffRec);
+  float* const atab = smem + kOffTab;  // Va rows + one zero row at the h buffer's stride (when it fits)
+  const uint16_t* const r_rowdeg = reinterpret_cast<const uint16_t*>(recl + kTRecRowdeg);
+  const unsigned char* const r_tilemax = recl + kTRecTilemax;
+  const uint16_t* const r_moloff = reinterpret_cast<const uint16_t*>(recl + kTRecMoloff);
+  const uint16_t* const r_molrows = reinterpret_cast<const uint16_t*>(recl + kTRecMolrows);
+  const uint16_t* const r_poolrow = reinterpret_cast<const uint16_t*>(recl + kTRecPoolrow);
+  const int32_t* const r_rowatom = reinterpret_cast<const int32_t*>(recl + kTRecRowatom);
+  const uint16_t* const r_counts = reinterpret_cast<const uint16_t*>(recl + kTRecCounts);
+  const uint16_t* const r_jdptr = reinterpret_cast<const uint16_t*>(recl + kTRecJdptr);
+  const uint4* const r_grp = reinterpret_cast<const uint4*>(recl + kTRecGrp);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int a = lane & 15, q = lane >> 4;
+  unsigned long long* stamp = p.stamps ? p.stamps + (size_t)blockIdx.x * 32 : nullptr;
+  if (stamp && tid == 0) stamp[0] = __builtin_amdgcn_s_memtime();
+
+  // The workspace must hold a typed plan made for this launch geometry (impnn_encoder_plan with the same
+  // arguments): anything else would be read at wrong offsets.  A mismatch poisons the outputs instead.
+  {
+    const PlanHeader hd = *p.header;
+    if (hd.magic != kPlanMagic || hd.kind != 1 || hd.nwg != (int)gridDim.x || hd.max_sub != p.max_sub ||
+        hd.B != p.B || hd.n_ions != p.n_ions) {
+      const float nan = __builtin_nanf("");
+      for (int g = 0; g < p.n_ions; ++g)
+        for (int64_t t = (int64_t)blockIdx.x * kThreads + tid; t < (int64_t)p.B * kD; t += (int64_t)gridDim.x * kThreads)
+          p.pooled[g][t] = nan;
+      return;
+    }
+  }
+  const int c_begin = blockIdx.x * p.max_sub;
+  const int c_end = c_begin + __builtin_amdgcn_readfirstlane(p.nsub[blockIdx.x]);
+  if (c_begin >= c_end) return;
+
+  if (p.atab_lds)
+    for (int t = tid; t < (p.Va + 1) * (kD / 4); t += kThreads) {
+      const int r = t >> 3, c = t & 7;
+      st4(atab + r * kHS + 4 * c, r < p.Va ? ld4(p.atom_table + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+  unsigned long long t_pro = 0, t_steps = 0, t_pool = 0, t_mark = 0, t_msg = 0;
+  if (stamp && tid == 0) t_mark = __builtin_amdgcn_s_memtime();
+
+  // The record of the NEXT chunk travels in three registers per thread while the current chunk runs; the step-0
+  // update image of the next chunk (same ion: a share never mixes ions) is what the last step's prefetch brings in.
+  const unsigned char* rec_c = p.rec + (size_t)c_begin * kTRecBytes;
+  uint2 rec_n8 = reinterpret_cast<const uint2*>(rec_c)[tid];
+  uint32_t rec_n4 = reinterpret_cast<const uint32_t*>(rec_c + 8 * kThreads)[tid];
+  int4 dsc_next = reinterpret_cast<const int4*>(p.desc)[c_begin];
+  bool image_ready = false;
+  for (int c = c_begin; c < c_end; ++c) {
+    // ---- chunk prologue: descriptor, record -> LDS, h0 = atom_table[atom ids] (only without the LDS table)
+    const int4 dsc = dsc_next;
+    const int m0 = __builtin_amdgcn_readfirstlane(dsc.x), M = __builtin_amdgcn_readfirstlane(dsc.y);
+    const int rg = __builtin_amdgcn_readfirstlane(dsc.w);
+    const int R = rg & 0xffff, g = rg >> 16;
+    const int ntiles = (R + 15) >> 4;
+    const float* upd_g = p.upd[g];
+    const float* tmat_g = p.tmat[g];
+    reinterpret_cast<uint2*>(recl)[tid] = rec_n8;
+    reinterpret_cast<uint32_t*>(recl + 8 * kThreads)[tid] = rec_n4;
+    {
+      const int cn = (c + 1) < c_end ? (c + 1) : c;  // clamped: unconditional loads
+      const unsigned char* rn = p.rec + (size_t)cn * kTRecBytes;
+      rec_n8 = reinterpret_cast<const uint2*>(rn)[tid];
+      rec_n4 = reinterpret_cast<const uint32_t*>(rn + 8 * kThreads)[tid];
+      dsc_next = reinterpret_cast<const int4*>(p.desc)[cn];
+    }
+    f32x4 pf0, pf1;
+    const bool need_image = p.S > 0 && !image_ready;  // workgroup-uniform
+    if (need_image) {
+      pf0 = ld4(upd_g + 4 * tid);
+      pf1 = ld4(upd_g + 4 * (tid + kThreads));
+    }
+    lds_barrier();
+    if (!p.atab_lds || p.S == 0) {  // 4 threads per placed row, 2 x 16 B each; slack rows: zeros
+      const int row = tid >> 2, sub = tid & 3;
+      const int id = r_rowatom[row];
+      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+      if ((unsigned)id < (unsigned)p.Va) {
+        if (p.atab_lds) {
+          v0 = ld4(atab + id * kHS + 8 * sub);
+          v1 = ld4(atab + id * kHS + 8 * sub + 4);
+        } else {
+          v0 = ld4(p.atom_table + (int64_t)id * kD + 8 * sub);
+          v1 = ld4(p.atom_table + (int64_t)id * kD + 8 * sub + 4);
+        }
+      }
+      st4(hbuf + row * kHS + 8 * sub, v0);
+      st4(hbuf + row * kHS + 8 * sub + 4, v1);
+    }
+    if (need_image) {
+      st4(wupd + 4 * tid, pf0);
+      if (4 * (tid + kThreads) < kTUpdLds) st4(wupd + 4 * (tid + kThreads), pf1);
+    }
+    image_ready = p.S > 0;
+    lds_barrier();
+    const int ngrp = __builtin_amdgcn_readfirstlane(r_counts[0]);
+    const int nbatch = (ngrp + 1) >> 1;
+    if (stamp && tid == 0) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      t_pro += t - t_mark;
+      t_mark = t;
+    }
+
+    for (int s = 0; s < p.S; ++s) {
+      const bool g0 = p.atab_lds && s == 0;  // step 0 reads h0 = atom_table[id] straight from the LDS table
+      const int sn = (s + 1) < p.S ? (s + 1) : 0;  // the last step fetches the step-0 image for the next chunk
+      const float* nxt = upd_g + (int64_t)sn * kTUpdSlot;
+      const float* tm_s = tmat_g + (size_t)s * p.Vb * kTMatFloats;
+
+      // ---- message phase: m_e = A[type_e] h[src_e] for two groups of <= 4 edges per wave and turn
+      __builtin_amdgcn_s_setprio(2);
+      for (int bt = wave; bt < nbatch; bt += kWaves) {
+        const int gi = 2 * bt + (lane >> 5);
+        uint4 ge = make_uint4(0u, 0u, 0u, 0u);
+        if (gi < ngrp) ge = r_grp[gi];
+        const int type = ge.x & 0xff, cnt = (ge.x >> 8) & 7;
+        const float* bp = tm_s + (size_t)type * kTMatFloats + (lane & 31) * 4;
+        f32x4 bq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bq[i] = ld4(bp + i * 128);
+        f32x4 aq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) aq[i] = any4();
+        if ((lane & 31) < 4) {
+          const int src = (ge.y >> (8 * (lane & 3))) & 0xff;
+          const float* base = hbuf + src * kHS;
+          if (g0) {
+            const int id = r_rowatom[src];
+            base = atab + ((unsigned)id < (unsigned)p.Va ? id : p.Va) * kHS;
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) aq[i] = ld4(base + 4 * i);
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc0 = mfma1(aq[i][0], bq[i][0], acc0);
+          acc1 = mfma1(aq[i][1], bq[i][1], acc1);
+          acc0 = mfma1(aq[i][2], bq[i][2], acc0);
+          acc1 = mfma1(aq[i][3], bq[i][3], acc1);
+        }
+        acc0 += acc1;
+        // lane (block b, j): D_b[i][j] in element i = message of edge i, feature 4*(b & 7) + j = lane & 31
+        const int u = (lane & 31) >> 2, cc = lane & 3;
+        if (cnt > 0) msg[tmsg_off(ge.z & 0xffff, u) + cc] = acc0[0];
+        if (cnt > 1) msg[tmsg_off(ge.z >> 16, u) + cc] = acc0[1];
+        if (cnt > 2) msg[tmsg_off(ge.w & 0xffff, u) + cc] = acc0[2];
+        if (cnt > 3) msg[tmsg_off(ge.w >> 16, u) + cc] = acc0[3];
+      }
+      const bool mstamp = stamp && c == c_begin && s == 1;
+      if (mstamp && lane == 0) stamp[16 + wave] = __builtin_amdgcn_s_memtime();
+      // Mid-step barrier: every message is in LDS and every read of h by the message phase is done (h is updated in
+      // place below); the update image of this step, stored after the previous step's barrier, is in place too.
+      lds_barrier();
+      if (mstamp && tid == 0) stamp[12] = __builtin_amdgcn_s_memtime();
+      if (stamp && tid == 0 && c == c_begin && s == 1) t_msg = __builtin_amdgcn_s_memtime();
+
+      // ---- atom phase: one 16-atom tile per wave.  Tile -> wave map as in encoder_fused.hip: waves w, w+4, w+8,
+      // w+12 share a SIMD; tiles are ordered heavy -> light, the SIMD groups with one tile fewer take the heaviest.
+      int my_tile = -1;
+      {
+        const int grp = wave & 3, slot = wave >> 2, q4 = ntiles >> 2, r4 = ntiles & 3;
+        const int heavy = (4 - r4) * q4;
+        if (grp >= r4) {
+          if (slot < q4) my_tile = slot * (4 - r4) + (grp - r4);
+        } else if (slot <= q4) {
+          my_tile = heavy + slot * r4 + grp;
+        }
+      }
+      const bool has_tile = my_tile >= 0 && my_tile < ntiles;
+      bool pf_issued = false;
+      if (has_tile) {
+        const int tile = my_tile;
+        const int row = tile * 16 + a;
+        // ---- Reduce (models/layers.py:57-83): in-edge messages summed in edge-slot order
+        const int deg = r_rowdeg[row];
+        const int maxdeg = __builtin_amdgcn_readfirstlane(r_tilemax[tile]);
+        f32x4 agg0 = {0.f, 0.f, 0.f, 0.f}, agg1 = agg0;
+        for (int d = 0; d < maxdeg; ++d) {
+          if (d < deg) {
+            const int sl = r_jdptr[d] + row;
+            agg0 += ld4(msg + tmsg_off(sl, q));
+            agg1 += ld4(msg + tmsg_off(sl, 4 + q));
+          }
+        }
+        __builtin_amdgcn_s_setprio(1);
+        int own = row * kHS + (int)(hbuf - smem);
+        if (g0) {
+          const int id = r_rowatom[row];
+          own = ((unsigned)id < (unsigned)p.Va ? id : p.Va) * kHS + (int)(atab - smem);
+        }
+        own += 4 * q;
+        const f32x4 h0 = ld4(smem + own);
+        const f32x4 h1 = ld4(smem + own + 16);
+        // next step's update image starts its flight now
+        pf0 = ld4(nxt + 4 * tid);
+        pf1 = ld4(nxt + 4 * (tid + kThreads));
+        pf_issued = true;
+
+        // ---- gates z, r (models/layers.py:144-147) and candidate (:150-151): out^T = W^T [h | agg]^T
+        f32x4 z0 = ld4(wvec + 0 * kD + 4 * q), z1 = ld4(wvec + 0 * kD + 16 + 4 * q);
+        f32x4 r0 = ld4(wvec + 1 * kD + 4 * q), r1 = ld4(wvec + 1 * kD + 16 + 4 * q);
+        f32x4 t0 = ld4(wvec + 2 * kD + 4 * q), t1 = ld4(wvec + 2 * kD + 16 + 4 * q);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int col = 32 * half + 16 * u + 4 * q;
+            const f32x4 Az0 = ld4(wupd + (0 * kD + a) * kUpdRS + col);
+            const f32x4 Az1 = ld4(wupd + (0 * kD + 16 + a) * kUpdRS + col);
+            const f32x4 Ar0 = ld4(wupd + (1 * kD + a) * kUpdRS + col);
+            const f32x4 Ar1 = ld4(wupd + (1 * kD + 16 + a) * kUpdRS + col);
+            const f32x4 Bv = half == 0 ? (u == 0 ? h0 : h1) : (u == 0 ? agg0 : agg1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              z0 = mfma4(Az0[r], Bv[r], z0);
+              z1 = mfma4(Az1[r], Bv[r], z1);
+              r0 = mfma4(Ar0[r], Bv[r], r0);
+              r1 = mfma4(Ar1[r], Bv[r], r1);
+            }
+          }
+        }
+        z0 = sigmoid4<false>(z0);
+        z1 = sigmoid4<false>(z1);
+        const f32x4 rh0 = sigmoid4<false>(r0) * h0;  // :149
+        const f32x4 rh1 = sigmoid4<false>(r1) * h1;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int col = 32 * half + 16 * u + 4 * q;
+            const f32x4 Ah0 = ld4(wupd + (2 * kD + a) * kUpdRS + col);
+            const f32x4 Ah1 = ld4(wupd + (2 * kD + 16 + a) * kUpdRS + col);
+            const f32x4 Bv = half == 0 ? (u == 0 ? rh0 : rh1) : (u == 0 ? agg0 : agg1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              t0 = mfma4(Ah0[r], Bv[r], t0);
+              t1 = mfma4(Ah1[r], Bv[r], t1);
+            }
+          }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        // ---- blend, LayerNorm, residual  (models/layers.py:153-155); (1-z) h + z t == h + z (t - h)
+        f32x4 n0 = z0 * (tanh4<false>(t0) - h0) + h0;
+        f32x4 n1 = z1 * (tanh4<false>(t1) - h1) + h1;
+        const f32x4 s4 = n0 + n1;
+        float sum = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        const float mean = sum * (1.0f / kD);
+        n0 -= mean;
+        n1 -= mean;
+        const f32x4 q4 = n0 * n0 + n1 * n1;
+        float var = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+        var += __shfl_xor(var, 16);
+        var += __shfl_xor(var, 32);
+        const float inv = __builtin_amdgcn_rsqf(var * (1.0f / kD) + p.ln_eps);
+        const f32x4 gm0 = ld4(wvec + 3 * kD + 4 * q), gm1 = ld4(wvec + 3 * kD + 16 + 4 * q);
+        const f32x4 bt0 = ld4(wvec + 4 * kD + 4 * q), bt1 = ld4(wvec + 4 * kD + 16 + 4 * q);
+        const f32x4 o0 = n0 * (gm0 * inv) + (bt0 + h0);
+        const f32x4 o1 = n1 * (gm1 * inv) + (bt1 + h1);
+        st4(hbuf + row * kHS + 4 * q, o0);
+        st4(hbuf + row * kHS + 16 + 4 * q, o1);
+      }
+      if (!pf_issued) {  // waves without a tile in this chunk still carry their share of the image
+        pf0 = ld4(nxt + 4 * tid);
+        pf1 = ld4(nxt + 4 * (tid + kThreads));
+      }
+      __syncthreads();
+      st4(wupd + 4 * tid, pf0);
+      if (4 * (tid + kThreads) < kTUpdLds) st4(wupd + 4 * (tid + kThreads), pf1);
+      if (stamp && c == c_begin && s < 2 && tid == 0) stamp[14 + s] = __builtin_amdgcn_s_memtime();
+    }
+    if (stamp && tid == 0) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      t_steps += t - t_mark;
+      t_mark = t;
+    }
+
+    // ---- GlobalSumPool (models/layers.py:161-164), as in encoder_fused.hip: eight lanes share one
+    //      (molecule, 4 features), ascending rows, then a fixed 3-step butterfly on the DPP network.
+    float* out_g = p.pooled[g];
+    for (int t0 = 0; t0 < M * 64; t0 += kThreads) {
+      const int t = t0 + tid;
+      const int part = t & 7, f4 = (t >> 3) & 7, m = t >> 6;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (m < M) {
+        const int nr = r_molrows[m], mo = r_moloff[m];
+        for (int n = part; n < nr; n += 8) {
+          const int pr = r_poolrow[mo + n];
+          if (pr & 0x8000) acc += ld4(hbuf + (pr & 0xff) * kHS + 4 * f4);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = acc[i];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+        acc[i] = v;
+      }
+      if (m < M && part == 0) st4(out_g + (int64_t)(m0 + m) * kD + 4 * f4, acc);
+    }
+    lds_barrier();  // the record / h buffers are rewritten by the next chunk's prologue
+    if (stamp && tid == 0) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      t_pool += t - t_mark;
+      t_mark = t;
+    }
+  }
+  if (stamp && tid == 0) {
+    stamp[1] = t_pro;
+    stamp[2] = t_steps;
+    stamp[3] = t_pool;
+    stamp[4] = (unsigned long long)(c_end - c_begin);
+    stamp[5] = t_msg;
+    stamp[7] = __builtin_amdgcn_s_memtime();
+  }
+}
+
+}  // namespace
+}  // namespace enc
+
+bool encoder_typed_supported(int N, int E, int D, int S, int Vb) {
+  using namespace enc;
+  if (D != kD || S < 0) return false;
+  if (N < 1 || N > 0xffff || E < 0 || E > 255) return false;  // in-degrees travel as 8 bits in the plan
+  if (Vb < 1 || Vb > kTVbMax) return false;
+  if (vr_max_of(N, E, true) > kRCap / 2) return false;
+  return true;
+}
+
+size_t encoder_typed_prepared_bytes(int S, int Vb) { return enc::typed_prepared_floats(S, Vb) * sizeof(float); }
+
+int launch_encoder_typed_prepare(const float* weights, const float* bond_table, int K, int S, int Vb, void* prepared,
+                                 hipStream_t s) {
+  if (S <= 0) return IMPNN_OK;
+  enc::TImageParams ip{};
+  ip.weights = weights;
+  ip.bond_table = bond_table;
+  ip.prepared = static_cast<float*>(prepared);
+  ip.K = K;
+  ip.S = S;
+  ip.Vb = Vb;
+  ip.step_floats = impnn_encoder_step_floats(enc::kD, K);
+  return enc::launch_typed_image(ip, s);
+}
+
+int launch_encoder_typed_run(const EncoderArgs& a, const enc::Ws& w, hipStream_t s) {
+  using namespace enc;
+  char* base = static_cast<char*>(a.workspace);
+  TEncParams ep{};
+  const size_t S1 = a.S > 0 ? a.S : 1;
+  for (int g = 0; g < a.n_ions; ++g) {
+    const float* prep;
+    if (a.prepared[g]) {
+      if (!aligned16(a.prepared[g])) return fail(IMPNN_E_BADARG, "encoder_fused: prepared weights must be 16B aligned");
+      prep = static_cast<const float*>(a.prepared[g]);
+    } else {  // canonical weights: build the images into the workspace first
+      float* img = reinterpret_cast<float*>(base + w.img_off) + (size_t)g * typed_prepared_floats(a.S, a.Vb);
+      if (int rc = launch_encoder_typed_prepare(a.weights[g], a.bond_table, a.K, a.S, a.Vb, img, s)) return rc;
+      prep = img;
+    }
+    ep.upd[g] = prep;
+    ep.tmat[g] = prep + S1 * kTUpdSlot;
+    ep.pooled[g] = a.pooled[g];
+  }
+  ep.atom_table = a.atom_table;
+  ep.nsub = reinterpret_cast<const int32_t*>(base + w.nsub_off);
+  ep.desc = reinterpret_cast<const int32_t*>(base + w.desc_off);
+  ep.rec = reinterpret_cast<const unsigned char*>(base + w.rec_off);
+  ep.header = reinterpret_cast<const PlanHeader*>(base);
+  ep.n_ions = a.n_ions; ep.B = a.B; ep.S = a.S; ep.Va = a.Va; ep.Vb = a.Vb; ep.max_sub = w.max_sub;
+  ep.ln_eps = a.ln_eps;
+  ep.stamps = nullptr;
+  {
+    size_t sb = 0;
+    void* sp = debug_stamp_buffer(&sb);
+    if (sp && sb >= (size_t)w.nwg * 32 * sizeof(unsigned long long)) ep.stamps = static_cast<unsigned long long*>(sp);
+  }
+  if (int rc = ensure_lds_limit((const void*)encoder_typed_kernel, 4)) return rc;
+  size_t lds = kTLdsFixedBytes;
+  const size_t atab_bytes = ((size_t)a.Va + 1) * kHS * sizeof(float);
+  ep.atab_lds = lds + atab_bytes <= 160 * 1024;
+  if (ep.atab_lds) lds += atab_bytes;
+  profile_record_start(s);
+  encoder_typed_kernel<<<w.nwg, kThreads, lds, s>>>(ep);
+  profile_record_stop(s);
+  return check_launch("encoder_typed");
+}
+
+}  // namespace impnn

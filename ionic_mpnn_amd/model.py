@@ -75,7 +75,8 @@ class MPNNModel:
         self._packed = None
         self._prepared = {}
         self._split_deg_limit = None
-        self.encoder_mode = "auto"  # "auto" | "f32" | "f16x2"
+        self.encoder_mode = "auto"  # "auto" | "f32t" | "f32" | "f16x2" (ops.encoder_fused)
+        self.encoder_workgroups = 0  # persistent workgroups per encoder launch (0: library default, one per CU)
 
     # ------------------------------------------------------------------ construction
     def _build_all(self):
@@ -225,7 +226,8 @@ class MPNNModel:
     def _prepared_weights(self, mode):
         """Kernel-side weight images (one per ion), built once per weight version and mode."""
         if mode not in self._prepared:
-            self._prepared[mode] = [ops.prepare_encoder_weights(pk, self.atom_dim, self.bond_dim, self.num_steps, mode)
+            self._prepared[mode] = [ops.prepare_encoder_weights(pk, self.bond_emb.embeddings, self.atom_dim,
+                                                                self.bond_dim, self.num_steps, mode)
                                     if pk is not None else None for pk in self._packed_weights()]
         return self._prepared[mode]
 
@@ -249,17 +251,32 @@ class MPNNModel:
             self._packed = packed
         return self._packed
 
-    def resolve_encoder_mode(self, E):
-        """"f16x2" when the static range bound holds for every possible in-degree (<= E edge slots),
-        else the exact "f32" mode."""
-        if self.encoder_mode != "auto":
-            return self.encoder_mode
-        self._packed_weights()
-        return "f16x2" if (self._split_deg_limit is None or E <= self._split_deg_limit) else "f32"
+    def resolve_encoder_mode(self, N, E=None):
+        """The fused encoder mode for (N, E)-shaped ion inputs, or None when no mode covers them.
+        "auto" picks exact-f32 arithmetic only: "f32t" (per-bond-type messages, any bond_dim) first, then "f32"
+        (pull form, bond_dim <= 8).  "f16x2" (split-fp16 products, narrower than f32) is used on request only, and
+        then only while its static range bound holds for every possible in-degree (<= E edge slots); otherwise the
+        request falls back to the exact modes."""
+        if E is None:  # (older call sites passed E alone)
+            N, E = 1, N
+        sup = lambda m: ops.encoder_fused_supported(N, E, self.atom_dim, self.bond_dim, self.num_steps,
+                                                    self.bond_vocab_size, m)
+        want = self.encoder_mode
+        if want == "f16x2":
+            self._packed_weights()
+            if sup("f16x2") and (self._split_deg_limit is None or E <= self._split_deg_limit):
+                return "f16x2"
+            want = "auto"
+        if want in ("f32t", "f32"):
+            return want if sup(want) else None
+        for m in ("f32t", "f32"):
+            if sup(m):
+                return m
+        return None
 
     # ------------------------------------------------------------------ forward
     def fused_supported(self, N, E):
-        return ops.encoder_fused_supported(N, E, self.atom_dim, self.bond_dim, self.num_steps, self.bond_vocab_size)
+        return self.resolve_encoder_mode(N, E) is not None
 
     def _builds_graph(self):
         """True when this call is differentiated: grad mode on and some variable asks for a gradient."""
@@ -311,13 +328,16 @@ class MPNNModel:
             self._pipeline = ops.EncoderPipeline(self.device)
         ions = [(inputs["cat_atom"], inputs["cat_bond"], inputs["cat_connectivity"]),
                 (inputs["an_atom"], inputs["an_bond"], inputs["an_connectivity"])]
+        mode = self.resolve_encoder_mode(inputs["cat_atom"].shape[1], inputs["cat_bond"].shape[1])
+        if mode is None:
+            raise ops.EncoderUnsupported("no fused encoder mode covers this model / batch shape")
         return self._pipeline.plan(ions, self.atom_dim, self.bond_dim, self.num_steps, self.atom_vocab_size,
-                                   self.bond_vocab_size)
+                                   self.bond_vocab_size, mode=mode, workgroups=self.encoder_workgroups)
 
     def encode_pooled(self, inputs, fused=None, trace=None, plan=None):
         """Both ions' GlobalSumPool outputs: the hot path."""
         if plan is not None:
-            mode = self.resolve_encoder_mode(plan.shape[2])
+            mode = plan.mode
             pc, pa = self._pipeline.run(plan, self.atom_emb.embeddings, self.bond_emb.embeddings,
                                         self._prepared_weights(mode), mode=mode)
             if trace is not None:
@@ -329,11 +349,14 @@ class MPNNModel:
             fused = (tuple(ca.shape) == tuple(aa.shape) and tuple(cb.shape) == tuple(ab.shape)
                      and self.fused_supported(ca.shape[1], cb.shape[1]))
         if fused:
-            mode = self.resolve_encoder_mode(cb.shape[1])
+            mode = self.resolve_encoder_mode(ca.shape[1], cb.shape[1])
+            if mode is None:
+                raise ops.EncoderUnsupported("no fused encoder mode covers this model / batch shape")
             prepared = self._prepared_weights(mode) if self.num_steps > 0 else None
             pc, pa = ops.encoder_fused([(ca, cb, cc), (aa, ab, ac)], self.atom_emb.embeddings,
                                        self.bond_emb.embeddings, None if prepared else self._packed_weights(),
-                                       self.num_steps, mode=mode, prepared=prepared)
+                                       self.num_steps, mode=mode, prepared=prepared,
+                                       workgroups=self.encoder_workgroups)
             if trace is not None:
                 trace["cat/pooled"], trace["an/pooled"] = pc, pa
             return pc, pa

@@ -293,29 +293,20 @@ def _workspace(device, nbytes):
     return ws
 
 
-def set_encoder_workgroups(n):
-    """Persistent workgroups per encoder launch (impnn_encoder_set_workgroups; 0 = one per CU) -> previous value.
-    Process-wide; change it only between batches.  Fewer workgroups per launch pay when several batches are in flight
-    on several streams (bench.py: 3 streams x 128 workgroups)."""
-    prev = _lib.load().impnn_encoder_set_workgroups(int(n))
-    if prev < 0:
-        check(prev)
-    return prev
+ENCODER_MODES = {"f32": 0, "f16x2": 1, "f32t": 2}
+FP16_MAX = 65504.0
+SPLIT_SX, SPLIT_SW = 16.0, 256.0  # kSX / kSW of encoder_fused.hip
 
 
-def encoder_fused_supported(N, E, D, K, S, Vb):
+def encoder_fused_supported(N, E, D, K, S, Vb, mode="f32t"):
+    """Does the fused encoder cover this shape in this mode (impnn_encoder_workspace_bytes says so)?"""
     out = C.c_size_t(0)
-    rc = _lib.load().impnn_encoder_workspace_bytes(1, 1, N, E, D, K, S, Vb, C.byref(out))
+    rc = _lib.load().impnn_encoder_workspace_bytes(1, 1, N, E, D, K, S, Vb, ENCODER_MODES[mode], 0, C.byref(out))
     return rc == 0
 
 
 class EncoderUnsupported(RuntimeError):
     pass
-
-
-ENCODER_MODES = {"f32": 0, "f16x2": 1}
-FP16_MAX = 65504.0
-SPLIT_SX, SPLIT_SW = 16.0, 256.0  # kSX / kSW of encoder_fused.hip
 
 
 def split_mode_degree_limit(atom_table, bond_table, steps, D):
@@ -340,33 +331,37 @@ def split_mode_degree_limit(atom_table, bond_table, steps, D):
     return float("inf") if per_deg == 0.0 else 0.999 * FP16_MAX / per_deg
 
 
-def prepare_encoder_weights(packed, D, K, num_steps, mode="f16x2"):
+def prepare_encoder_weights(packed, bond_table, D, K, num_steps, mode="f32t"):
     """Builds the encoder's kernel-side weight image once (impnn_encoder_prepare_weights); pass the
-    result as `prepared` to encoder_fused while the weights stay unchanged."""
-    require_gpu(packed)
-    packed = f32c(packed)
-    S = int(num_steps)
+    result as `prepared` to encoder_fused while the weights stay unchanged.  Mode "f32t" folds the bond
+    embedding table into the image (the per-bond-type matrices), so it must be rebuilt when that table changes."""
+    require_gpu(packed, bond_table)
+    packed, bond_table = f32c(packed), f32c(bond_table)
+    S, Vb = int(num_steps), int(bond_table.shape[0])
     lib = _lib.load()
-    nbytes = int(lib.impnn_encoder_prepared_bytes(S))
-    out = torch.empty(nbytes, dtype=torch.uint8, device=packed.device)
+    nbytes = int(lib.impnn_encoder_prepared_bytes(S, Vb, ENCODER_MODES[mode]))
+    out = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=packed.device)
     with torch.cuda.device(packed.device):
-        rc = lib.impnn_encoder_prepare_weights(ptr(packed), D, K, S, ENCODER_MODES[mode], ptr(out), nbytes,
-                                               stream_ptr())
+        rc = lib.impnn_encoder_prepare_weights(ptr(packed), ptr(bond_table), D, K, S, Vb, ENCODER_MODES[mode],
+                                               ptr(out), nbytes, stream_ptr())
     if rc == _lib.IMPNN_E_UNSUPPORTED:
         raise EncoderUnsupported(lib.impnn_last_error_string().decode())
     check(rc)
     return out
 
 
-def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=LN_EPS, mode="f16x2", prepared=None):
+def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=LN_EPS, mode="f32t", prepared=None,
+                  workgroups=0):
     """encode() up to GlobalSumPool for 1 or 2 ion branches in one launch.
 
     ions: list of (atom_ids (B,N), bond_ids (B,E), conn (B,E,2)); packed_weights: list of packed
     step-weight tensors (pack_step_weights), or None when `prepared` (list of
     prepare_encoder_weights outputs built for the same `mode`) is given.  Returns a list of pooled
     (B,D) tensors.
-    mode: "f32" (exact f32 MFMA) or "f16x2" (split-fp16 MFMA, f32 accumulate; the caller vouches for
+    mode: "f32t" (per-bond-type messages, exact f32 MFMA, any bond_dim), "f32" (pull form, exact f32 MFMA,
+    bond_dim <= 8) or "f16x2" (pull form, split-fp16 MFMA, f32 accumulate; the caller vouches for
     the range condition of include/impnn.h - ionic_mpnn_amd.model does via split_mode_degree_limit).
+    workgroups: persistent workgroups of the launch (0: library default, one per CU).
     """
     n = len(ions)
     if n not in (1, 2):
@@ -388,9 +383,10 @@ def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=L
     Va, D = atom_table.shape
     Vb, K = bond_table.shape
     S = int(num_steps)
+    mode_i, wgs = ENCODER_MODES[mode], int(workgroups)
     lib = _lib.load()
     need = C.c_size_t(0)
-    rc = lib.impnn_encoder_workspace_bytes(n, B, N, E, D, K, S, Vb, C.byref(need))
+    rc = lib.impnn_encoder_workspace_bytes(n, B, N, E, D, K, S, Vb, mode_i, wgs, C.byref(need))
     if rc == _lib.IMPNN_E_UNSUPPORTED:
         raise EncoderUnsupported(lib.impnn_last_error_string().decode())
     check(rc)
@@ -405,19 +401,19 @@ def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=L
               ptr(atom_table), Va, ptr(bond_table), Vb)
     with torch.cuda.device(dev):
         if prepared is not None:
-            if len(prepared) != n or any(int(t.numel()) < int(lib.impnn_encoder_prepared_bytes(S)) for t in prepared):
-                raise ValueError("prepared weight images do not match (n_ions, num_steps)")
-            check(lib.impnn_encoder_fused_prepared(n, *common, mk(prepared), ENCODER_MODES[mode], mk(pooled), B, N, E,
-                                                   D, K, S, float(eps), ptr(ws), ws.numel(), stream_ptr()))
+            if len(prepared) != n or any(int(t.numel()) < int(lib.impnn_encoder_prepared_bytes(S, Vb, mode_i))
+                                         for t in prepared):
+                raise ValueError("prepared weight images do not match (n_ions, num_steps, bond vocabulary, mode)")
+            check(lib.impnn_encoder_fused_prepared(n, *common, mk(prepared), mode_i, mk(pooled), B, N, E,
+                                                   D, K, S, float(eps), wgs, ptr(ws), ws.numel(), stream_ptr()))
         else:
             ws_w = [f32c(w) if w is not None else None for w in packed_weights]
             step_f = encoder_step_floats(D, K)
             for w in ws_w:
                 if S > 0 and (w is None or w.numel() != S * step_f):
                     raise ValueError(f"packed step weights must hold S*{step_f} floats")
-            lib.impnn_encoder_set_mode(ENCODER_MODES[mode])
-            check(lib.impnn_encoder_fused(n, *common, mk(ws_w), mk(pooled), B, N, E, D, K, S, float(eps), ptr(ws),
-                                          ws.numel(), stream_ptr()))
+            check(lib.impnn_encoder_fused(n, *common, mk(ws_w), mode_i, mk(pooled), B, N, E, D, K, S, float(eps), wgs,
+                                          ptr(ws), ws.numel(), stream_ptr()))
     return pooled
 
 
@@ -426,7 +422,7 @@ def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=L
 # ---------------------------------------------------------------------------------------------
 class EncoderPlan:
     """A planned batch: its workspace, the event that marks the plan complete, and the shapes."""
-    __slots__ = ("slot", "ready", "ions", "shape", "n_ions")
+    __slots__ = ("slot", "ready", "ions", "shape", "n_ions", "info", "mode")
 
 
 class EncoderPipeline:
@@ -441,7 +437,8 @@ class EncoderPipeline:
         self.slots = [{"ws": None, "done": None} for _ in range(depth)]
         self.next = 0
 
-    def plan(self, ions, D, K, S, Va, Vb):
+    def plan(self, ions, D, K, S, Va, Vb, mode="f32t", workgroups=0):
+        """mode: the mode the batch will be run in (modes "f32"/"f16x2" share one record kind, "f32t" has its own)."""
         n = len(ions)
         prep = []
         for (a, b, c) in ions:
@@ -451,7 +448,8 @@ class EncoderPipeline:
         E = prep[0][1].shape[1]
         lib = _lib.load()
         need = C.c_size_t(0)
-        rc = lib.impnn_encoder_workspace_bytes(n, B, N, E, D, K, S, Vb, C.byref(need))
+        mode_i, wgs = ENCODER_MODES[mode], int(workgroups)
+        rc = lib.impnn_encoder_workspace_bytes(n, B, N, E, D, K, S, Vb, mode_i, wgs, C.byref(need))
         if rc == _lib.IMPNN_E_UNSUPPORTED:
             raise EncoderUnsupported(lib.impnn_last_error_string().decode())
         check(rc)
@@ -466,9 +464,10 @@ class EncoderPipeline:
         if slot["done"] is not None:
             self.side.wait_event(slot["done"])  # the encoder that last read this workspace
         with torch.cuda.device(self.device), torch.cuda.stream(self.side):
+            info = _lib.PlanInfo()
             check(lib.impnn_encoder_plan(n, mk([p[0] for p in prep]), mk([p[1] for p in prep]), mk([p[2] for p in prep]),
-                                         B, N, E, D, K, S, Va, Vb, ptr(slot["ws"]), slot["ws"].numel(),
-                                         C.c_void_p(self.side.cuda_stream)))
+                                         B, N, E, D, K, S, Va, Vb, mode_i, wgs, ptr(slot["ws"]), slot["ws"].numel(),
+                                         C.c_void_p(self.side.cuda_stream), C.byref(info)))
             ready = torch.cuda.Event()
             ready.record(self.side)
         for trio in prep:
@@ -476,9 +475,11 @@ class EncoderPipeline:
                 t.record_stream(self.side)
         h = EncoderPlan()
         h.slot, h.ready, h.ions, h.shape, h.n_ions = slot, ready, prep, (B, N, E, D, K, S, Vb), n
+        h.info, h.mode = info, mode
         return h
 
-    def run(self, plan, atom_table, bond_table, prepared, mode="f16x2", eps=LN_EPS):
+    def run(self, plan, atom_table, bond_table, prepared, mode=None, eps=LN_EPS):
+        mode = plan.mode if mode is None else mode
         B, N, E, D, K, S, Vb = plan.shape
         n = plan.n_ions
         atom_table, bond_table = f32c(atom_table), f32c(bond_table)
@@ -492,7 +493,7 @@ class EncoderPipeline:
         with torch.cuda.device(self.device):
             check(lib.impnn_encoder_run(n, mk([p[0] for p in plan.ions]), ptr(atom_table), atom_table.shape[0],
                                         ptr(bond_table), Vb, mk(prepared), ENCODER_MODES[mode], mk(pooled), B, N, E, D,
-                                        K, S, float(eps), ptr(ws), ws.numel(), stream_ptr()))
+                                        K, S, float(eps), C.byref(plan.info), ptr(ws), ws.numel(), stream_ptr()))
             done = torch.cuda.Event()
             done.record(cur)
         plan.slot["done"] = done

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_identity():
     lib = _lib.load()
-    assert lib.impnn_abi_version() == 1
+    assert lib.impnn_abi_version() == 2
     assert lib.impnn_target_arch() == b"gfx950"
     assert lib.impnn_encoder_step_floats(32, 8) == 8 * 1024 + 3 * (2048 + 32) + 64
 
@@ -56,12 +56,77 @@ def test_bad_arguments_are_status_codes_not_crashes():
 def test_encoder_shape_coverage_is_reported():
     lib = _lib.load()
     need = C.c_size_t(0)
-    assert lib.impnn_encoder_workspace_bytes(2, 4096, 40, 80, 32, 8, 3, 72, C.byref(need)) == 0
-    assert 0 < need.value < (64 << 20)
-    assert lib.impnn_encoder_workspace_bytes(2, 4096, 40, 80, 128, 8, 3, 72, C.byref(need)) == -2   # D=128
-    assert lib.impnn_encoder_workspace_bytes(2, 4096, 40, 80, 32, 1024, 3, 72, C.byref(need)) == -2  # K=D*D
+    F32, F16X2, TYPED = 0, 1, 2
+    for mode in (F32, F16X2, TYPED):
+        assert lib.impnn_encoder_workspace_bytes(2, 4096, 40, 80, 32, 8, 3, 72, mode, 0, C.byref(need)) == 0
+        assert 0 < need.value < (64 << 20)
+        assert lib.impnn_encoder_workspace_bytes(2, 4096, 40, 80, 128, 8, 3, 72, mode, 0, C.byref(need)) == -2   # D=128
+    # K = D*D (train_melting_point.py:146): the typed mode covers it (BASELINE config 3), the pull form does not
+    assert lib.impnn_encoder_workspace_bytes(2, 8192, 40, 80, 32, 1024, 4, 72, TYPED, 0, C.byref(need)) == 0
+    assert lib.impnn_encoder_workspace_bytes(2, 4096, 40, 80, 32, 1024, 3, 72, F32, 0, C.byref(need)) == -2
     assert b"not covered" in lib.impnn_last_error_string()
-    assert lib.impnn_encoder_workspace_bytes(3, 16, 40, 80, 32, 8, 3, 72, C.byref(need)) == -1
+    assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 300, 32, 8, 3, 72, TYPED, 0, C.byref(need)) == -2   # E > 255
+    assert lib.impnn_encoder_workspace_bytes(3, 16, 40, 80, 32, 8, 3, 72, F32, 0, C.byref(need)) == -1
+    assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 80, 32, 8, 3, 72, 3, 0, C.byref(need)) == -1       # no mode 3
+    assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 80, 32, 8, 3, 72, F32, -1, C.byref(need)) == -1
+    assert lib.impnn_encoder_prepared_bytes(3, 72, TYPED) > lib.impnn_encoder_prepared_bytes(3, 72, F32) > 0
+
+
+def test_encoder_sizing_has_no_hidden_state():
+    """The workgroup count is an argument, not library state: two host threads sizing workspaces with different
+    counts at the same time always get the answer that belongs to their own arguments."""
+    import threading
+    lib = _lib.load()
+
+    def size(wgs, mode=2):
+        need = C.c_size_t(0)
+        assert lib.impnn_encoder_workspace_bytes(2, 4096, 40, 80, 32, 8, 3, 72, mode, wgs, C.byref(need)) == 0
+        return need.value
+
+    want = {w: size(w) for w in (0, 64, 128, 200)}
+    assert len(set(want.values())) >= 3 and want[64] != want[128]
+    errors = []
+
+    def worker(wgs):
+        for _ in range(3000):
+            got = size(wgs)
+            if got != want[wgs]:
+                errors.append((wgs, got))
+                return
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in (64, 128, 200, 0)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    # neither entry exists any more: the mode and the workgroup count travel with every call
+    raw = C.CDLL(str(_lib.lib_path()))
+    assert not hasattr(raw, "impnn_encoder_set_workgroups") and not hasattr(raw, "impnn_encoder_set_mode")
+
+
+def test_plan_info_is_checked_on_the_host():
+    """impnn_encoder_run validates the plan info before anything is enqueued (no device needed: every failing
+    call returns before its first launch; the pointers below are never dereferenced)."""
+    lib = _lib.load()
+    info = _lib.PlanInfo()
+    fake = (C.c_void_p * 2)(0x1000, 0x1000)
+    fp = C.c_void_p(0x1000)
+
+    def run(B=4, N=10, E=20, S=1, Vb=5, mode=2):
+        return lib.impnn_encoder_run(2, fake, fp, 10, fp, Vb, fake, mode, fake, B, N, E, 32, 8, S, 1e-3, C.byref(info),
+                                     fp, 1 << 30, None)
+
+    assert run() == -1 and b"not filled by impnn_encoder_plan" in lib.impnn_last_error_string()
+    # B = 0 plans nothing on the device but still records what it was planned for
+    rc = lib.impnn_encoder_plan(2, fake, fake, fake, 0, 10, 20, 32, 8, 1, 10, 5, 2, 96, fp, 1 << 30, None, C.byref(info))
+    assert rc == 0 and info.v[3] == 0 and info.v[8] == 96 and info.v[1] == 1
+    for kw in ({"B": 4}, {"N": 11}, {"E": 21}, {"S": 2}, {"Vb": 6}, {"mode": 0}):
+        args = {"B": 0}
+        args.update(kw)
+        assert run(**args) == -1, kw
+        assert b"planned for another" in lib.impnn_last_error_string(), kw
+    assert run(B=0) == 0  # matching (empty) batch: accepted
 
 
 def test_cpu_tensors_fail_loudly():

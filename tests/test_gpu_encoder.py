@@ -26,7 +26,7 @@ def make_model(w, Va, Vb, D=32, K=8, fp=32, mix=20, mode="auto"):
     return m
 
 
-MODES = ["f32", "f16x2"]
+MODES = ["f32t", "f32", "f16x2"]
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -57,6 +57,9 @@ def test_fused_encoder_random_shapes(N, E, K, S, B, seed, mode):
                                min_atoms=min(3, N), seed=seed)
     w = weights.init_weights("viscosity", Va, Vb, atom_dim=32, bond_dim=K, num_steps=S, seed=seed + 100, perturb=True)
     m = make_model(w, Va, Vb, K=K, mode=mode)
+    if mode == "f32t" and E > 255:
+        assert not m.fused_supported(N, E)  # typed records carry in-degrees as 8 bits; "auto" takes the pull form
+        m.encoder_mode = "auto"
     assert m.fused_supported(N, E)
     pc, pa = m.encode_pooled(to_dev(inp), fused=True)
     rc = O.encode(w, "cat", inp["cat_atom"], inp["cat_bond"], inp["cat_connectivity"], pooled_only=True)
@@ -235,15 +238,19 @@ def test_pipelined_plan_run_matches_single_call(full):
         assert torch.equal(c, pc) and torch.equal(a, pa)
 
 
-def test_auto_mode_uses_static_range_bound():
-    """auto = f16x2 only when the LayerNorm / in-degree bound keeps every operand inside fp16 range."""
+def test_mode_resolution_exact_by_default_split_only_inside_its_range_bound():
+    """auto = exact f32 arithmetic ("f32t", else "f32"); "f16x2" runs only on request and only while the
+    LayerNorm / in-degree bound keeps every operand inside fp16 range."""
     w = weights.init_weights("viscosity", synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, num_steps=3, seed=1)
     m = make_model(w, synthetic.DEFAULT_VA, synthetic.DEFAULT_VB)
-    assert m.resolve_encoder_mode(80) == "f16x2" and m._split_deg_limit > 80
+    assert m.resolve_encoder_mode(40, 80) == "f32t"
+    assert m.resolve_encoder_mode(40, 300) == "f32"      # E > 255: outside the typed records, pull form covers it
+    m.encoder_mode = "f16x2"
+    assert m.resolve_encoder_mode(40, 80) == "f16x2" and m._split_deg_limit > 80
     big = dict(w)
     big["bond_embedding"] = w["bond_embedding"] * 400.0        # |G| bound explodes -> exact mode
     m.load_weights(big)
-    assert m.resolve_encoder_mode(80) == "f32"
+    assert m.resolve_encoder_mode(40, 80) == "f32t"
     inp = synthetic.make_batch(16, seed=3)
     ref = O.encode(big, "cat", inp["cat_atom"], inp["cat_bond"], inp["cat_connectivity"], pooled_only=True)
     pc, _ = m.encode_pooled(to_dev(inp), fused=True)
@@ -251,7 +258,43 @@ def test_auto_mode_uses_static_range_bound():
     huge = dict(w)
     huge["cat_bmm_0/bond_transform"] = w["cat_bmm_0/bond_transform"] * 1.0e4   # |W|*256 > fp16 max
     m.load_weights(huge)
-    assert m._packed_weights() is not None and m._split_deg_limit == 0.0 and m.resolve_encoder_mode(1) == "f32"
+    assert m._packed_weights() is not None and m._split_deg_limit == 0.0 and m.resolve_encoder_mode(40, 1) == "f32t"
+
+
+def test_plan_and_run_must_agree_on_geometry():
+    """impnn_encoder_run refuses a workspace planned for another shape / record kind (host check through the plan
+    info), and an encoder kernel that finds a foreign plan header poisons its outputs instead of reading records at
+    wrong offsets (device check)."""
+    import ctypes as C
+    from ionic_mpnn_amd import _lib
+    Va, Vb = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB
+    w = weights.init_weights("viscosity", Va, Vb, num_steps=2, seed=4)
+    m = make_model(w, Va, Vb)
+    d = to_dev(synthetic.make_batch(300, seed=5))
+    ref = m.encode_pooled(d, fused=True)
+    m.encoder_workgroups = 64
+    plan = m.plan_batch(d)
+    assert plan.info.v[8] == 64
+    m.encoder_workgroups = 128                      # changing the knob after planning must not matter:
+    pc, pa = m.encode_pooled(d, plan=plan)          # the run takes its geometry from the plan
+    assert torch.equal(pc, ref[0]) and torch.equal(pa, ref[1])
+    plan2 = m.plan_batch(d)
+    plan2.mode = "f32"                              # typed records, pull-form kernel: refused on the host
+    with pytest.raises(_lib.ImpnnError, match="planned for another"):
+        m.encode_pooled(d, plan=plan2)
+    plan3 = m.plan_batch(d)
+    plan3.shape = (299,) + plan3.shape[1:]          # another batch size
+    with pytest.raises(_lib.ImpnnError, match="planned for another"):
+        m._pipeline.run(plan3, m.atom_emb.embeddings, m.bond_emb.embeddings, m._prepared_weights("f32t"))
+    # device-side check: forge the host info so that the run uses another workgroup count than the plan on the device
+    plan4 = m.plan_batch(d)
+    torch.cuda.synchronize()
+    plan4.info.v[8] = 96
+    need = C.c_size_t(0)
+    _lib.load().impnn_encoder_workspace_bytes(2, 300, 40, 80, 32, 8, 2, Vb, 2, 96, C.byref(need))
+    if plan4.slot["ws"].numel() >= need.value:
+        pc, pa = m._pipeline.run(plan4, m.atom_emb.embeddings, m.bond_emb.embeddings, m._prepared_weights("f32t"))
+        assert torch.isnan(pc).all() and torch.isnan(pa).all()
 
 
 @pytest.mark.parametrize("name", ["config2_perturbed_b6", "tiny_melting_point", "tiny_viscosity"])
@@ -379,14 +422,11 @@ def test_batches_in_flight_on_two_streams_do_not_share_a_workspace():
     assert len({k for k in ops._workspaces if k[1] in (lanes[0].cuda_stream, lanes[1].cuda_stream)}) == 2
     # fewer persistent workgroups per launch (what bench.py uses with three streams): same results bit for bit
     for wgs in (128, 48, 1000):
-        prev = ops.set_encoder_workgroups(wgs)
-        try:
-            for i in (0, 1):
-                pc, pa = m.encode_pooled(batches[i], fused=True)
-                assert torch.equal(pc, ref[i][0]) and torch.equal(pa, ref[i][1])
-        finally:
-            ops.set_encoder_workgroups(prev)
-    assert ops.set_encoder_workgroups(0) == 0
+        m.encoder_workgroups = wgs
+        for i in (0, 1):
+            pc, pa = m.encode_pooled(batches[i], fused=True)
+            assert torch.equal(pc, ref[i][0]) and torch.equal(pa, ref[i][1])
+    m.encoder_workgroups = 0
 
 
 @pytest.mark.parametrize("fused", [True, False])
