@@ -64,12 +64,12 @@ static_assert(kRecEnt + 4 * kECap <= kRecBytes && kRecEnt % 16 == 0, "record lay
 // ---- "typed" encoder (mode 2, encoder_typed.hip): the message is m_e = A[bond type of e] * h[src_e] with the
 // per-bond-type matrices A[v] = sum_k bond_table[v,k] W[k] (models/layers.py:108 evaluated once per type), so
 // bond_dim drops out of the kernel (K = D^2 of train_melting_point.py:146 included).  Edges of a chunk are grouped
-// by type in groups of <= 4 (one v_mfma_f32_4x4x1 block column each), messages land in an LDS buffer in
+// by type in groups of <= 4 (the 4 rows of a v_mfma_f32_4x4x1 block), messages land in an LDS buffer in
 // "jagged diagonal" order - slot(row, d) = jdptr[d] + row for the d-th in-edge (edge-slot order) of placed row
 // `row`; rows are placed by descending in-degree, so the rows that have a d-th in-edge are a prefix - and every
 // atom row then sums its in-edges in edge-slot order (the reference's sequential scatter_nd, models/layers.py:78-82).
 constexpr int kTECap = 512;          // valid edges per chunk (2 per virtual row)
-constexpr int kTGrpCap = 512;        // <= kTECap/4 + (Vb - 1) groups
+constexpr int kTGrpCap = 512;        // >= kTECap/4 + kTVbMax groups
 constexpr int kTVbMax = 256;         // bond ids travel as 8 bits
 constexpr int kTRecRowdeg = 0;       // u16[kRCap]    : in-degree of the PLACED row
 constexpr int kTRecTilemax = 528;    // u8[16]
@@ -79,20 +79,28 @@ constexpr int kTRecPoolrow = 1584;   // u16[kRCap]
 constexpr int kTRecRowatom = 2096;   // i32[kRCap]
 constexpr int kTRecCounts = 3120;    // u16 groups, u16 edges, u16 max in-degree
 constexpr int kTRecJdptr = 3136;     // u16[258]      : first message slot of in-edge index d
-constexpr int kTRecGrp = 3664;       // uint4[kTGrpCap]: type | cnt << 8, 4 x u8 placed source row, 4 x u16 message slot
+constexpr int kTRecWstart = 3664;    // u16[17]       : first group of every wave, + end (whole bond types per wave)
+constexpr int kTRecGrp = 3712;       // uint4[kTGrpCap]: x = type | edges << 8 | groups of the type from here on << 24,
+                                     //   y = 4 x u8 placed source row, z/w = 4 x u16 message key (tmsg_key of the edge's
+                                     //   slot; the dump slot for unused lanes); in type order
 constexpr int kTRecBytes = 12288;
 static_assert(kTRecGrp % 16 == 0 && kTRecGrp + 16 * kTGrpCap <= kTRecBytes, "typed record layout");
-constexpr int kTMsgFloats = kTECap * kD;  // message buffer, 128 B per slot, 16-byte units XOR-swizzled by slot
+constexpr int kTMsgFloats = (kTECap + 1) * kD;  // message buffer, 128 B per slot, 16-byte units XOR-swizzled by slot;
+                                                // slot kTECap is a dump for the unused edge lanes of a group
 // 16-byte unit u (0..7) of message slot s -> float offset.  16 consecutive slots x one unit cover all 16 bank quads
 // (the pull of a tile is conflict-free), and the 8 units of a slot stay a permutation of its 32 banks.
 __host__ __device__ constexpr int tmsg_off(int s, int u) { return s * kD + ((u ^ ((s >> 1) & 7)) << 2); }
+// the same as one XOR per lane: float offset of feature f (0..31) of slot s = tmsg_key(s) ^ f
+__host__ __device__ constexpr int tmsg_key(int s) { return s * kD + (((s >> 1) & 7) << 2); }
+static_assert(tmsg_key(kTECap) < 65536, "message keys travel as 16 bits");
 // per-step update image: gate kernels transposed (3 x 32 rows of kUpdRS) + 5 vectors, in a slot of 2 loads per thread
 constexpr int kTUpdFloats = 3 * kD * kUpdRS + 5 * kD;  // 6688
 constexpr int kTUpdSlot = 2 * kThreads * 4;             // 8192 floats
 constexpr int kTUpdLds = 6912;                          // floats kept in LDS (>= kTUpdFloats, multiple of 128)
 static_assert(kTUpdFloats <= kTUpdLds && kTUpdLds <= kTUpdSlot, "typed update image");
 // type matrices of one (ion, step): Vb x 1024 floats, each in 4x4x1-MFMA B-operand order:
-//   A[v][r][k] at v*1024 + (k >> 2)*128 + r*4 + (k & 3)   (lane r & 31 loads 8 x 16 B, one per k-quad)
+//   A[v][r][k] at v*1024 + (k >> 2)*128 + r*4 + (k & 3)   (lane l loads the 4 k-quads 4*(l >> 5) + i of row l & 31:
+//   a wave's load i is two contiguous 512 B runs)
 constexpr int kTMatFloats = kD * kD;
 // prepared buffer of one ion: S update slots | S x Vb type matrices | one canonical (Vb,32,32) scratch
 inline size_t typed_prepared_floats(int S, int Vb) {

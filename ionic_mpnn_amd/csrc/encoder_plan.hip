@@ -659,17 +659,40 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
 
   // P5: every row's in-edge list in edge-slot order: entry-parallel rank sort, straight into the record
   if constexpr (TYPED) {
-    // groups of <= 4 edges of one bond type: group base per type, zeroed table, headers
-    int ngrp = 0;
+    // Groups of <= 4 edges of one bond type, in type order: entry x = type | edges << 8 | groups of this type from
+    // this one on << 24.  All groups of a type go to ONE wave (which fetches the type's matrix once per chunk-step:
+    // the message phase is bound by the L2 -> CU fill rate): wave w takes the types whose group-range midpoint
+    // falls into its 1/16 of the groups.
     const int n_t = thist[tid];
-    const int gb = block_excl_scan((n_t + 3) >> 2, scratch, ngrp);
+    const int ng = (n_t + 3) >> 2;  // <= 128
+    int ngrp = 0;
+    const int gb = block_excl_scan(ng, scratch, ngrp);
     tgb[tid] = gb;
     thist[tid] = 0;  // becomes the fill cursor of the type
-    for (int i = tid; i < ngrp; i += kRCap) grp[i] = make_uint4(0u, 0u, 0u, 0u);
+    int* const wof = cnt;  // (free since P2) wave of every type that has groups, -1 otherwise
+    wof[tid] = -1;
+    {
+      const uint32_t dump = (uint32_t)tmsg_key(kTECap) * 0x10001u;  // unused edge lanes write to the dump slot
+      for (int i = tid; i < ngrp; i += kRCap) grp[i] = make_uint4(0u, 0u, dump, dump);
+    }
     lds_barrier();
-    for (int jg = 0; jg * 4 < n_t; ++jg) {
-      const int c = n_t - 4 * jg;
-      grp[gb + jg].x = (uint32_t)tid | ((uint32_t)(c < 4 ? c : 4) << 8);
+    if (ng > 0) {
+      for (int jg = 0; jg < ng; ++jg) {
+        const int c = n_t - 4 * jg;
+        grp[gb + jg].x = (uint32_t)tid | ((uint32_t)(c < 4 ? c : 4) << 8) | ((uint32_t)(ng - jg) << 24);
+      }
+      const int wv = (16 * (2 * gb + ng)) / (2 * ngrp);
+      wof[tid] = wv > 15 ? 15 : wv;
+    }
+    lds_barrier();
+    if (tid <= 16) {  // wstart[w] = first group of the first type given to a wave >= w (types are in group order)
+      int first = ngrp;
+      for (int t = 0; t < p.Vb; ++t)
+        if (wof[t] >= tid) {
+          first = tgb[t];
+          break;
+        }
+      reinterpret_cast<uint16_t*>(rec + kTRecWstart)[tid] = (uint16_t)(tid == 16 ? ngrp : first);
     }
     if (tid == 0) {
       uint16_t* cw = reinterpret_cast<uint16_t*>(rec + kTRecCounts);
@@ -695,7 +718,7 @@ __global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
       const int idx = atomicAdd(&thist[bid], 1);
       unsigned char* ge = reinterpret_cast<unsigned char*>(&grp[tgb[bid] + (idx >> 2)]);
       ge[4 + (idx & 3)] = (unsigned char)srow;
-      reinterpret_cast<uint16_t*>(ge + 8)[idx & 3] = (uint16_t)mslot;
+      reinterpret_cast<uint16_t*>(ge + 8)[idx & 3] = (uint16_t)tmsg_key((int)mslot);
     }
     lds_barrier();
     uint4* r_grp = reinterpret_cast<uint4*>(rec + kTRecGrp);

@@ -9,13 +9,10 @@
 // bond_state is always an Embedding lookup (train_viscosity.py:172), so A_e is one of Vb matrices
 // A[v] = sum_k bond_table[v,k] W[k], prepared once per weight version (encoder_plan.hip: typed_image).
 //
-//   message phase (all 16 waves): the chunk's valid edges are grouped by bond type in groups of <= 4.  One
-//     v_mfma_f32_4x4x1_16b_f32 has 16 independent 4x4 blocks; block b = (group half << 3) | feature quad computes
-//     D_b[i][j] += h[src of edge i][k] * A[type][4*(b&7) + j][k].  The edge operand is supplied by ONE block per
-//     half-wave and broadcast to the other seven by the instruction's CBSZ/ABID fields (8 lanes read LDS, not 64);
-//     the matrix operand is a lane's row of A[type] (32 floats = 8 x 16 B straight from L2, operand order).
-//     32 instructions (k = 0..31, two accumulator chains) give two groups' messages: exact f32 products, the
-//     reference's summation order over j.  Messages are written to an LDS buffer in jagged-diagonal order.
+//   message phase (all 16 waves): the chunk's valid edges are grouped by bond type in groups of <= 4; a group is
+//     16 x v_mfma_f32_4x4x1_16b_f32 (16 independent 4x4 blocks: 8 feature quads x 2 halves of k), exact f32
+//     products, the edge operand broadcast inside the instruction (CBSZ/ABID), the matrix operand straight from L2
+//     once per type and chunk-step.  Messages are written to an LDS buffer in jagged-diagonal order.
 //   atom phase (one 16-atom tile per wave): agg[a] = sum of the row's in-edge messages in edge-slot order (the
 //     reference's sequential scatter_nd, models/layers.py:78-82; slot(row, d) = jdptr[d] + row, so a tile's reads
 //     of one d are 16 consecutive slots: conflict-free), then GatedUpdate (models/layers.py:142-156) exactly as in
@@ -52,6 +49,7 @@ constexpr size_t kTLdsFixedBytes = sizeof(float) * (size_t)kOffTab;
 static_assert(kTLdsFixedBytes <= 160 * 1024, "LDS budget");
 static_assert(kTRecBytes == 12 * kThreads, "record prefetch: 8 + 4 bytes per thread");
 
+template <bool STAMPS>
 __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel(TEncParams p) {
   extern __shared__ __align__(16) float smem[];
   float* const wupd = smem + kOffUpd;
@@ -68,11 +66,13 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
   const int32_t* const r_rowatom = reinterpret_cast<const int32_t*>(recl + kTRecRowatom);
   const uint16_t* const r_counts = reinterpret_cast<const uint16_t*>(recl + kTRecCounts);
   const uint16_t* const r_jdptr = reinterpret_cast<const uint16_t*>(recl + kTRecJdptr);
+  const uint16_t* const r_wstart = reinterpret_cast<const uint16_t*>(recl + kTRecWstart);
   const uint4* const r_grp = reinterpret_cast<const uint4*>(recl + kTRecGrp);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int a = lane & 15, q = lane >> 4;
-  unsigned long long* stamp = p.stamps ? p.stamps + (size_t)blockIdx.x * 32 : nullptr;
+  // diagnostics build only (impnn_debug_set_stamp_buffer): the stamp bookkeeping costs ~10 VGPRs
+  unsigned long long* stamp = STAMPS && p.stamps ? p.stamps + (size_t)blockIdx.x * 32 : nullptr;
   if (stamp && tid == 0) stamp[0] = __builtin_amdgcn_s_memtime();
 
   // The workspace must hold a typed plan made for this launch geometry (impnn_encoder_plan with the same
@@ -154,8 +154,6 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
     }
     image_ready = p.S > 0;
     lds_barrier();
-    const int ngrp = __builtin_amdgcn_readfirstlane(r_counts[0]);
-    const int nbatch = (ngrp + 1) >> 1;
     if (stamp && tid == 0) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
       t_pro += t - t_mark;
@@ -168,45 +166,92 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
       const float* nxt = upd_g + (int64_t)sn * kTUpdSlot;
       const float* tm_s = tmat_g + (size_t)s * p.Vb * kTMatFloats;
 
-      // ---- message phase: m_e = A[type_e] h[src_e] for two groups of <= 4 edges per wave and turn
+      // ---- message phase: m_e = A[type_e] h[src_e], one group of <= 4 edges of one bond type per 16 MFMAs.
+      // v_mfma_f32_4x4x1_16b: 16 independent 4x4 blocks.  Block b < 8 accumulates, for feature quad b, the k < 16
+      // half of the dot products of the group's 4 edges; block 8 + b the k >= 16 half:
+      //     D_b[i][j] += h[src_i][k] * A[type][4*(b & 7) + j][k],   k = 16*(b >> 3) + step.
+      // The edge operand h[src_i][k] comes from ONE block per half-wave (lanes 0-3 / 32-35) and is broadcast to the
+      // other seven by CBSZ/ABID: 8 lanes read LDS, not 64.  The matrix operand of lane l is half a row of A[type]
+      // (16 floats = 4 x 16 B, straight from L2).  All groups of a type run on one wave, so a type's 4 KB are
+      // fetched once per chunk-step, and the next type's matrix is in flight while the current one is used
+      // (two register sets, the type loop unrolled by two so that neither is ever copied).  The two k-halves meet in
+      // one v_permlane32_swap per edge pair; the sums go to the LDS message buffer in jagged-diagonal order.
+      // The f32 MFMA shares its issue port with the VALU (tools/ubench: no co-execution), so every VALU instruction in
+      // this loop costs matrix time: the plan hands over ready-made LDS keys (message slot incl. swizzle; unused edge
+      // lanes point at a dump slot, so the stores are unconditional) and the loop body is branch-free.
       __builtin_amdgcn_s_setprio(2);
-      for (int bt = wave; bt < nbatch; bt += kWaves) {
-        const int gi = 2 * bt + (lane >> 5);
-        uint4 ge = make_uint4(0u, 0u, 0u, 0u);
-        if (gi < ngrp) ge = r_grp[gi];
-        const int type = ge.x & 0xff, cnt = (ge.x >> 8) & 7;
-        const float* bp = tm_s + (size_t)type * kTMatFloats + (lane & 31) * 4;
-        f32x4 bq[8];
+      {
+        const uint32_t* const grp_x = reinterpret_cast<const uint32_t*>(r_grp);
+        const int g_hi = __builtin_amdgcn_readfirstlane(r_wstart[wave + 1]);
+        int gi = __builtin_amdgcn_readfirstlane(r_wstart[wave]);
+        const int kh = lane >> 5, f = lane & 31;
+        const bool feeds = f < 4;
+        const int boff = kh * 512 + f * 4;
+        const int aoff = (g0 ? (int)(atab - smem) : (int)(hbuf - smem)) + 16 * kh;
+        const int ysh = 8 * (lane & 3), zsh = 16 * kh;
+        auto run_type = [&](int g, int n, const f32x4 (&bq)[4]) {
+          for (int e = g; e < g + n; ++e) {
+            const uint4 ge = r_grp[e];
+            f32x4 aq[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) bq[i] = ld4(bp + i * 128);
-        f32x4 aq[8];
+            for (int i = 0; i < 4; ++i) aq[i] = any4();
+            if (feeds) {
+              int src = __builtin_amdgcn_ubfe(ge.y, ysh, 8);
+              if (g0) {
+                const int id = r_rowatom[src];
+                src = (unsigned)id < (unsigned)p.Va ? id : p.Va;
+              }
+              const float* base = smem + src * kHS + aoff;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) aq[i] = any4();
-        if ((lane & 31) < 4) {
-          const int src = (ge.y >> (8 * (lane & 3))) & 0xff;
-          const float* base = hbuf + src * kHS;
-          if (g0) {
-            const int id = r_rowatom[src];
-            base = atab + ((unsigned)id < (unsigned)p.Va ? id : p.Va) * kHS;
+              for (int i = 0; i < 4; ++i) aq[i] = ld4(base + 4 * i);
+            }
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              acc0 = mfma1(aq[i][0], bq[i][0], acc0);
+              acc1 = mfma1(aq[i][1], bq[i][1], acc1);
+              acc0 = mfma1(aq[i][2], bq[i][2], acc0);
+              acc1 = mfma1(aq[i][3], bq[i][3], acc1);
+            }
+            acc0 += acc1;
+            // element i of lane l: edge i, feature l & 31, k-half l >> 5.
+            // v_permlane32_swap x, y: lanes 32-63 of x <-> lanes 0-31 of y.  Afterwards x = {x.lo, y.lo},
+            // y = {x.hi, y.hi}, so x + y is edge 0 (2) complete in lanes 0-31 and edge 1 (3) in lanes 32-63.
+            // (Inline asm: the compiler's builtin for this gfx950 instruction folded its two operands into one here.
+            //  The s_nop covers the VALU-write -> permlane-read wait states the assembler does not insert.)
+            float x0 = acc0[0], x1 = acc0[1], x2 = acc0[2], x3 = acc0[3];
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+            msg[__builtin_amdgcn_ubfe(ge.z, zsh, 16) ^ f] = x0 + x1;
+            msg[__builtin_amdgcn_ubfe(ge.w, zsh, 16) ^ f] = x2 + x3;
           }
+        };
+        // The next type's matrix rows are requested before the current type's groups multiply (two register sets,
+        // the run loop unrolled by two so that neither is ever copied).  Measured dead ends, for the record: deeper
+        // rings (3-4 sets) spill; forcing every group to one L1-resident matrix gains only 4 % (the phase is not
+        // bound by the L2 fill rate); hand-placed s_waitcnt around inline-asm loads is not safe against the
+        // compiler's register copies.
+        auto fetch = [&](int g, f32x4 (&bq)[4]) {
+          const int type = __builtin_amdgcn_readfirstlane(grp_x[4 * g]) & 0xff;
+          const float* bp = tm_s + (size_t)type * kTMatFloats + boff;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) aq[i] = ld4(base + 4 * i);
+          for (int i = 0; i < 4; ++i) bq[i] = ld4(bp + i * 128);
+        };
+        f32x4 bP[4], bQ[4];
+        if (gi < g_hi) fetch(gi, bP);
+        while (gi < g_hi) {
+          int n = __builtin_amdgcn_readfirstlane(grp_x[4 * gi]) >> 24;  // groups of this type (all inside this wave's range)
+          int nxt = gi + n;
+          if (nxt < g_hi) fetch(nxt, bQ);
+          run_type(gi, n, bP);
+          gi = nxt;
+          if (gi >= g_hi) break;
+          n = __builtin_amdgcn_readfirstlane(grp_x[4 * gi]) >> 24;
+          nxt = gi + n;
+          if (nxt < g_hi) fetch(nxt, bP);
+          run_type(gi, n, bQ);
+          gi = nxt;
         }
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          acc0 = mfma1(aq[i][0], bq[i][0], acc0);
-          acc1 = mfma1(aq[i][1], bq[i][1], acc1);
-          acc0 = mfma1(aq[i][2], bq[i][2], acc0);
-          acc1 = mfma1(aq[i][3], bq[i][3], acc1);
-        }
-        acc0 += acc1;
-        // lane (block b, j): D_b[i][j] in element i = message of edge i, feature 4*(b & 7) + j = lane & 31
-        const int u = (lane & 31) >> 2, cc = lane & 3;
-        if (cnt > 0) msg[tmsg_off(ge.z & 0xffff, u) + cc] = acc0[0];
-        if (cnt > 1) msg[tmsg_off(ge.z >> 16, u) + cc] = acc0[1];
-        if (cnt > 2) msg[tmsg_off(ge.w & 0xffff, u) + cc] = acc0[2];
-        if (cnt > 3) msg[tmsg_off(ge.w >> 16, u) + cc] = acc0[3];
       }
       const bool mstamp = stamp && c == c_begin && s == 1;
       if (mstamp && lane == 0) stamp[16 + wave] = __builtin_amdgcn_s_memtime();
@@ -439,13 +484,14 @@ int launch_encoder_typed_run(const EncoderArgs& a, const enc::Ws& w, hipStream_t
     void* sp = debug_stamp_buffer(&sb);
     if (sp && sb >= (size_t)w.nwg * 32 * sizeof(unsigned long long)) ep.stamps = static_cast<unsigned long long*>(sp);
   }
-  if (int rc = ensure_lds_limit((const void*)encoder_typed_kernel, 4)) return rc;
+  void (*kern)(TEncParams) = ep.stamps ? encoder_typed_kernel<true> : encoder_typed_kernel<false>;
+  if (int rc = ensure_lds_limit((const void*)kern, ep.stamps ? 5 : 4)) return rc;
   size_t lds = kTLdsFixedBytes;
   const size_t atab_bytes = ((size_t)a.Va + 1) * kHS * sizeof(float);
   ep.atab_lds = lds + atab_bytes <= 160 * 1024;
   if (ep.atab_lds) lds += atab_bytes;
   profile_record_start(s);
-  encoder_typed_kernel<<<w.nwg, kThreads, lds, s>>>(ep);
+  kern<<<w.nwg, kThreads, lds, s>>>(ep);
   profile_record_stop(s);
   return check_launch("encoder_typed");
 }

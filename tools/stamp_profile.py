@@ -16,6 +16,7 @@ from ionic_mpnn_amd import _lib, model, synthetic, weights
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--mp-steps", type=int, default=3)
+ap.add_argument("--mode", default="auto")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 B, S = args.batch, args.mp_steps
@@ -23,6 +24,9 @@ inp = synthetic.make_batch(B, seed=0)
 w = weights.init_weights("viscosity", synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, num_steps=S, seed=1)
 m = model.build_model(synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, num_steps=S, device=dev)
 m.load_weights(w)
+m.encoder_mode = args.mode
+mode = m.resolve_encoder_mode(40, 80)
+print('encoder mode:', mode)
 d = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
 for _ in range(3):
     m.encode_pooled(d, fused=True)
@@ -47,6 +51,20 @@ print(f"persistent workgroups with work: {live.sum()} of {nwg}; chunks per workg
 print(f"cycles per workgroup: total mean {tot.mean():.0f} max {tot.max()} min {tot.min()} | prologues {pro.mean():.0f} "
       f"steps {steps.mean():.0f} pools {pool.mean():.0f}")
 print(f"per chunk: prologue {(pro / nch).mean():.0f}  steps {(steps / nch).mean():.0f}  pool {(pool / nch).mean():.0f}")
+
+if mode == "f32t":
+    # typed encoder: stamp 14 = end of step 0, 16+w = wave w done with its message batches (step 1, first chunk),
+    # 12 = mid-step barrier released, 15 = end of step 1
+    t0 = st[:, 14]
+    ok = (t0 > 0) & (st[:, 15] > 0)
+    arr = (st[:, 16:32] - t0[:, None])[ok]
+    mid = (st[:, 12] - t0)[ok]
+    end = (st[:, 15] - t0)[ok]
+    srt = np.sort(arr, axis=1)
+    print(f"step 1 of the first chunk ({ok.sum()} workgroups): duration {end.mean():.0f}; message phase: waves done at "
+          f"min {srt[:, 0].mean():.0f} / median {srt[:, 8].mean():.0f} / last {srt[:, 15].mean():.0f}, barrier released "
+          f"{mid.mean():.0f}; atom phase + end barrier {(end - mid).mean():.0f}")
+    sys.exit(0)
 
 # one step (first chunk, step 1) in detail: when each wave reaches the step barrier, barrier + image copy cost
 t0 = st[:, 14]                      # end of step 0 == start of step 1
