@@ -28,7 +28,8 @@ if str(ROOT) not in sys.path:
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA peak (16x16x4 / 4x4x1 f32: 256 flop/clk/CU)
+PEAK_F16_MFMA_TFLOPS = 2500.0  # dense fp16 MFMA peak
 PEAK_HBM_GBS = 8000.0          # HBM3E spec
 
 
@@ -51,53 +52,80 @@ def usable_cores():
             n = min(n, max(1, int(float(quota) / float(period))))
     except (OSError, ValueError):
         pass
-    return max(1, min(n, int(os.environ.get("IMPNN_BENCH_CORES", "16"))))  # GPU-box share: 16 cores per GPU
+    cap = os.environ.get("IMPNN_BENCH_CORES")  # optional override; default: every core this process may use
+    return max(1, min(n, int(cap))) if cap else max(1, n)
 
 
-def pmc_field(name):
+def pmc_field(name, kernel="encoder_fused"):
     """A figure for the encoder kernel from the committed rocprofv3 --pmc passes (profiles/pmc_*.json,
     latest round wins), or None.  hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the gfx950
-    FETCH_SIZE correction of MI355X_MICROARCH.md's HBM section."""
+    FETCH_SIZE correction of MI355X_MICROARCH.md's HBM section.  (PMC passes are separate rocprofv3 runs of this
+    same command, tools/pmc_profile.sh; the figure is per launch of the named kernel.)"""
     best = None
+    key = "encoder_typed" if "typed" in kernel else "encoder_fused"
     for f in sorted((ROOT / "profiles").glob("pmc_*.json")):
         try:
-            best = json.loads(f.read_text()).get("encoder_fused", {}).get(name, best)
+            best = json.loads(f.read_text()).get(key, {}).get(name, best)
         except (OSError, ValueError):
             pass
     return best
 
 
-def cpu_baseline(inputs, w, gpu_pooled=None, budget_s=20.0):
-    """Reference-schedule torch-CPU forward (oracle/torch_ref.py) on a bounded sample of the same
-    workload on the usable host cores.  Reported beside the GPU number; never `value`.  The same sample
-    also checks the GPU result of the timed configuration (BASELINE.json: "fp32 max-abs-err vs ref"): the
-    fp64 run of the port is the reference, the errors are those of the first `sample` pairs."""
+def _time_cpu(fn, warmup, iters, budget_s):
+    """median seconds of fn() over up to `iters` timed runs after `warmup` untimed ones, inside a time budget
+    (at least 2 timed runs) -> (median, timed runs, warm-up runs)."""
+    t0 = time.perf_counter()
+    fn()
+    first = time.perf_counter() - t0
+    w_done = 1
+    while w_done < warmup and (w_done + 1) * first < 0.25 * budget_s:
+        fn()
+        w_done += 1
+    n = int(max(2, min(iters, (budget_s - w_done * first) / max(first, 1e-4))))
+    times = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+    return float(np.median(times)), n, w_done
+
+
+def cpu_baseline(inputs, w, gpu_pooled=None, budget_s=24.0):
+    """Reference-schedule torch-CPU forward (oracle/torch_ref.py) of the same workload on the host cores this
+    process may use: batch 32 (the reference's own batch, train_viscosity.py:332) with 5
+    warm-up + 20 timed iterations, and batch 4096 (the GPU workload) with as many of the 5 + 20 iterations as fit a
+    time budget (the (B,E,D,D) tensor the reference materialises is 1.3 GB per layer call at this batch).
+    Reported beside the GPU number; never `value`.  A 256-pair sample of the GPU result of the timed configuration is
+    also checked against the fp64 run of the port (BASELINE.json: "fp32 max-abs-err vs ref")."""
     from oracle import torch_ref as TR
     cores = usable_cores()
     torch.set_num_threads(cores)
-    sample = 256
-    sub = {k: v[:sample] for k, v in inputs.items()}
     acc = None
     if gpu_pooled is not None:
+        sample = 256
+        sub = {k: v[:sample] for k, v in inputs.items()}
         ref = [t.numpy() for t in TR.pooled_pair(w, sub, torch.float64)]
         got = [t[:sample].double().cpu().numpy() for t in gpu_pooled]
         abs_err = max(float(np.abs(g - r).max()) for g, r in zip(got, ref))
         rel_err = max(float(np.abs(g - r).max() / np.abs(r).max()) for g, r in zip(got, ref))
         acc = {"max_abs_err": abs_err, "max_rel_err": rel_err,
                "of": f"GlobalSumPool outputs of the first {sample} pairs vs the fp64 CPU port (tolerance 1e-5 relative)"}
-    t0 = time.perf_counter()
-    TR.pooled_pair(w, sub)  # warm-up / page-in
-    first = time.perf_counter() - t0
-    iters = int(max(2, min(50, (budget_s - first) / max(first, 1e-3))))
-    times = []
-    for _ in range(iters):
-        t0 = time.perf_counter()
-        TR.pooled_pair(w, sub)
-        times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    out = {"value": sample / med, "unit": "graph-pairs/s", "cores": cores, "kind": "port",
-           "sample": f"{sample} pairs x {iters} iterations (median), torch-CPU fp32, reference op schedule "
-                     f"materialising (B,E,D,D); restatement, not TensorFlow itself"}
+    B = int(next(iter(inputs.values())).shape[0])
+    b32 = {k: v[:32] for k, v in inputs.items()}
+    med32, n32, w32 = _time_cpu(lambda: TR.pooled_pair(w, b32), 5, 20, 0.25 * budget_s)
+    medB, nB, wB = _time_cpu(lambda: TR.pooled_pair(w, inputs), 5, 20, 0.75 * budget_s)
+    try:
+        cpu_model = next(l.split(":", 1)[1].strip() for l in Path("/proc/cpuinfo").read_text().splitlines()
+                         if l.startswith("model name"))
+    except (OSError, StopIteration):
+        cpu_model = "unknown"
+    out = {"value": B / medB, "unit": "graph-pairs/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+           "sample": f"batch {B}: {wB} warm-up + {nB} timed iterations (median; BASELINE.md asks for 5 + 20, bounded here "
+                     f"by a {0.75 * budget_s:.0f} s budget); torch-CPU fp32, {cores} threads, reference op schedule "
+                     f"materialising (B,E,D,D); restatement, not TensorFlow itself",
+           "batch32": {"value": 32 / med32, "unit": "graph-pairs/s", "ms_per_batch": med32 * 1e3,
+                       "sample": f"batch 32: {w32} warm-up + {n32} timed iterations (median)"},
+           f"batch{B}": {"value": B / medB, "unit": "graph-pairs/s", "ms_per_batch": medB * 1e3}}
     if acc:
         out["gpu_vs_port_fp64"] = acc
     return out
@@ -118,17 +146,17 @@ def main():
                          "MI355X: the encoder fills every CU's register file, see include/impnn.h)")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams that take consecutive batches in turn (fused schedule; 1: every launch on one "
-                         "stream).  Measured on MI355X (M pairs/s): 1 stream x 256 workgroups 39.2, 2 x 256 44.2, "
-                         "3 x 256 45.4, 2 x 192 47.0, 3 x 128 49.0-49.5, 3 x 160 47.7, 3 x 96 47.4, 4 x 128 39.1")
+                         "stream): the plan kernels and the uneven tail of one batch's persistent encoder overlap "
+                         "the neighbouring batches' kernels")
     ap.add_argument("--encoder-workgroups", type=int, default=None,
-                    help="persistent workgroups per encoder launch (impnn_encoder_set_workgroups; 0 = one per CU). "
+                    help="persistent workgroups per encoder launch (the `workgroups` argument of the encoder entries; 0 = one per CU). "
                          "Default: 128 with 3 or more streams, else 0")
     ap.add_argument("--ramp-ms", type=float, default=150.0,
                     help="untimed clock ramp before the W warm-up steps: the same step() repeated for this many "
                          "milliseconds (0 disables)")
     ap.add_argument("--mode", choices=["auto", "f32t", "f32", "f16x2"], default="auto",
-                    help="GEMM arithmetic of the fused encoder (include/impnn.h); auto = f16x2 when the static "
-                         "range bound holds, else exact f32")
+                    help="schedule / arithmetic of the fused encoder (include/impnn.h); auto = exact f32: the "
+                         "per-bond-type form f32t, else the pull form f32.  f16x2 (narrower products) on request only")
     args = ap.parse_args()
 
     from ionic_mpnn_amd import _lib, dist as idist, model, ops, synthetic, weights
@@ -228,43 +256,76 @@ def main():
         local_sum = t
     total_pairs = float(local_sum[1].item())
 
-    # extra (not `value`): the whole model forward = hot path + impnn_model_head, same batch
-    full_ms = None
-    if fused and lanes:
-        m.encoder_workgroups = 0  # the single-stream extras below run alone on the chip: one workgroup per CU
-    if fused and world == 1:
-        for _ in range(3):
-            y = m(d_in, fused=True)
+    # ---- everything below is outside the timed region ----------------------------------------------------------
+    def events_ms(fn, n):
+        """mean HIP-event duration (ms) of the encoder kernel over n calls of fn on the current stream: the events
+        are recorded by libimpnn around that launch alone, on the stream it is launched on"""
+        _lib.check(lib.impnn_profile_enable(n))
+        for _ in range(n):
+            fn()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            y = m(d_in, fused=True)
-        torch.cuda.synchronize()
-        full_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        buf = (C.c_float * n)()
+        cnt = C.c_int32(0)
+        _lib.check(lib.impnn_profile_collect(buf, n, C.byref(cnt)))
+        lib.impnn_profile_disable()
+        return float(np.mean(np.frombuffer(buf, dtype=np.float32, count=cnt.value))) if cnt.value else None
 
-    kernel_ms = None
+    overlapped_ms = None
     if fused:
         buf = (C.c_float * args.steps)()
         n = C.c_int32(0)
         _lib.check(lib.impnn_profile_collect(buf, args.steps, C.byref(n)))
         lib.impnn_profile_disable()
         if n.value:
-            kernel_ms = float(np.mean(np.frombuffer(buf, dtype=np.float32, count=n.value)))
+            overlapped_ms = float(np.mean(np.frombuffer(buf, dtype=np.float32, count=n.value)))
 
-    # the same kernel without a neighbour: K more steps on ONE stream, outside the timed region.  With several streams
-    # the event-bracketed duration of a launch includes the time it shares the chip with the other batch's kernels.
-    exclusive_ms = None
-    if fused and lanes and rank == 0:
-        _lib.check(lib.impnn_profile_enable(args.steps))
+    # the dominant kernel ALONE on the chip (one stream, one workgroup per CU): what roofline.achieved is computed from.
+    # With several streams the event-bracketed duration of a launch includes the time it shares the chip with the
+    # neighbouring batches' kernels, so that figure is reported as `overlapped` only.
+    exclusive_ms, single_ms, full_ms, extras = None, None, None, {}
+    if fused and rank == 0:
+        m.encoder_workgroups = 0
+        for _ in range(5):
+            m.encode_pooled(d_in, fused=True)
+        exclusive_ms = events_ms(lambda: m.encode_pooled(d_in, fused=True), args.steps)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
         for _ in range(args.steps):
             m.encode_pooled(d_in, fused=True)
         torch.cuda.synchronize()
-        buf = (C.c_float * args.steps)()
-        n = C.c_int32(0)
-        _lib.check(lib.impnn_profile_collect(buf, args.steps, C.byref(n)))
-        lib.impnn_profile_disable()
-        if n.value:
-            exclusive_ms = float(np.mean(np.frombuffer(buf, dtype=np.float32, count=n.value)))
+        single_ms = (time.perf_counter() - t1) / args.steps * 1e3  # plan + encoder, one batch at a time
+        if world == 1:
+            for _ in range(3):
+                y = m(d_in, fused=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                y = m(d_in, fused=True)
+            torch.cuda.synchronize()
+            full_ms = (time.perf_counter() - t1) / args.steps * 1e3
+            # labelled extras: the other encoder modes on the same batch, single stream, with their own error against
+            # the timed mode's result (never `value`: "f16x2" is narrower arithmetic than the reference's f32)
+            ref_c, ref_a = m.encode_pooled(d_in, fused=True)
+            for other in ("f32", "f16x2"):
+                if other == mode_used:
+                    continue
+                m.encoder_mode = other
+                if m.resolve_encoder_mode(N, E) != other:
+                    continue
+                oc, oa = m.encode_pooled(d_in, fused=True)
+                k_ms = events_ms(lambda: m.encode_pooled(d_in, fused=True), args.steps)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    m.encode_pooled(d_in, fused=True)
+                torch.cuda.synchronize()
+                s_ms = (time.perf_counter() - t1) / args.steps * 1e3
+                scale = float(max(ref_c.abs().max(), ref_a.abs().max()))
+                extras[other] = {"kernel_ms": k_ms, "ms_per_step_single_stream": s_ms,
+                                 "graph_pairs_per_s_single_stream": B / (s_ms * 1e-3),
+                                 "max_rel_diff_vs_timed_mode": float(max((oc - ref_c).abs().max(),
+                                                                         (oa - ref_a).abs().max())) / scale}
+            m.encoder_mode = args.mode
     m.encoder_workgroups = enc_wgs
 
     if rank != 0:
@@ -276,21 +337,33 @@ def main():
     value = total_pairs * args.steps / elapsed
     flops_launch = algorithmic_flops_per_pair(N, E, D, S) * B
     bytes_launch = algorithmic_bytes_per_pair(N, E, D) * B
+    # what the kernel actually multiplies (it skips padding atoms and padding edges - exact):
+    # update 12 D^2 per kept row, message 2 D^2 per valid edge (per-bond-type form) or 2 K D^2 per kept row (pull form)
+    kept_rows, valid_edges = 0, 0
+    for pfx in ("cat", "an"):
+        ids, conn = inputs[f"{pfx}_atom"], inputs[f"{pfx}_connectivity"]
+        ok = (conn[:, :, 0] > 0) & (conn[:, :, 1] > 0)
+        last_id = np.where(ids > 0, np.arange(ids.shape[1])[None, :] + 1, 0).max(axis=1)
+        last_e = np.where(ok, conn.max(axis=2) + 1, 0).max(axis=1)
+        kept_rows += int(np.maximum(last_id, last_e).sum())
+        valid_edges += int(ok.sum())
+    msg_flops = 2 * D * D * valid_edges if mode_used == "f32t" else 2 * K * D * D * kept_rows
+    executed_flops = S * (12 * D * D * kept_rows + msg_flops)
+    arith = {"f16x2": "f32 in/out/accumulate; every f32 GEMM product formed from fp16 hi/lo splits (3 "
+                      "v_mfma_f32_16x16x32_f16 per f32 product, product error ~2^-21: NARROWER than the reference's f32)",
+             "f32": "exact f32 products on v_mfma_f32_16x16x4_f32 (pull form: agg = sum_k W_k G_k)",
+             "f32t": "exact f32 products: per-bond-type messages (models/layers.py:108-112 in the reference's own order) "
+                     "on v_mfma_f32_4x4x1_16b_f32, GatedUpdate on v_mfma_f32_16x16x4_f32; f32 accumulate, f32 in/out",
+             "layered": "f32, one launch per reference layer"}[mode_used]
     out = {
         "metric": "molecule-graph pairs/sec (fwd), batch 4096 per MI355X",  # BASELINE.json's metric; 1 pair = 2 graphs
         "value": value, "unit": "graph-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if mode_used != "f16x2" else "f16x2 (split-fp16 products, f32 accumulate)", "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[1]: message-passing forward (embedding gather -> {S}x"
                                f"(BondMatrixMessage, Reduce, GatedUpdate) -> GlobalSumPool), cation+anion, synthetic "
                                f"padded graphs N<={N} E<={E}, D={D}, K={K}, batch {B} pairs/GPU, schedule={args.schedule}",
-                   "arithmetic": {"f16x2": "f32 in/out/accumulate; every f32 GEMM product formed from fp16 hi/lo splits "
-                                           "(3 v_mfma_f32_16x16x32_f16 per f32 product, error ~2^-21; parity <=1e-5 vs "
-                                           "fp64 oracle in tests/test_gpu_encoder.py)",
-                                  "f32": "exact f32 products on v_mfma_f32_16x16x4_f32 (pull form)",
-                                  "f32t": "exact f32 products: per-bond-type messages on v_mfma_f32_4x4x1_16b_f32, "
-                                          "GatedUpdate on v_mfma_f32_16x16x4_f32",
-                                  "layered": "f32 VALU, one launch per reference layer"}[mode_used],
+                   "arithmetic": arith,
                    "mode": mode_used,
                    "pipeline": ("plan kernels of step i+1 run on a side stream under the encoder of step i; every "
                                 "step still plans and encodes one full batch") if pipelined else "none",
@@ -298,44 +371,60 @@ def main():
                                "stream order on its own workspace); kernels of neighbouring batches overlap; "
                                f"{enc_wgs or 'one per CU:'} persistent workgroups per encoder launch") if lanes
                    else "1 (every launch on one stream)",
+                   "resident_batch": "every step plans and encodes the SAME resident batch from scratch (nothing is "
+                                     "cached across steps); its 10 MB of inputs stay warm in L2/MALL - immaterial here: "
+                                     "the path is compute-bound (HBM < 1 % of 8 TB/s)",
                    "global_batch": int(total_pairs), "molecule_graphs_per_s": 2.0 * value, "parallelism": f"batch-sharded x{world}, weights replicated, "
                    "no data-path collective; one all-reduce of the fingerprint checksum after the timed region",
                    "clock_ramp": f"{ramp_steps} untimed steps ({args.ramp_ms:g} ms) before the {args.warmup} warm-up steps, "
                                  "so that the timed steps run at the sustained GPU clock",
                    "checksum": float(local_sum[0].item())},
     }
+    if single_ms:
+        out["config"]["single_stream"] = {"ms_per_step": single_ms, "graph_pairs_per_s": B / (single_ms * 1e-3),
+                                          "note": "plan + encoder of one batch at a time on ONE stream, one workgroup "
+                                                  "per CU (untimed extra steps of this run)"}
     if full_ms:
         out["config"]["full_model_forward"] = {"ms_per_step": full_ms, "graph_pairs_per_s": B / (full_ms * 1e-3),
-                                               "note": "hot path + heads (impnn_model_head) -> log_eta; not `value`"}
+                                               "note": "hot path + heads (impnn_model_head) -> log_eta, single stream; "
+                                                       "not `value`"}
+    if extras:
+        out["config"]["other_modes"] = extras
     if rehearsal:
         out["config"]["rehearsal"] = f"{world} ranks share {ndev} GPU(s) over gloo - not a scaling number"
-    if kernel_ms:
-        ach = flops_launch / (kernel_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "encoder_fused_kernel", "achieved": ach,
-                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                           "traffic": pmc_field("hbm_bytes_per_launch"), "kernel_ms": kernel_ms,
-                           "matrix_pipe_busy_frac_pmc": pmc_field("mfma_pipe_busy_frac"),
-                           "note": "achieved = SURVEY 8(d) algorithmic f32 flops / measured kernel time; peak = dense "
-                                   "f32 MFMA (= f32 VALU) peak, the rate an exact-f32 implementation is bound by. "
-                                   "In mode f16x2 the products run on the fp16 matrix pipe (3 per f32 product), so "
-                                   "frac may exceed 1; the kernel is then VALU-issue bound (DESIGN.md 4.1)",
+    k_ms = exclusive_ms or overlapped_ms
+    if k_ms:
+        # peak of the pipe the products run on: exact-f32 modes -> dense f32 MFMA (= f32 VALU) 157.3 TFLOP/s with the
+        # SURVEY 8(d) algorithmic flops; f16x2 -> its executed fp16 MFMA flops (3 per f32 product) against 2.5 PFLOP/s
+        if mode_used == "f16x2":
+            flops_for_frac, peak, what = 3.0 * executed_flops, PEAK_F16_MFMA_TFLOPS, "executed fp16 MFMA flops (3 per f32 product)"
+        else:
+            flops_for_frac, peak, what = float(flops_launch), PEAK_F32_MFMA_TFLOPS, "SURVEY 8(d) algorithmic f32 flops"
+        ach = flops_for_frac / (k_ms * 1e-3) / 1e12
+        kname = "encoder_typed_kernel" if mode_used == "f32t" else "encoder_fused_kernel"
+        out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                           "frac": ach / peak, "traffic": pmc_field("hbm_bytes_per_launch", kname),
+                           "kernel_ms": k_ms,
+                           "timing": ("HIP events around the kernel alone on the chip: one stream, one workgroup per CU, "
+                                      f"{args.steps} untimed extra launches of this run") if exclusive_ms else
+                                     "HIP events per launch inside the timed loop",
+                           "note": f"achieved = {what} per launch / kernel_ms; the algorithmic count (2 S (2 D^2 E + 12 D^2 N) "
+                                   "per pair) includes padding atoms and padding edge slots, which the kernel skips exactly: "
+                                   "`executed_flops_per_launch` is what it multiplies",
                            "algorithmic_flops_per_launch": flops_launch,
-                           "overlap": (None if not lanes else {
-                               "streams": len(lanes),
-                               "note": "kernel_ms / achieved / frac above are per launch as HIP events and rocprofv3 see "
-                                       "it while neighbouring batches' kernels share the chip; `exclusive` is the same "
-                                       "kernel alone on one stream with one workgroup per CU (K untimed extra steps of "
-                                       "this run); `whole_step` divides "
-                                       "the algorithmic flops by ms_per_step (plan kernels included)",
-                               "exclusive": (None if not exclusive_ms else {
-                                   "kernel_ms": exclusive_ms,
-                                   "achieved": flops_launch / (exclusive_ms * 1e-3) / 1e12,
-                                   "frac": flops_launch / (exclusive_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}),
-                               "whole_step": {"achieved": flops_launch / (ms_per_step * 1e-3) / 1e12,
-                                              "frac": flops_launch / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS}}),
+                           "executed_flops_per_launch": executed_flops,
+                           "executed_achieved": executed_flops / (k_ms * 1e-3) / 1e12,
+                           "matrix_pipe_busy_frac_pmc": pmc_field("mfma_pipe_busy_frac", kname),
+                           "overlapped": (None if not (lanes and overlapped_ms) else {
+                               "streams": len(lanes), "kernel_ms": overlapped_ms,
+                               "note": "per launch as HIP events / rocprofv3 see it inside the timed loop, while the "
+                                       "neighbouring batches' kernels share the chip - not a roofline figure"}),
+                           "whole_step": {"achieved": flops_launch / (ms_per_step * 1e-3) / 1e12,
+                                          "frac": flops_launch / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                          "note": "algorithmic flops / ms_per_step (plan kernels included)"},
                            "hbm": {"algorithmic_bytes_per_launch": bytes_launch,
-                                   "achieved_GBs": bytes_launch / (kernel_ms * 1e-3) / 1e9,
-                                   "frac_of_8TBs": bytes_launch / (kernel_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}}
+                                   "achieved_GBs": bytes_launch / (k_ms * 1e-3) / 1e9,
+                                   "frac_of_8TBs": bytes_launch / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(inputs, w, gpu_pooled=(pc, pa))
     print(json.dumps(out), flush=True)

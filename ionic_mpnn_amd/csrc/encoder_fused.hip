@@ -646,7 +646,7 @@ int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
   pp.header = reinterpret_cast<PlanHeader*>(base);
   pp.typed = typed ? 1 : 0;
   pp.n_ions = a.n_ions; pp.B = a.B; pp.N = a.N; pp.E = a.E; pp.Va = a.Va; pp.Vb = a.Vb;
-  pp.grid_sub = w.max_sub < 6 ? w.max_sub : 6;  // 6 x 256 workgroups of 256 threads are resident at once on 256 CUs
+  pp.grid_sub = w.max_sub < 5 ? w.max_sub : 5;  // 5 x 256 workgroups of 256 threads are resident at once on 256 CUs (<= 96 VGPRs)
   pp.nwg = w.nwg;
   pp.max_sub = w.max_sub;
   pp.nblk = w.nblk;

@@ -358,7 +358,8 @@ __device__ __forceinline__ int block_excl_scan(int v, int32_t* wsum /* [4] LDS *
 // TYPED: records of the typed encoder (encoder_layout.h "typed"): rows placed by EXACT descending in-degree, message
 // slots in jagged-diagonal order, edges grouped by bond type.  Dynamic LDS: the group table (16 B x (128 + Vb)).
 template <bool TYPED>
-__global__ __launch_bounds__(kRCap) void plan_chunks_kernel(PlanParams p) {
+__global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  // <= 96 VGPRs: 5 workgroups per CU
+
   __shared__ int32_t moloff[kRCap + 2], molrows[kRCap], cnt[kRCap], place[kRCap], cursor[kRCap], rowptr[kRCap + 2];
   __shared__ int32_t bins[TYPED ? 2 * kRCap + 2 : 48], tilemax[16], scratch[8];
   __shared__ int32_t jdp[TYPED ? kRCap + 2 : 1], thist[TYPED ? kTVbMax : 1], tgb[TYPED ? kTVbMax : 1];

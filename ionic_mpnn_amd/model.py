@@ -179,11 +179,14 @@ class MPNNModel:
         import json
         arrays = self.state_dict()
         cfg = {k: v for k, v in self.get_config().items() if k != "layers"}
-        np.savez(path, __config__=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), **arrays)
+        # through a file handle: np.savez(path, ...) appends ".npz" to any other suffix, and the reference flow saves
+        # to "models/viscosity_final.keras" and loads that very name (train_melting_point_transfer.py:78)
+        with open(path, "wb") as f:
+            np.savez(f, __config__=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8), **arrays)
 
     def save(self, path):
-        """model.save("models/viscosity_final.keras") (train_viscosity.py:354) - here the .npz of save_weights (config +
-        variables); the Keras zip/HDF5 container is not written."""
+        """model.save("models/viscosity_final.keras") (train_viscosity.py:354) - here the npz container of save_weights
+        (config + variables) under exactly the name given; the Keras zip/HDF5 container is not written."""
         self.save_weights(path)
 
     @staticmethod

@@ -441,3 +441,83 @@ def test_predict_in_chunks_equals_predict_at_once(fused):
         parts = m.predict(inp, batch_size=bs, fused=fused)
         assert parts.shape == whole.shape
         np.testing.assert_allclose(parts, whole, rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------ BASELINE.json configs 3 and 5 at their real shapes
+@pytest.fixture(scope="module")
+def config3():
+    """Melting-point model at its real shape (train_melting_point.py:137-198): D=32, K=D*D=1024, S=4, batch 8192
+    (BASELINE.json configs[2]; N=40 / E=80 / vocabulary stand-ins as SURVEY.md 8(d) - the real pkl is absent)."""
+    Va, Vb, B = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, 8192
+    inp = synthetic.make_batch(B, seed=21, with_temperature=False)
+    w = weights.init_weights("melting_point", Va, Vb, atom_dim=32, bond_dim=1024, num_steps=4, seed=22, perturb=True)
+    m = MM.build_melting_point_model(Va, Vb, atom_dim=32, num_steps=4, device=DEV)
+    m.load_weights(w)
+    d = to_dev(inp)
+    return inp, w, m, d
+
+
+def test_config3_melting_point_real_shape_fused_typed(config3):
+    inp, w, m, d = config3
+    assert m.bond_dim == 1024 and m.resolve_encoder_mode(40, 80) == "f32t"   # K = D^2 runs in the fused encoder
+    pc, pa = m.encode_pooled(d, fused=True)
+    y = m(d, fused=True)
+    torch.cuda.synchronize()
+    idx = np.random.default_rng(5).choice(8192, size=40, replace=False)
+    sub = {k: v[idx] for k, v in inp.items()}
+    rc = O.encode(w, "cat", sub["cat_atom"], sub["cat_bond"], sub["cat_connectivity"], pooled_only=True)
+    ra = O.encode(w, "an", sub["an_atom"], sub["an_bond"], sub["an_connectivity"], pooled_only=True)
+    assert_close(pc.cpu().numpy()[idx], rc, what="config 3 cat pooled (sample)")
+    assert_close(pa.cpu().numpy()[idx], ra, what="config 3 an pooled (sample)")
+    assert_close(y.cpu().numpy()[idx], O.melting_point_forward(w, sub), what="config 3 melting-point head (sample)")
+    # batch shards recomputed separately are the same rows bit for bit (SURVEY.md 8e)
+    h = 8192 // 2 + 33
+    c0, a0 = m.encode_pooled({k: v[:h].contiguous() for k, v in d.items()}, fused=True)
+    c1, a1 = m.encode_pooled({k: v[h:].contiguous() for k, v in d.items()}, fused=True)
+    assert torch.equal(torch.cat([c0, c1]), pc) and torch.equal(torch.cat([a0, a1]), pa)
+    # and the layer-at-a-time HIP path (per-bond-type matrices through impnn_bond_type_matrices) agrees
+    lc, la = m.encode_pooled({k: v[:512].contiguous() for k, v in d.items()}, fused=False)
+    assert_close(lc.cpu().numpy(), pc[:512].cpu().numpy(), what="config 3 layered vs fused cat")
+    assert_close(la.cpu().numpy(), pa[:512].cpu().numpy(), what="config 3 layered vs fused an")
+
+
+def test_config5_shape_forward_vs_oracle():
+    """BASELINE.json configs[4]'s forward shape: atom_dim 128, 6 message-passing steps, batch 4096 (the validation /
+    predict path of the full training loop), sampled molecules against the oracle."""
+    Va, Vb, B = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, 4096
+    inp = synthetic.make_batch(B, seed=31)
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=128, bond_dim=8, num_steps=6, seed=32, perturb=True)
+    m = MM.build_model(Va, Vb, atom_dim=128, bond_dim=8, num_steps=6, device=DEV)
+    m.load_weights(w)
+    d = to_dev(inp)
+    pc, pa = m.encode_pooled(d)
+    y = m(d)
+    torch.cuda.synchronize()
+    idx = np.random.default_rng(6).choice(B, size=24, replace=False)
+    sub = {k: v[idx] for k, v in inp.items()}
+    rc = O.encode(w, "cat", sub["cat_atom"], sub["cat_bond"], sub["cat_connectivity"], pooled_only=True)
+    ra = O.encode(w, "an", sub["an_atom"], sub["an_bond"], sub["an_connectivity"], pooled_only=True)
+    assert_close(pc.cpu().numpy()[idx], rc, what="config 5 cat pooled (sample)")
+    assert_close(pa.cpu().numpy()[idx], ra, what="config 5 an pooled (sample)")
+    assert_close(y.cpu().numpy()[idx], O.viscosity_forward(w, sub), what="config 5 log_eta (sample)")
+    h = B // 2 - 5
+    c0, a0 = m.encode_pooled({k: v[:h].contiguous() for k, v in d.items()})
+    c1, a1 = m.encode_pooled({k: v[h:].contiguous() for k, v in d.items()})
+    assert torch.equal(torch.cat([c0, c1]), pc) and torch.equal(torch.cat([a0, a1]), pa)
+
+
+@pytest.mark.parametrize("K,Vb", [(1024, 72), (64, 200), (17, 256), (1, 3)])
+def test_typed_encoder_any_bond_dim(K, Vb):
+    """The typed mode's only use of bond_dim is the prepared per-bond-type matrices: any K, up to 256 bond types."""
+    Va = 50
+    inp = synthetic.make_batch(130, max_atoms=30, max_edges=60, atom_vocab_size=Va, bond_vocab_size=Vb, min_atoms=4,
+                               seed=K, with_temperature=False)
+    w = weights.init_weights("melting_point", Va, Vb, atom_dim=32, bond_dim=K, num_steps=2, seed=K + 1, perturb=True)
+    m = MM.MPNNModel("melting_point", Va, Vb, 32, K, 32, 20, 2, 1e-4, device=DEV)
+    m.load_weights(w)
+    m.encoder_mode = "f32t"
+    pc, pa = m.encode_pooled(to_dev(inp), fused=True)
+    rc = O.encode(w, "cat", inp["cat_atom"], inp["cat_bond"], inp["cat_connectivity"], pooled_only=True)
+    ra = O.encode(w, "an", inp["an_atom"], inp["an_bond"], inp["an_connectivity"], pooled_only=True)
+    assert_close(pc.cpu().numpy(), rc, what=f"cat pooled K={K} Vb={Vb}")
+    assert_close(pa.cpu().numpy(), ra, what="an pooled")

@@ -420,6 +420,14 @@ def test_weight_file_round_trip(tmp_path):
     assert np.array_equal(m.predict(inp), m2.predict(inp))
     lc = m.get_config()["layers"]
     assert {"atom_dim": 16, "bond_dim": 4}.items() <= next(c["config"] for c in lc if c["class_name"] == "BondMatrixMessage").items()
+    # the reference's own file name (train_viscosity.py:354 -> train_melting_point_transfer.py:78): the name is kept
+    # verbatim (numpy would append ".npz" to a plain path)
+    kpath = tmp_path / "viscosity_final.keras"
+    m.save(str(kpath))
+    assert kpath.exists() and not (tmp_path / "viscosity_final.keras.npz").exists()
+    m4 = MM.load_model(str(kpath), device=DEV)
+    assert np.array_equal(m.predict(inp), m4.predict(inp))
+    m2.load_weights(str(kpath))
 
 
 def test_trainer_flow_end_to_end(monkeypatch):
