@@ -509,11 +509,12 @@ class MPNNModel:
         with torch.no_grad():
             return train.mse(y, pred) + self.regularization_loss()
 
-    def train_on_batch(self, inputs, y, group=None):
+    def train_on_batch(self, inputs, y, group=None, n_global=None):
         """One optimizer step on one mini-batch -> the batch loss (MSE + penalties) as a 0-d tensor.
         With torch.distributed initialised (or ``group`` given) every rank calls this with its shard of
         the global mini-batch: the gradients are averaged over ranks (weighted by shard size) with one
-        all-reduce of the flat gradient buffer, then every rank applies the same step."""
+        all-reduce of the flat gradient buffer, then every rank applies the same step.  ``n_global``: size of the
+        global mini-batch when the caller knows it (fit does) - saves the blocking all-reduce that counts it."""
         from . import dist as idist
         if getattr(self, "optimizer", None) is None:
             self.compile()
@@ -521,7 +522,10 @@ class MPNNModel:
         n_local = len(inputs["cat_atom"])
         loss = self._loss(inputs, y, training=True) if n_local else None
         if idist.is_distributed():
-            weight, _ = idist.shard_loss_weight(n_local, opt.flat_grad.device, group)
+            if n_global is not None:
+                weight = float(n_local) / float(n_global) if n_global > 0 else 0.0
+            else:
+                weight, _ = idist.shard_loss_weight(n_local, opt.flat_grad.device, group)
             if loss is not None:
                 (loss * weight).backward()
             self.join_training_streams()
@@ -550,13 +554,29 @@ class MPNNModel:
         mini-batches of ``batch_size``, `loss` = sample-weighted mean of the batch losses, `val_loss` from
         evaluate(); callbacks see on_train_begin / on_epoch_end / on_train_end.  Returns a History.
         ``graph=True`` (single process): full-size mini-batches replay one captured hipGraph of the whole step
-        (train.GraphedTrainStep); the last, smaller batch of an epoch runs eagerly."""
+        (train.GraphedTrainStep); the last, smaller batch of an epoch runs eagerly.
+        Under torch.distributed every rank passes the FULL (x, y): the shuffle seed is rank 0's (broadcast once), every
+        global mini-batch is cut into contiguous shards (data.shard_bounds), so all ranks run the same number of steps
+        with the same sample order, and the reported loss is the global sample-weighted mean."""
         from . import train
         if getattr(self, "optimizer", None) is None:
             self.compile()
         x = self._to_device(x)
         y = np.asarray(y, dtype=np.float32)
         n = len(y)
+        if n:  # once per data set (one device sync), not per batch: raise where tf-CPU's gather / scatter_nd would
+            for pfx in ("cat", "an"):
+                ops.validate_indices(conn=x[f"{pfx}_connectivity"], atom_ids=x[f"{pfx}_atom"], bond_ids=x[f"{pfx}_bond"],
+                                     N=x[f"{pfx}_atom"].shape[1], Va=self.atom_vocab_size, Vb=self.bond_vocab_size)
+        from . import dist as idist
+        distributed = idist.is_distributed()
+        if distributed:  # one shared permutation stream: rank 0's seed (drawn if none was given)
+            import torch.distributed as tdist
+            sd = torch.tensor([int(seed) if seed is not None else int(np.random.SeedSequence().entropy % (1 << 62))],
+                              dtype=torch.int64, device=self.device if tdist.get_backend() == "nccl" else "cpu")
+            tdist.broadcast(sd, src=0)
+            seed = int(sd.item())
+            rank, world = tdist.get_rank(), tdist.get_world_size()
         rng = np.random.default_rng(seed)
         hist = train.History()
         callbacks = list(callbacks or [])
@@ -566,9 +586,8 @@ class MPNNModel:
                 cb.set_model(self)
             if hasattr(cb, "on_train_begin"):
                 cb.on_train_begin({})
-        from . import dist as idist
         graphed = None
-        use_graph = bool(graph) and not idist.is_distributed() and n >= batch_size
+        use_graph = bool(graph) and not distributed and n >= batch_size
         y_dev = torch.from_numpy(y).to(self.device).reshape(-1, 1)
         val_dev = None
         for epoch in range(int(epochs)):
@@ -584,9 +603,23 @@ class MPNNModel:
                         graphed = train.GraphedTrainStep(self, {k: v[tidx] for k, v in x.items()}, y[idx],
                                                          resident=(x, y_dev))
                     loss = graphed.step_on_rows(x, y_dev, tidx)
+                elif distributed:
+                    from .data import shard_bounds
+                    s0, s1 = shard_bounds(len(idx), world, rank)
+                    sidx = tidx[s0:s1]
+                    loss = self.train_on_batch({k: v[sidx] for k, v in x.items()}, y_dev[sidx], n_global=len(idx))
+                    tot.add_(loss, alpha=s1 - s0)  # shard means, weighted by shard size; summed over ranks below
+                    continue
                 else:
                     loss = self.train_on_batch({k: v[tidx] for k, v in x.items()}, y_dev[tidx])
                 tot.add_(loss, alpha=len(idx))
+            if distributed:  # every rank summed its shards' losses: one all-reduce per epoch for the logged mean
+                if tdist.get_backend() == "nccl":
+                    tdist.all_reduce(tot)
+                else:
+                    t_cpu = tot.cpu()
+                    tdist.all_reduce(t_cpu)
+                    tot = t_cpu.to(self.device)
             logs = {"loss": float(tot) / max(n, 1)}
             if validation_data is not None:
                 if val_dev is None:  # uploaded once, not per epoch

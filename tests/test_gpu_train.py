@@ -444,3 +444,55 @@ def test_trainer_flow_end_to_end(monkeypatch):
     out = mod.main()
     assert out["epochs_run"] == 6 and np.isfinite(out["last_loss"]) and out["last_loss"] < out["first_loss"]
     assert all(np.isfinite(out[k]) for k in ("train_r2", "dev_mae", "test_mae"))
+
+
+def _fit_rank(rank, world, port, out_dir):
+    """One data-parallel rank of model.fit: ranks share cuda:0 (one-GPU box), gloo carries the collectives."""
+    import os
+    import sys
+    from pathlib import Path
+    sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    from ionic_mpnn_amd import dist as idist
+    idist.init_distributed(backend="gloo")
+    m, _, inp, y = _tiny_model(S=1, seed=7)
+    m.compile(train.Adam(1e-2, clipnorm=1.0))
+    # only rank 0 names a seed: the others must end up with its permutation stream (broadcast), and 23 samples at
+    # batch 10 leave a last mini-batch of 3 that is cut 1 + 2 - every rank still runs the same number of steps
+    sub = {k: v[:23] for k, v in inp.items()}
+    hist = m.fit(sub, y[:23], epochs=3, batch_size=10, seed=11 if rank == 0 else None)
+    np.savez(Path(out_dir) / f"fit_{rank}.npz", loss=np.array(hist.history["loss"]), **m.state_dict())
+    torch.distributed.destroy_process_group()
+
+
+def test_fit_under_torch_distributed_two_ranks(tmp_path):
+    """fit() under torch.distributed - shared shuffle, sharded mini-batches, same step count on every rank.
+    Both ranks must finish with identical weights and the same logged loss, equal (to fp32 reassociation) to the
+    single-process run with rank 0's seed."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_fit_rank, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    for r, p in enumerate(procs):
+        if p.is_alive():
+            p.kill()
+            pytest.fail(f"rank {r} hung")
+        assert p.exitcode == 0, f"rank {r} exit code {p.exitcode}"
+    a, b = np.load(tmp_path / "fit_0.npz"), np.load(tmp_path / "fit_1.npz")
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), f"ranks disagree on {k}"
+    m, _, inp, y = _tiny_model(S=1, seed=7)
+    m.compile(train.Adam(1e-2, clipnorm=1.0))
+    hist = m.fit({k: v[:23] for k, v in inp.items()}, y[:23], epochs=3, batch_size=10, seed=11, graph=False)
+    close(a["loss"], np.array(hist.history["loss"]), 1e-4, "distributed vs single-process loss history")
+    sd = m.state_dict()
+    for k in ("cat_gu_0/dense_z/kernel", "atom_embedding", "visc_params/kernel"):
+        close(a[k], sd[k], 2e-3, f"distributed vs single-process {k}")

@@ -107,3 +107,20 @@ def test_flatten_ion_ragged_layout():
     assert f["edge_flat"][:5].tolist() == [[0, 1], [1, 0], [0, 1], [1, 0], [1, 2]]  # 4th edge cut: only 3 bond ids
     assert f["bond_flat"][:5].tolist() == [2, 2, 1, 1, 4]
     assert all(v.dtype == np.int32 for v in f.values())
+
+
+def test_id_dataset_is_validated_once_on_the_host():
+    """Corrupt records raise when the dataset is built (the reference's tf.gather / scatter_nd raise on them on the
+    CPU); the kernels themselves treat out-of-range indices as padding (include/impnn.h)."""
+    import copy
+    import pytest
+    from ionic_mpnn_amd import data, synthetic
+    recs, vocab = synthetic.make_id_records(6, seed=1)
+    data.IonPairDataset(recs, vocab)  # clean
+    for mutate, what in ((lambda r: r["cation"]["atom_ids"].__setitem__(0, vocab["atom_vocab_size"]), "atom_ids"),
+                         (lambda r: r["anion"]["bond_ids"].__setitem__(0, -2), "bond_ids"),
+                         (lambda r: r["anion"]["edge_indices"].__setitem__(0, (0, 99)), "edge_indices")):
+        bad = copy.deepcopy(recs)
+        mutate(bad[2])
+        with pytest.raises(ValueError, match=what):
+            data.IonPairDataset(bad, vocab)
