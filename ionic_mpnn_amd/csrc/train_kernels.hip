@@ -1049,11 +1049,27 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
   float* ws = rhs + 64 * LDR;         // 2 x 16 x LDW, element (k = 4*qq + r, column c) at ((qq * LDW + c) * 4 + r)
   float* part = ws + 2 * 16 * LDW;    // 4 x (4 x 64): LayerNorm row partials (sum, sq. deviation, m1, m2)
   float* red = part + 4 * 256;        // 4 row tiles x 5 x D column sums
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, a = lane & 15, q = lane >> 4;
-  const int rt = wv & 3, fg = wv >> 2;
+  const int tid = threadIdx.x;
+  int a = tid & 15, q = (tid >> 4) & 3, rt = (tid >> 6) & 3, fg = tid >> 8;  // lane = 16 q + a, wave = 4 fg + rt
   constexpr int kPre = 16 * 2 * D / 1024;
   float pre[kPre];
+  // (`opaque(tid)`: the slice addresses are recomputed where they are used - a few integer ops - instead of being
+  //  hoisted out of the GEMM loops by the compiler: ~60 loop-invariant per-thread addresses had been spilled to scratch
+  //  in the prologue and reloaded in every iteration)
+  auto opaque = [](int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+  };
+  auto opaque0 = [](int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+  };
+  auto relane = [&]() {  // same values, re-derived: every phase's element addresses start from here
+    const int t_ = opaque0(threadIdx.x);
+    a = t_ & 15; q = (t_ >> 4) & 3; rt = (t_ >> 6) & 3; fg = t_ >> 8;
+  };
   auto park = [&](float* dst, int ncols) {  // slice element t -> (k = t / ncols, column t % ncols)
+    const int tid = opaque(threadIdx.x);
 #pragma unroll
     for (int i = 0; i < kPre; ++i) {
       const int t = tid + 1024 * i;
@@ -1064,6 +1080,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     }
   };
   auto park_t = [&](float* dst) {           // transposed slices: element t -> (column t / 16, k = t % 16)
+    const int tid = opaque(threadIdx.x);
 #pragma unroll
     for (int i = 0; i < kPre; ++i) {
       const int t = tid + 1024 * i, c = t >> 4, jj = t & 15;
@@ -1099,6 +1116,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       rr[TL] = f32x4_t{br[f], br[f], br[f], br[f]};
     }
     auto fetch1 = [&](int u) {
+      const int tid = opaque(threadIdx.x);
 #pragma unroll
       for (int i = 0; i < kPre; ++i) {
         const int t = tid + 1024 * i, jj = t / (2 * D), c = t - jj * 2 * D;
@@ -1127,6 +1145,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       if (u + 1 < 2 * NT) park(nxt, 2 * D);
       __syncthreads();
     }
+    relane();
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL)
 #pragma unroll
@@ -1137,6 +1156,13 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
         const float v = rr[TL][g] * cs[rl * LDC + f];
         rhs[rl * LDR + f] = v;
         if (rl < nrt) rh_t[rl * D + f] = v;
+        // Register relief (the kernel ran 156 VGPRs over its 128 with everything held): r, z and tanh(t) are parked
+        // in the tile's own dpre rows - slots that receive drp / dzp / dtp later anyway - and read back by the same
+        // thread where they are needed again (L2-resident, same address: program order).
+        if (rl < nrt) {
+          dpre_t[rl * 3 * D + D + f] = rr[TL][g];
+          dpre_t[rl * 3 * D + f] = z[TL][g];
+        }
       }
     // ---- P2: t
     f32x4_t tt[NL];
@@ -1146,6 +1172,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       tt[TL] = f32x4_t{b2, b2, b2, b2};
     }
     auto fetch2 = [&](int u) {
+      const int tid = opaque(threadIdx.x);
 #pragma unroll
       for (int i = 0; i < kPre; ++i) {
         const int t = tid + 1024 * i;
@@ -1171,7 +1198,8 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       __syncthreads();
     }
     // ---- blend, LayerNorm forward statistics
-    f32x4_t xh[NL], dy[NL];
+    relane();
+    f32x4_t xh[NL];
     float sum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL)
@@ -1179,10 +1207,11 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       for (int g = 0; g < 4; ++g) {
         const int rl = 16 * rt + 4 * q + g, f = 16 * (fg * NL + TL) + a;
         const float hv = cs[rl * LDC + f];
-        tt[TL][g] = tanhf(tt[TL][g]);
-        xh[TL][g] = (1.0f - z[TL][g]) * hv + z[TL][g] * tt[TL][g];
+        const float tv = tanhf(tt[TL][g]);
+        const float zz = rl < nrt ? dpre_t[rl * 3 * D + f] : 0.f;
+        xh[TL][g] = (1.0f - zz) * hv + zz * tv;
         sum[g] += xh[TL][g];
-        dy[TL][g] = rl < nrt ? dout_t[rl * D + f] : 0.f;
+        if (rl < nrt) dpre_t[rl * 3 * D + 2 * D + f] = tv;
       }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1216,12 +1245,15 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       inv[g] = 1.0f / sqrtf(((part[rl] + part[64 + rl]) + (part[128 + rl] + part[192 + rl])) * (1.0f / D) + eps);
     }
     // ---- LayerNorm backward
-    f32x4_t dxh[NL];
+    relane();
+    f32x4_t dxh[NL], dy[NL];
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL) {
       const float gm = gamma[16 * (fg * NL + TL) + a];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+        const int rl = 16 * rt + 4 * q + g;
+        dy[TL][g] = rl < nrt ? dout_t[rl * D + 16 * (fg * NL + TL) + a] : 0.f;
         xh[TL][g] *= inv[g];
         dxh[TL][g] = dy[TL][g] * gm;
         m1[g] += dxh[TL][g];
@@ -1245,6 +1277,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       m1[g] = ((part[512 + rl] + part[576 + rl]) + (part[640 + rl] + part[704 + rl])) * (1.0f / D);
       m2[g] = ((part[768 + rl] + part[832 + rl]) + (part[896 + rl] + part[960 + rl])) * (1.0f / D);
     }
+    relane();
     f32x4_t dzp[NL], dhA[NL];
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL)
@@ -1253,7 +1286,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
         const int rl = 16 * rt + 4 * q + g, f = 16 * (fg * NL + TL) + a;
         const float hv = cs[rl * LDC + f];
         const float dn = inv[g] * (dxh[TL][g] - m1[g] - xh[TL][g] * m2[g]);
-        const float zz = z[TL][g], tv = tt[TL][g];
+        const float zz = rl < nrt ? dpre_t[rl * 3 * D + f] : 0.f, tv = rl < nrt ? dpre_t[rl * 3 * D + 2 * D + f] : 0.f;
         dzp[TL][g] = dn * (tv - hv) * zz * (1.0f - zz);
         const float dtp = dn * zz * (1.0f - tv * tv);
         dhA[TL][g] = dy[TL][g] + dn * (1.0f - zz);
@@ -1269,7 +1302,8 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     f32x4_t lo[NL], hi[NL];
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL) lo[TL] = hi[TL] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    auto fetch3 = [&](int u) {  // slice u of Wh^T: (k = j - 16u, column i') = Wh[i'][16u + k]
+    auto fetch3 = [&](int u) {
+      const int tid = opaque(threadIdx.x);  // slice u of Wh^T: (k = j - 16u, column i') = Wh[i'][16u + k]
 #pragma unroll
       for (int i = 0; i < kPre; ++i) {
         const int t = tid + 1024 * i;
@@ -1298,13 +1332,14 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       if (u + 1 < NT) park_t(nxt);
       __syncthreads();
     }
+    relane();
     f32x4_t daA[NL];
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int rl = 16 * rt + 4 * q + g, f = 16 * (fg * NL + TL) + a;
-        const float hv = cs[rl * LDC + f], rv = rr[TL][g];
+        const float hv = cs[rl * LDC + f], rv = rl < nrt ? dpre_t[rl * 3 * D + D + f] : 0.f;
         const float drp = lo[TL][g] * hv * rv * (1.0f - rv);
         dhA[TL][g] = fmaf(lo[TL][g], rv, dhA[TL][g]);
         daA[TL][g] = hi[TL][g];
@@ -1313,6 +1348,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
         if (rl < nrt) dpre_t[rl * 3 * D + D + f] = drp;
       }
     __syncthreads();  // all reads of c = [h|agg] are done: it becomes [dzp|drp]
+    relane();
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL)
 #pragma unroll
@@ -1325,6 +1361,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL) lo[TL] = hi[TL] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     auto fetch4 = [&](int u) {
+      const int tid = opaque(threadIdx.x);
       const float* W = u < NT ? Wz : Wr;
       const int u0 = u < NT ? u : u - NT;
 #pragma unroll
@@ -1355,6 +1392,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       if (u + 1 < 2 * NT) park_t(nxt);
       __syncthreads();
     }
+    relane();
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL)
 #pragma unroll
