@@ -69,7 +69,7 @@ static_assert(kRecEnt + 4 * kECap <= kRecBytes && kRecEnt % 16 == 0, "record lay
 // `row`; rows are placed by descending in-degree, so the rows that have a d-th in-edge are a prefix - and every
 // atom row then sums its in-edges in edge-slot order (the reference's sequential scatter_nd, models/layers.py:78-82).
 constexpr int kTECap = 512;          // valid edges per chunk (2 per virtual row)
-constexpr int kTGrpCap = 512;        // >= kTECap/4 + kTVbMax groups
+constexpr int kTGrpCap = 384;        // = kTECap/4 + kTVbMax groups
 constexpr int kTVbMax = 256;         // bond ids travel as 8 bits
 constexpr int kTRecRowdeg = 0;       // u16[kRCap]    : in-degree of the PLACED row
 constexpr int kTRecTilemax = 528;    // u8[16]
@@ -79,12 +79,13 @@ constexpr int kTRecPoolrow = 1584;   // u16[kRCap]
 constexpr int kTRecRowatom = 2096;   // i32[kRCap]
 constexpr int kTRecCounts = 3120;    // u16 groups, u16 edges, u16 max in-degree
 constexpr int kTRecJdptr = 3136;     // u16[258]      : first message slot of in-edge index d
-constexpr int kTRecWstart = 3664;    // u16[17]       : first group of every wave, + end (whole bond types per wave)
+constexpr int kTRecNrun = 3664;      // u16           : type runs (bond types present in the chunk)
 constexpr int kTRecGrp = 3712;       // uint4[kTGrpCap]: x = type | edges << 8 | groups of the type from here on << 24,
                                      //   y = 4 x u8 placed source row, z/w = 4 x u16 message key (tmsg_key of the edge's
                                      //   slot; the dump slot for unused lanes); in type order
+constexpr int kTRecRuns = kTRecGrp + 16 * kTGrpCap;  // u16[kTVbMax + 2]: first group of every type run, + end
 constexpr int kTRecBytes = 12288;
-static_assert(kTRecGrp % 16 == 0 && kTRecGrp + 16 * kTGrpCap <= kTRecBytes, "typed record layout");
+static_assert(kTRecGrp % 16 == 0 && kTRecRuns + 2 * (kTVbMax + 2) <= kTRecBytes, "typed record layout");
 constexpr int kTMsgFloats = (kTECap + 1) * kD;  // message buffer, 128 B per slot, 16-byte units XOR-swizzled by slot;
                                                 // slot kTECap is a dump for the unused edge lanes of a group
 // 16-byte unit u (0..7) of message slot s -> float offset.  16 consecutive slots x one unit cover all 16 bank quads

@@ -661,17 +661,14 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
   // P5: every row's in-edge list in edge-slot order: entry-parallel rank sort, straight into the record
   if constexpr (TYPED) {
     // Groups of <= 4 edges of one bond type, in type order: entry x = type | edges << 8 | groups of this type from
-    // this one on << 24.  All groups of a type go to ONE wave (which fetches the type's matrix once per chunk-step:
-    // the message phase is bound by the L2 -> CU fill rate): wave w takes the types whose group-range midpoint
-    // falls into its 1/16 of the groups.
+    // this one on << 24.  All groups of a type form one "run", processed by one wave of the encoder (which fetches
+    // the type's matrix once per chunk-step).
     const int n_t = thist[tid];
     const int ng = (n_t + 3) >> 2;  // <= 128
     int ngrp = 0;
     const int gb = block_excl_scan(ng, scratch, ngrp);
     tgb[tid] = gb;
     thist[tid] = 0;  // becomes the fill cursor of the type
-    int* const wof = cnt;  // (free since P2) wave of every type that has groups, -1 otherwise
-    wof[tid] = -1;
     {
       const uint32_t dump = (uint32_t)tmsg_key(kTECap) * 0x10001u;  // unused edge lanes write to the dump slot
       for (int i = tid; i < ngrp; i += kRCap) grp[i] = make_uint4(0u, 0u, dump, dump);
@@ -682,18 +679,18 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
         const int c = n_t - 4 * jg;
         grp[gb + jg].x = (uint32_t)tid | ((uint32_t)(c < 4 ? c : 4) << 8) | ((uint32_t)(ng - jg) << 24);
       }
-      const int wv = (16 * (2 * gb + ng)) / (2 * ngrp);
-      wof[tid] = wv > 15 ? 15 : wv;
     }
-    lds_barrier();
-    if (tid <= 16) {  // wstart[w] = first group of the first type given to a wave >= w (types are in group order)
-      int first = ngrp;
-      for (int t = 0; t < p.Vb; ++t)
-        if (wof[t] >= tid) {
-          first = tgb[t];
-          break;
-        }
-      reinterpret_cast<uint16_t*>(rec + kTRecWstart)[tid] = (uint16_t)(tid == 16 ? ngrp : first);
+    // run table: first group of every type that has groups, in type order (+ end).  The encoder's waves take runs
+    // from it one at a time (an LDS counter), so the message phase is balanced dynamically.
+    {
+      int nrun = 0;
+      const int ridx = block_excl_scan(ng > 0 ? 1 : 0, scratch, nrun);
+      uint16_t* runs = reinterpret_cast<uint16_t*>(rec + kTRecRuns);
+      if (ng > 0) runs[ridx] = (uint16_t)gb;
+      if (tid == 0) {
+        runs[nrun] = (uint16_t)ngrp;
+        *reinterpret_cast<uint16_t*>(rec + kTRecNrun) = (uint16_t)nrun;
+      }
     }
     if (tid == 0) {
       uint16_t* cw = reinterpret_cast<uint16_t*>(rec + kTRecCounts);

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
   const int32_t* const r_rowatom = reinterpret_cast<const int32_t*>(recl + kTRecRowatom);
   const uint16_t* const r_counts = reinterpret_cast<const uint16_t*>(recl + kTRecCounts);
   const uint16_t* const r_jdptr = reinterpret_cast<const uint16_t*>(recl + kTRecJdptr);
-  const uint16_t* const r_wstart = reinterpret_cast<const uint16_t*>(recl + kTRecWstart);
+  const uint16_t* const r_runs = reinterpret_cast<const uint16_t*>(recl + kTRecRuns);
+  int* const run_ctr = reinterpret_cast<int*>(recl + kTRecCounts + 8);  // next type run of the message phase
   const uint4* const r_grp = reinterpret_cast<const uint4*>(recl + kTRecGrp);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
       if (4 * (tid + kThreads) < kTUpdLds) st4(wupd + 4 * (tid + kThreads), pf1);
     }
     image_ready = p.S > 0;
+    if (tid == 0) *run_ctr = 0;  // (the record's bytes there are not written by the plan)
     lds_barrier();
     if (stamp && tid == 0) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -182,8 +184,6 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
       __builtin_amdgcn_s_setprio(2);
       {
         const uint32_t* const grp_x = reinterpret_cast<const uint32_t*>(r_grp);
-        const int g_hi = __builtin_amdgcn_readfirstlane(r_wstart[wave + 1]);
-        int gi = __builtin_amdgcn_readfirstlane(r_wstart[wave]);
         const int kh = lane >> 5, f = lane & 31;
         const bool feeds = f < 4;
         const int boff = kh * 512 + f * 4;
@@ -206,6 +206,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
               for (int i = 0; i < 4; ++i) aq[i] = ld4(base + 4 * i);
             }
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#ifndef IMPNN_DIAG_NO_MSG_MFMA  // (diagnostics builds only: wrong results)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               acc0 = mfma1(aq[i][0], bq[i][0], acc0);
@@ -213,6 +214,10 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
               acc0 = mfma1(aq[i][2], bq[i][2], acc0);
               acc1 = mfma1(aq[i][3], bq[i][3], acc1);
             }
+#else
+            acc0[0] = aq[0][0] + bq[0][0] + aq[3][3] + bq[3][3];
+            acc1[1] = aq[1][1] + bq[1][1] + aq[2][2] + bq[2][2];
+#endif
             acc0 += acc1;
             // element i of lane l: edge i, feature l & 31, k-half l >> 5.
             // v_permlane32_swap x, y: lanes 32-63 of x <-> lanes 0-31 of y.  Afterwards x = {x.lo, y.lo},
@@ -226,31 +231,41 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
             msg[__builtin_amdgcn_ubfe(ge.w, zsh, 16) ^ f] = x2 + x3;
           }
         };
-        // The next type's matrix rows are requested before the current type's groups multiply (two register sets,
-        // the run loop unrolled by two so that neither is ever copied).  Measured dead ends, for the record: deeper
-        // rings (3-4 sets) spill; forcing every group to one L1-resident matrix gains only 4 % (the phase is not
-        // bound by the L2 fill rate); hand-placed s_waitcnt around inline-asm loads is not safe against the
-        // compiler's register copies.
-        auto fetch = [&](int g, f32x4 (&bq)[4]) {
+        // Type runs are handed out one at a time through an LDS counter (the runs differ in length and in how long their
+        // matrix rows take to arrive; a static split left the slowest wave 20 % behind the median).  A wave holds two
+        // runs: the one it multiplies and the next one, whose matrix rows are already in flight (two register sets,
+        // loop unrolled by two so that neither is ever copied).
+        const int nrun = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint16_t*>(recl + kTRecNrun));
+        auto grab = [&](int& g, int& n, f32x4 (&bq)[4]) {  // -> false when the runs are used up
+          int r = 0;
+          if (lane == 0) r = atomicAdd(run_ctr, 1);
+          r = __builtin_amdgcn_readfirstlane(r);
+          if (r >= nrun) return false;
+          g = __builtin_amdgcn_readfirstlane(r_runs[r]);
+          n = __builtin_amdgcn_readfirstlane(r_runs[r + 1]) - g;
           const int type = __builtin_amdgcn_readfirstlane(grp_x[4 * g]) & 0xff;
           const float* bp = tm_s + (size_t)type * kTMatFloats + boff;
 #pragma unroll
           for (int i = 0; i < 4; ++i) bq[i] = ld4(bp + i * 128);
+          return true;
+        };
+        // `landed`: the rows are consumed here (an empty asm that reads and rewrites the registers), so the compiler
+        // places its s_waitcnt vmcnt HERE - before the next run's loads are issued.  vmcnt counts in order: waiting for
+        // the current rows after the prefetch has been issued would wait for the prefetch as well.
+        auto landed = [](f32x4 (&b)[4]) {
+          asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : : "memory");
         };
         f32x4 bP[4], bQ[4];
-        if (gi < g_hi) fetch(gi, bP);
-        while (gi < g_hi) {
-          int n = __builtin_amdgcn_readfirstlane(grp_x[4 * gi]) >> 24;  // groups of this type (all inside this wave's range)
-          int nxt = gi + n;
-          if (nxt < g_hi) fetch(nxt, bQ);
-          run_type(gi, n, bP);
-          gi = nxt;
-          if (gi >= g_hi) break;
-          n = __builtin_amdgcn_readfirstlane(grp_x[4 * gi]) >> 24;
-          nxt = gi + n;
-          if (nxt < g_hi) fetch(nxt, bP);
-          run_type(gi, n, bQ);
-          gi = nxt;
+        int gP = 0, nP = 0, gQ = 0, nQ = 0;
+        bool haveP = grab(gP, nP, bP);
+        while (haveP) {
+          landed(bP);
+          const bool haveQ = grab(gQ, nQ, bQ);
+          run_type(gP, nP, bP);
+          if (!haveQ) break;
+          landed(bQ);
+          haveP = grab(gP, nP, bP);
+          run_type(gQ, nQ, bQ);
         }
       }
       const bool mstamp = stamp && c == c_begin && s == 1;
@@ -258,6 +273,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
       // Mid-step barrier: every message is in LDS and every read of h by the message phase is done (h is updated in
       // place below); the update image of this step, stored after the previous step's barrier, is in place too.
       lds_barrier();
+      if (tid == 0) *run_ctr = 0;  // for the next step's message phase (ordered by the end-of-step barrier)
       if (mstamp && tid == 0) stamp[12] = __builtin_amdgcn_s_memtime();
       if (stamp && tid == 0 && c == c_begin && s == 1) t_msg = __builtin_amdgcn_s_memtime();
 
