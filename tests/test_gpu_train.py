@@ -403,6 +403,37 @@ def test_graphed_train_step_follows_the_eager_trajectory():
     close(np.array(h2.history["loss"]), np.array(h1.history["loss"]), 1e-4, "fit loss, graph vs eager")
 
 
+def test_graph_replay_survives_allocator_churn():
+    """Every pointer a captured step reads or writes (static inputs, gradient sinks, per-node workspaces, the loss
+    workspace, the Adam state) must stay valid for the graph's whole life: between replays this test frees and
+    re-allocates hundreds of MB through torch's caching allocator, scribbles NaNs over what it gets, and drops the
+    Python references the capture left behind (gc).  The trajectory must still equal the eager one.
+    ("hipMemsetAsync in a captured graph": the lifetime audit of the captured buffers.)"""
+    import gc
+    ma, w, inp, y = _tiny_model(S=2, seed=13)
+    mb, _, _, _ = _tiny_model(S=2, seed=13)
+    for m in (ma, mb):
+        m.compile(train.Adam(1e-3, clipnorm=1.0))
+    d = ma._to_device(inp)
+    pick = lambda idx: ({k: v[torch.from_numpy(idx).to(DEV)] for k, v in d.items()}, y[idx])
+    g = train.GraphedTrainStep(mb, *pick(np.arange(0, 8)))
+    rng = np.random.default_rng(0)
+    for it in range(6):
+        junk = [torch.full((int(rng.integers(1, 64)) << 18,), float("nan"), device=DEV) for _ in range(6)]
+        del junk
+        gc.collect()
+        torch.cuda.empty_cache()                      # hand the eager pool's blocks back; the graph's pool must stay
+        junk = [torch.full((1 << 22,), float("nan"), device=DEV) for _ in range(4)]
+        idx = rng.permutation(24)[:8]
+        la = ma.train_on_batch(*pick(idx))
+        lb = g(*pick(idx)).clone()
+        close(lb, la, 1e-5, f"loss at replay {it}")
+        del junk
+    for (n, ta), (_, tb) in zip(ma.trainable_variables(), mb.trainable_variables()):
+        assert torch.isfinite(tb).all(), n
+        close(tb, ta, 2e-4, f"weights {n}")
+
+
 def test_weight_file_round_trip(tmp_path):
     """f3: config + variables under their Keras-style names survive save_weights -> from_config + load_weights."""
     from ionic_mpnn_amd import layers as LL
