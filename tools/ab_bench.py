@@ -54,25 +54,24 @@ prep = {}
 def call(lib):
     if hasattr(lib, "impnn_encoder_fused_prepared"):
         if id(lib) not in prep:
-            nb = int(lib.impnn_encoder_prepared_bytes(S))
+            nb = int(lib.impnn_encoder_prepared_bytes(S, btab.shape[0], ops.ENCODER_MODES[args.mode]))
             bufs = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(2)]
             for bf, pk in zip(bufs, packed):
-                assert lib.impnn_encoder_prepare_weights(pk.data_ptr(), 32, 8, S, ops.ENCODER_MODES[args.mode],
-                                                         bf.data_ptr(), nb, torch.cuda.current_stream().cuda_stream) == 0
+                assert lib.impnn_encoder_prepare_weights(pk.data_ptr(), btab.data_ptr(), 32, 8, S, btab.shape[0],
+                                                         ops.ENCODER_MODES[args.mode], bf.data_ptr(), nb,
+                                                         torch.cuda.current_stream().cuda_stream) == 0
             prep[id(lib)] = bufs
         rc = lib.impnn_encoder_fused_prepared(2, mk([i[0] for i in ions]), mk([i[1] for i in ions]),
                                               mk([i[2] for i in ions]), atab.data_ptr(), atab.shape[0], btab.data_ptr(),
                                               btab.shape[0], mk(prep[id(lib)]), ops.ENCODER_MODES[args.mode], mk(pooled),
-                                              B, 40, 80, 32, 8, S, 1e-3, ws.data_ptr(), ws.numel(),
+                                              B, 40, 80, 32, 8, S, 1e-3, 0, ws.data_ptr(), ws.numel(),
                                               torch.cuda.current_stream().cuda_stream)
         assert rc == 0, lib.impnn_last_error_string()
         return
-    if hasattr(lib, "impnn_encoder_set_mode"):
-        lib.impnn_encoder_set_mode(ops.ENCODER_MODES[args.mode])
     rc = lib.impnn_encoder_fused(2, mk([i[0] for i in ions]), mk([i[1] for i in ions]), mk([i[2] for i in ions]),
-                                 atab.data_ptr(), atab.shape[0], btab.data_ptr(), btab.shape[0], mk(packed), mk(pooled),
-                                 B, 40, 80, 32, 8, S, 1e-3, ws.data_ptr(), ws.numel(),
-                                 torch.cuda.current_stream().cuda_stream)
+                                 atab.data_ptr(), atab.shape[0], btab.data_ptr(), btab.shape[0], mk(packed),
+                                 ops.ENCODER_MODES[args.mode], mk(pooled), B, 40, 80, 32, 8, S, 1e-3, 0, ws.data_ptr(),
+                                 ws.numel(), torch.cuda.current_stream().cuda_stream)
     assert rc == 0, lib.impnn_last_error_string()
 
 
