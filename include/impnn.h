@@ -97,6 +97,23 @@ int impnn_gated_update(const float* h, const float* agg, const float* Wz, const 
                        const float* gamma, const float* beta, float ln_eps, float* out,
                        int64_t rows, int32_t D, impnn_stream_t stream);
 
+/* ---- a7 on a row list: the same arithmetic on rows row_index[0 .. *n_rows) of h / agg / out only (all other rows of
+ *      `out` are left untouched).  The reference computes GatedUpdate on padding atoms too; their values can reach
+ *      neither a message (no valid edge names them) nor the pool, so a caller that owns the whole encode() loop may
+ *      skip them: impnn_kept_rows gives, per molecule, r_b = 1 + max(last n with atom_ids[b,n] > 0, largest atom
+ *      index on a valid edge) (the kept rows are closed under "is a source of": skipping is exact), and
+ *      impnn_row_index_fill turns r and its inclusive prefix sum into the flat list b*N + [0, r_b) and its length
+ *      (*n_rows, device memory - no host round trip; the launch is sized for max_rows = B*N).  atom_dim 64 / 128. */
+int impnn_gated_update_rows(const float* h, const float* agg, const float* Wz, const float* bz,
+                            const float* Wr, const float* br, const float* Wh, const float* bh,
+                            const float* gamma, const float* beta, float ln_eps, float* out,
+                            const int32_t* row_index, const int32_t* n_rows, int64_t max_rows, int32_t D,
+                            impnn_stream_t stream);
+int impnn_kept_rows(const int32_t* atom_ids, const int32_t* bond_ids, const int32_t* conn, int32_t* rows_out,
+                    int32_t B, int32_t N, int32_t E, int32_t Vb, impnn_stream_t stream);
+int impnn_row_index_fill(const int32_t* kept_rows, const int32_t* kept_rows_inclusive_prefix,
+                         int32_t* row_index, int32_t* n_rows, int32_t B, int32_t N, impnn_stream_t stream);
+
 /* ---- a8: GlobalSumPool.call (models/layers.py:161-164): out[b,:] = sum_n h[b,n,:]*[ids[b,n]>0]. */
 int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, int32_t B,
                           int32_t N, int32_t D, impnn_stream_t stream);

@@ -27,6 +27,9 @@ SIGNATURES = {
     "impnn_reduce_scatter_add": (C.c_int, [vp, vp, i32, vp, i32, i32, i32, i32, vp]),
     "impnn_bmm_fused": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
     "impnn_gated_update": (C.c_int, [vp] * 10 + [f32, vp, i64, i32, vp]),
+    "impnn_gated_update_rows": (C.c_int, [vp] * 10 + [f32, vp, vp, vp, i64, i32, vp]),
+    "impnn_kept_rows": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, vp]),
+    "impnn_row_index_fill": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
     "impnn_global_sum_pool": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "impnn_encoder_step_floats": (i64, [i32, i32]),
     "impnn_encoder_workspace_bytes": (C.c_int, [i32] * 10 + [C.POINTER(sz)]),

@@ -129,6 +129,34 @@ int impnn_gated_update(const float* h, const float* agg, const float* Wz, const 
                              as_stream(stream));
 }
 
+int impnn_gated_update_rows(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
+                            const float* br, const float* Wh, const float* bh, const float* gamma,
+                            const float* beta, float ln_eps, float* out, const int32_t* row_index,
+                            const int32_t* n_rows, int64_t max_rows, int32_t D, impnn_stream_t stream) {
+  REQUIRE(max_rows >= 0 && D > 0, "bad shape");
+  if (max_rows == 0) return IMPNN_OK;
+  REQUIRE(h && agg && Wz && bz && Wr && br && Wh && bh && gamma && beta && out && row_index && n_rows, "null pointer");
+  REQUIRE(ln_eps >= 0.f, "ln_eps must be >= 0");
+  return launch_gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, ln_eps, out, max_rows, D, as_stream(stream),
+                             row_index, n_rows);
+}
+
+int impnn_kept_rows(const int32_t* atom_ids, const int32_t* bond_ids, const int32_t* conn, int32_t* rows_out,
+                    int32_t B, int32_t N, int32_t E, int32_t Vb, impnn_stream_t stream) {
+  REQUIRE(B >= 0 && N > 0 && E >= 0 && Vb > 0, "bad shape");
+  if (B == 0) return IMPNN_OK;
+  REQUIRE(atom_ids && rows_out && (E == 0 || conn), "null pointer");
+  return launch_kept_rows(atom_ids, bond_ids, conn, rows_out, B, N, E, Vb, as_stream(stream));
+}
+
+int impnn_row_index_fill(const int32_t* kept_rows, const int32_t* kept_rows_inclusive_prefix, int32_t* row_index,
+                         int32_t* n_rows, int32_t B, int32_t N, impnn_stream_t stream) {
+  REQUIRE(B >= 0 && N > 0, "bad shape");
+  if (B == 0) return IMPNN_OK;
+  REQUIRE(kept_rows && kept_rows_inclusive_prefix && row_index && n_rows, "null pointer");
+  return launch_row_index_fill(kept_rows, kept_rows_inclusive_prefix, row_index, n_rows, B, N, as_stream(stream));
+}
+
 int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, int32_t B, int32_t N,
                           int32_t D, impnn_stream_t stream) {
   REQUIRE(B >= 0 && N > 0 && D > 0, "bad shape");

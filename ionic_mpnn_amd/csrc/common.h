@@ -42,7 +42,11 @@ int launch_reduce_scatter_add(const float* m, const int32_t* tgt, int tgt_stride
 int launch_gated_update(const float* h, const float* agg, const float* Wz, const float* bz,
                         const float* Wr, const float* br, const float* Wh, const float* bh,
                         const float* gamma, const float* beta, float eps, float* out, int64_t rows,
-                        int D, hipStream_t s);
+                        int D, hipStream_t s, const int32_t* ridx = nullptr, const int32_t* nrows_dev = nullptr);
+int launch_kept_rows(const int32_t* atom_ids, const int32_t* bond_ids, const int32_t* conn, int32_t* rows_out, int B,
+                     int N, int E, int Vb, hipStream_t s);
+int launch_row_index_fill(const int32_t* r, const int32_t* incl, int32_t* idx, int32_t* count, int B, int N,
+                          hipStream_t s);
 int launch_global_sum_pool(const float* h, const int32_t* ids, float* out, int B, int N, int D,
                            hipStream_t s);
 int64_t model_head_loss_workspace_floats(int B);

@@ -728,23 +728,30 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
     const float* __restrict__ h, const float* __restrict__ agg, const float* __restrict__ Wz,
     const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
     const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float eps, float* __restrict__ out, int64_t rows) {
+    const float* __restrict__ beta, float eps, float* __restrict__ out, int64_t rows,
+    const int32_t* __restrict__ ridx, const int32_t* __restrict__ nrows_dev) {
+  // ridx / nrows_dev (optional): the kernel works on the rows ridx[0 .. *nrows_dev) of h / agg / out instead of on
+  // rows [0, rows) - the model's layered path skips padding atoms this way (impnn_kept_row_index); the grid is
+  // sized for `rows`, workgroups beyond the list leave at once.
+  if (nrows_dev) rows = *nrows_dev;
   constexpr int D = 16 * NT, LDC = 2 * D + 4, LDR = D + 4;
   constexpr int LDW = 2 * D;  // slice layout: element (input row 4*qq + r, column c) at ((qq * LDW + c) * 4 + r)
   extern __shared__ __align__(16) float smem[];
   float* cs = smem;                 // 64 x LDC : [h | agg]
   float* rhs = cs + 64 * LDC;       // 64 x LDR : r * h
-  float* ws = rhs + 64 * LDR;       // 2 x 16 x LDW : slices of 16 input rows of the gate kernels, double-buffered
+  float* ws = rhs + 64 * LDR;       // 3 x 16 x LDW : slices of 16 input rows of the gate kernels, a ring of three
   constexpr int NL = NT / 4;  // feature tiles of this wave
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, a = lane & 15, q = lane >> 4;
   const int wave = wv & 3, fg = wv >> 2;  // row tile, feature group
-  float* part = ws + 2 * 16 * LDW;  // 2 x 4 x 64 row partials (sum, squared deviation) of LayerNorm
+  float* part = ws + 3 * 16 * LDW;  // 2 x 4 x 64 row partials (sum, squared deviation) of LayerNorm
   const int64_t row0 = (int64_t)blockIdx.x * 64;
+  if (row0 >= rows) return;
   for (int t = tid; t < 64 * D; t += 1024) {
     const int r = t / D, c = t - r * D;
     const bool in = row0 + r < rows;
-    cs[r * LDC + c] = in ? h[(row0 + r) * D + c] : 0.f;
-    cs[r * LDC + D + c] = in ? agg[(row0 + r) * D + c] : 0.f;
+    const int64_t src = in ? (ridx ? (int64_t)ridx[row0 + r] : row0 + r) : 0;
+    cs[r * LDC + c] = in ? h[src * D + c] : 0.f;
+    cs[r * LDC + D + c] = in ? agg[src * D + c] : 0.f;
   }
   f32x4_t z[NL], rg[NL];
 #pragma unroll
@@ -755,30 +762,27 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
     rg[TL] = f32x4_t{b1, b1, b1, b1};
   }
   const float* crow = cs + (16 * wave + a) * LDC + 4 * q;
-  // kernel slices: global -> registers one slice ahead (in flight under the MFMAs) -> the other LDS buffer
+  // Kernel slices: global -> registers TWO slices ahead -> a ring of three LDS buffers.  One slice ahead was not
+  // enough: all 256 CUs stream the same 16 KB slice at the same time (one L2 channel group), a slice took ~5.5 K cycles
+  // against 2 K of MFMA work, each iteration waiting out its own L2 round trip in front of the barrier.
   constexpr int kP1 = 16 * 2 * D / 1024, kP2 = 16 * D / 1024;
-  float pre[kP1];
-  auto fetch1 = [&](int u) {
+  float preA[kP1], preB[kP1];
+  auto fetch1 = [&](int u, float (&pre)[kP1]) {
 #pragma unroll
     for (int i = 0; i < kP1; ++i) {
       const int t = tid + 1024 * i, jj = t / (2 * D), c = t - jj * 2 * D;
       pre[i] = c < D ? Wz[(int64_t)(16 * u + jj) * D + c] : Wr[(int64_t)(16 * u + jj) * D + c - D];
     }
   };
-  auto park1 = [&](float* dst) {
+  auto park1 = [&](float* dst, const float (&pre)[kP1]) {
 #pragma unroll
     for (int i = 0; i < kP1; ++i) {
       const int t = tid + 1024 * i, jj = t / (2 * D), c = t - jj * 2 * D;
       dst[(((jj >> 2) * LDW + c) << 2) + (jj & 3)] = pre[i];
     }
   };
-  fetch1(0);
-  park1(ws);
-  __syncthreads();
-  for (int u = 0; u < 2 * NT; ++u) {
-    float* cur = ws + (u & 1) * 16 * LDW;
-    float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
-    if (u + 1 < 2 * NT) fetch1(u + 1);
+  auto mma1 = [&](int u) {
+    const float* cur = ws + (u % 3) * 16 * LDW;
     const f32x4_t av = ldv4(crow + 16 * u);
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL) {
@@ -790,7 +794,20 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
         rg[TL] = mfma_f32(av[r], brv[r], rg[TL]);
       }
     }
-    if (u + 1 < 2 * NT) park1(nxt);  // nxt was last read two iterations ago: the barrier below orders it
+  };
+  fetch1(0, preA);
+  fetch1(1, preB);
+  park1(ws, preA);  // slice 0
+  __syncthreads();
+  // iteration u: slice u is in LDS buffer u % 3, slice u + 1 in registers (fetched one iteration ago), slice u + 2 is requested
+  for (int u = 0; u < 2 * NT; u += 2) {
+    if (u + 2 < 2 * NT) fetch1(u + 2, preA);          // preA was parked at the end of the previous iteration (or above)
+    mma1(u);
+    park1(ws + ((u + 1) % 3) * 16 * LDW, preB);       // slice u + 1; that buffer was last read at iteration u - 2
+    __syncthreads();
+    if (u + 3 < 2 * NT) fetch1(u + 3, preB);
+    mma1(u + 1);
+    if (u + 2 < 2 * NT) park1(ws + ((u + 2) % 3) * 16 * LDW, preA);
     __syncthreads();
   }
   // z, r -> sigmoid; r * h into LDS (every wave only touches its own 16 rows)
@@ -809,27 +826,22 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
     tt[TL] = f32x4_t{b2, b2, b2, b2};
   }
   const float* rrow = rhs + (16 * wave + a) * LDR + 4 * q;
-  auto fetch2 = [&](int u) {
+  auto fetch2 = [&](int u, float (&pre)[kP1]) {
 #pragma unroll
     for (int i = 0; i < kP2; ++i) {
       const int t = tid + 1024 * i, jj = t / D, c = t - jj * D;
       pre[i] = Wh[(int64_t)(16 * u + jj) * D + c];
     }
   };
-  auto park2 = [&](float* dst) {
+  auto park2 = [&](float* dst, const float (&pre)[kP1]) {
 #pragma unroll
     for (int i = 0; i < kP2; ++i) {
       const int t = tid + 1024 * i, jj = t / D, c = t - jj * D;
       dst[(((jj >> 2) * LDW + c) << 2) + (jj & 3)] = pre[i];
     }
   };
-  fetch2(0);
-  park2(ws);
-  __syncthreads();
-  for (int u = 0; u < 2 * NT; ++u) {
-    float* cur = ws + (u & 1) * 16 * LDW;
-    float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
-    if (u + 1 < 2 * NT) fetch2(u + 1);
+  auto mma2 = [&](int u) {
+    const float* cur = ws + (u % 3) * 16 * LDW;
     const f32x4_t av = u < NT ? ldv4(rrow + 16 * u) : ldv4(crow + 16 * u);  // [r*h | agg]
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL) {
@@ -837,7 +849,19 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) tt[TL] = mfma_f32(av[r], bv[r], tt[TL]);
     }
-    if (u + 1 < 2 * NT) park2(nxt);
+  };
+  fetch2(0, preA);
+  fetch2(1, preB);
+  park2(ws, preA);
+  __syncthreads();
+  for (int u = 0; u < 2 * NT; u += 2) {
+    if (u + 2 < 2 * NT) fetch2(u + 2, preA);
+    mma2(u);
+    park2(ws + ((u + 1) % 3) * 16 * LDW, preB);
+    __syncthreads();
+    if (u + 3 < 2 * NT) fetch2(u + 3, preB);
+    mma2(u + 1);
+    if (u + 2 < 2 * NT) park2(ws + ((u + 2) % 3) * 16 * LDW, preA);
     __syncthreads();
   }
   // blend, LayerNorm over the D features of each row (partials of the 4 feature groups meet in LDS), residual
@@ -889,8 +913,10 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int rl = 16 * wave + 4 * q + g;
-      if (row0 + rl < rows)
-        out[(row0 + rl) * D + f] = (tt[TL][g] - mean[g]) * inv[g] * gm + bt + cs[rl * LDC + f];
+      if (row0 + rl < rows) {
+        const int64_t dst = ridx ? (int64_t)ridx[row0 + rl] : row0 + rl;
+        out[dst * D + f] = (tt[TL][g] - mean[g]) * inv[g] * gm + bt + cs[rl * LDC + f];
+      }
     }
   }
 }
@@ -1192,11 +1218,68 @@ int launch_reduce_scatter_add(const float* m, const int32_t* tgt, int tgt_stride
   return check_launch("reduce_scatter_add");
 }
 
+// ---------------------------------------------------------------------------------------
+// Kept rows of a padded batch (the encoder's rule, encoder_plan.hip): molecule b keeps rows [0, r_b),
+// r_b = 1 + max(last n with atom_ids[b,n] > 0, largest atom index on a valid edge); rows beyond can neither send a
+// message nor be pooled.  One wave per molecule.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kept_rows_kernel(const int32_t* __restrict__ atom_ids,
+                                                        const int32_t* __restrict__ bond_ids,
+                                                        const int32_t* __restrict__ conn, int32_t* __restrict__ rows_out,
+                                                        int B, int N, int E, int Vb) {
+  const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  int r = 0;
+  for (int n = lane; n < N; n += 64)
+    if (atom_ids[(int64_t)b * N + n] > 0) r = n + 1;
+  for (int e = lane; e < E; e += 64) {
+    const int sv = conn[((int64_t)b * E + e) * 2], tv = conn[((int64_t)b * E + e) * 2 + 1];
+    const int bid = bond_ids ? bond_ids[(int64_t)b * E + e] : 0;
+    if (sv > 0 && tv > 0 && sv < N && tv < N && (unsigned)bid < (unsigned)Vb) {
+      const int m = (sv > tv ? sv : tv) + 1;
+      r = r > m ? r : m;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int t = __shfl_xor(r, o);
+    r = r > t ? r : t;
+  }
+  if (lane == 0) rows_out[b] = r;
+}
+
+// row list: molecule b's kept rows b*N + [0, r_b) at positions start_b + [0, r_b); start = exclusive prefix of r
+__global__ void row_index_fill_kernel(const int32_t* __restrict__ r, const int32_t* __restrict__ incl,
+                                      int32_t* __restrict__ idx, int32_t* __restrict__ count, int B, int N) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) *count = B > 0 ? incl[B - 1] : 0;
+  if (t >= (int64_t)B * N) return;
+  const int b = (int)(t / N), n = (int)(t - (int64_t)b * N);
+  if (n < r[b]) idx[incl[b] - r[b] + n] = (int32_t)t;
+}
+
+int launch_kept_rows(const int32_t* atom_ids, const int32_t* bond_ids, const int32_t* conn, int32_t* rows_out, int B,
+                     int N, int E, int Vb, hipStream_t s) {
+  if (B == 0) return IMPNN_OK;
+  kept_rows_kernel<<<(B + 3) / 4, 256, 0, s>>>(atom_ids, bond_ids, conn, rows_out, B, N, E, Vb);
+  return check_launch("kept_rows");
+}
+
+int launch_row_index_fill(const int32_t* r, const int32_t* incl, int32_t* idx, int32_t* count, int B, int N,
+                          hipStream_t s) {
+  if (B == 0) return IMPNN_OK;
+  const int64_t n = (int64_t)B * N;
+  row_index_fill_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(r, incl, idx, count, B, N);
+  return check_launch("row_index_fill");
+}
+
 int launch_gated_update(const float* h, const float* agg, const float* Wz, const float* bz,
                         const float* Wr, const float* br, const float* Wh, const float* bh,
                         const float* gamma, const float* beta, float eps, float* out, int64_t rows,
-                        int D, hipStream_t s) {
+                        int D, hipStream_t s, const int32_t* ridx, const int32_t* nrows_dev) {
   if (rows == 0) return IMPNN_OK;
+  if (ridx && !(D % 64 == 0 && D <= 128))
+    return fail(IMPNN_E_UNSUPPORTED, "gated_update: a row list is supported for atom_dim 64 and 128 only");
   if (D == 32 && aligned16(h) && aligned16(agg) && aligned16(out)) {
     const int64_t tiles = (rows + 15) / 16;
     int64_t blocks = (tiles + 3) / 4;
@@ -1216,13 +1299,13 @@ int launch_gated_update(const float* h, const float* agg, const float* Wz, const
       return check_launch("gated_update_wide");                                                                     \
     } while (0)
     if (D % 64 == 0) {  // 16 waves per workgroup: 4 per SIMD
-      const size_t l16 = lw + sizeof(float) * 512;
+      const size_t l16 = lw + sizeof(float) * (512 + 16 * 2 * D);  // a third slice buffer + the LayerNorm partials
 #define WIDE16(NT_)                                                                                                \
       do {                                                                                                          \
         (void)hipFuncSetAttribute((const void*)gated_update_wide16_kernel<NT_>,                                     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)l16);                            \
         gated_update_wide16_kernel<NT_><<<blocks, 1024, l16, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, out, \
-                                                                 rows);                                             \
+                                                                 rows, ridx, nrows_dev);                            \
         return check_launch("gated_update_wide16");                                                                 \
       } while (0)
       if (D == 64) WIDE16(4);

@@ -409,16 +409,24 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_seg_mfma_kernel(
   const int LD = D + 4;            // 16-byte aligned rows, bank-staggered
   float* As = smem;                // D x LD
   float* xm = As + D * LD;         // kSeg x LD, rows beyond n are zero
-  for (int t = tid; t < D * D; t += (int)blockDim.x) As[(t / D) * LD + (t % D)] = A[(int64_t)ty * D * D + t];
-  for (int t = tid; t < kSeg * D; t += (int)blockDim.x) {
-    const int e = t / D, c = t - e * D;
-    float v = 0.f;
+  // 16-byte loads throughout (D is a multiple of 16, rows of A / h / the LDS tiles are 16-byte aligned): the segment's
+  // time is its 64 KB of A[type] and its gathered source rows, not its 64 MFMAs per wave
+  const int D4 = D >> 2;
+  const float* Aty = A + (int64_t)ty * D * D;
+  for (int t = tid; t < D * D4; t += (int)blockDim.x) {
+    const int r = t / D4, c4 = t - r * D4;
+    stv4(As + r * LD + 4 * c4, ldv4(Aty + (int64_t)r * D + 4 * c4));
+  }
+  if (tid < kSeg) outrow[tid] = tid < n ? (int64_t)order[p0 + tid] : 0;
+  __syncthreads();
+  for (int t = tid; t < kSeg * D4; t += (int)blockDim.x) {
+    const int e = t / D4, c4 = t - e * D4;
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
     if (e < n) {
-      const int64_t be = order[p0 + e];
-      v = h[((be / E) * N + conn[be * 2]) * D + c];
-      if (c == 0) outrow[e] = be;
+      const int64_t be = outrow[e];
+      v = ldv4(h + ((be / E) * N + conn[be * 2]) * D + 4 * c4);
     }
-    xm[e * LD + c] = v;
+    stv4(xm + e * LD + 4 * c4, v);
   }
   __syncthreads();
   const int lane = tid & 63, wave = tid >> 6, a = lane & 15, q = lane >> 4;
@@ -2124,7 +2132,7 @@ int launch_bmm_message_typed_sorted(const float* h, const int32_t* bond_ids, con
   const int32_t* segbase = workspace + 3 * (Vb + 1);
   const int32_t* order = workspace + 4 * (Vb + 1);
   const int64_t max_segs = (BE + kSeg - 1) / kSeg + Vb;
-  if (D % 16 == 0 && (reinterpret_cast<uintptr_t>(m) & 15u) == 0) {
+  if (D % 16 == 0 && ((reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(h)) & 15u) == 0) {
     const size_t lm = sizeof(float) * ((size_t)D * (D + 4) + (size_t)kSeg * (D + 4));
     if (lm > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)bmm_message_typed_seg_mfma_kernel,

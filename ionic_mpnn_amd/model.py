@@ -304,6 +304,13 @@ class MPNNModel:
         if not typed:
             bond = bond.dense()
         one_node = typed and trace is None and self._builds_graph()  # training: a whole step as one autograd node
+        # inference at wide states (the layered path is what serves atom_dim 64 / 128): GatedUpdate only on the rows an
+        # encode() loop has to carry - padding atoms can reach neither a message nor the pool (include/impnn.h,
+        # impnn_gated_update_rows); their rows of h are left undefined and are never read
+        rows = None
+        if (typed and trace is None and not one_node and self.atom_dim in (64, 128) and self.num_steps > 0
+                and not torch.is_grad_enabled()):
+            rows = ops.kept_row_index(atom_ids, bond_ids, conn, self.bond_vocab_size)
         for i in range(self.num_steps):
             if one_node:
                 from . import autograd
@@ -315,7 +322,13 @@ class MPNNModel:
                 continue
             m = br["bmm"][i]([h, bond, conn])
             agg = br["reduce"][i]([m, conn[:, :, 1], h])
-            h = br["update"][i]([h, agg])
+            if rows is not None:
+                u, w = br["update"][i], br["update"][i]._weights
+                h = ops.gated_update(h, agg, w["dense_z/kernel"], w["dense_z/bias"], w["dense_r/kernel"],
+                                     w["dense_r/bias"], w["dense_h/kernel"], w["dense_h/bias"], u.gamma, u.beta,
+                                     u.epsilon, rows=rows)
+            else:
+                h = br["update"][i]([h, agg])
             if trace is not None:
                 trace[f"{prefix}/m{i}"], trace[f"{prefix}/agg{i}"], trace[f"{prefix}/h{i + 1}"] = m, agg, h
         pooled = br["pool"]([h, atom_ids])

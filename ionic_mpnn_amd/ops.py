@@ -228,8 +228,29 @@ def bmm_fused(h, bond_state, conn, W):
     return agg
 
 
-def gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps=LN_EPS):
-    """GatedUpdate.call, models/layers.py:142-156."""
+def kept_row_index(atom_ids, bond_ids, conn, Vb):
+    """(row_index (B*N,) int32, n_rows (1,) int32) of the rows an encode() loop has to carry: molecule b's rows
+    [0, r_b) as flat indices b*N + n (impnn_kept_rows + impnn_row_index_fill; the prefix sum in between is
+    torch.cumsum).  Everything stays on the device."""
+    require_gpu(atom_ids, bond_ids, conn)
+    atom_ids, bond_ids, conn = i32c(atom_ids), i32c(bond_ids), i32c(conn)
+    B, N = atom_ids.shape
+    E = conn.shape[1]
+    dev = atom_ids.device
+    r = torch.empty(B, dtype=torch.int32, device=dev)
+    idx = torch.empty(max(B * N, 1), dtype=torch.int32, device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        check(lib.impnn_kept_rows(ptr(atom_ids), ptr(bond_ids), ptr(conn), ptr(r), B, N, E, int(Vb), stream_ptr()))
+        incl = torch.cumsum(r, 0, dtype=torch.int32)
+        check(lib.impnn_row_index_fill(ptr(r), ptr(incl), ptr(idx), ptr(cnt), B, N, stream_ptr()))
+    return idx, cnt
+
+
+def gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps=LN_EPS, rows=None):
+    """GatedUpdate.call, models/layers.py:142-156.  ``rows`` = (row_index, n_rows) of kept_row_index: only those rows
+    of the output are computed (model-internal use: padding atoms; the rest of ``out`` is undefined)."""
     if _wants_grad(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta):
         from . import autograd
         return autograd.GatedUpdate.apply(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps)
@@ -242,9 +263,13 @@ def gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps=LN_EPS):
             raise ValueError(f"{name} kernel must be (2D,D)=({2 * D},{D}), got {tuple(w.shape)}")
     ts = [f32c(t) for t in (h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta)]
     out = torch.empty_like(ts[0])
-    rows = ts[0].numel() // D
+    nrows = ts[0].numel() // D
     with torch.cuda.device(h.device):
-        check(_lib.load().impnn_gated_update(*[ptr(t) for t in ts], float(eps), ptr(out), rows, D, stream_ptr()))
+        if rows is not None and D in (64, 128):
+            check(_lib.load().impnn_gated_update_rows(*[ptr(t) for t in ts], float(eps), ptr(out), ptr(rows[0]),
+                                                      ptr(rows[1]), nrows, D, stream_ptr()))
+        else:
+            check(_lib.load().impnn_gated_update(*[ptr(t) for t in ts], float(eps), ptr(out), nrows, D, stream_ptr()))
     return out
 
 

@@ -243,3 +243,38 @@ def test_reduce_small_batch_kernel_is_bitwise_the_large_batch_kernel(D, N, E):
             if 0 < t < N:
                 ref[b, t] += mh[b, e]
     np.testing.assert_array_equal(small.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_gated_update_on_kept_rows_only(D):
+    """impnn_kept_rows / impnn_row_index_fill / impnn_gated_update_rows (the model's layered path at wide states):
+    the row list is exactly the encoder's kept rows, the listed rows equal the full GatedUpdate bit for bit, every
+    other row of the output is left alone."""
+    import numpy as np
+    from ionic_mpnn_amd import synthetic
+    B, N, E, Vb = 37, 24, 40, 9
+    inp = synthetic.make_batch(B, max_atoms=N, max_edges=E, atom_vocab_size=12, bond_vocab_size=Vb, min_atoms=3, seed=D)
+    ids, bond, conn = (torch.from_numpy(inp[k]).to(DEV) for k in ("cat_atom", "cat_bond", "cat_connectivity"))
+    idx, cnt = ops.kept_row_index(ids, bond, conn, Vb)
+    # host model of the rule: r_b = 1 + max(last n with id > 0, largest index on a valid edge)
+    want = []
+    for b in range(B):
+        r = int(np.max(np.nonzero(inp["cat_atom"][b])[0], initial=-1)) + 1
+        c = inp["cat_connectivity"][b]
+        ok = (c[:, 0] > 0) & (c[:, 1] > 0)
+        if ok.any():
+            r = max(r, int(c[ok].max()) + 1)
+        want += [b * N + n for n in range(r)]
+    n = int(cnt.item())
+    assert n == len(want) and idx[:n].cpu().tolist() == want
+    g = torch.Generator().manual_seed(D)
+    h, agg = torch.randn(B, N, D, generator=g).to(DEV), torch.randn(B, N, D, generator=g).to(DEV)
+    W = [(torch.randn(2 * D, D, generator=g) / (2 * D) ** 0.5).to(DEV), torch.randn(D, generator=g).to(DEV) * 0.1,
+         (torch.randn(2 * D, D, generator=g) / (2 * D) ** 0.5).to(DEV), torch.randn(D, generator=g).to(DEV) * 0.1,
+         (torch.randn(2 * D, D, generator=g) / (2 * D) ** 0.5).to(DEV), torch.randn(D, generator=g).to(DEV) * 0.1,
+         torch.rand(D, generator=g).to(DEV) + 0.5, torch.randn(D, generator=g).to(DEV) * 0.1]
+    full = ops.gated_update(h, agg, *W)
+    part = ops.gated_update(h, agg, *W, rows=(idx, cnt))
+    keep = torch.zeros(B * N, dtype=torch.bool, device=DEV)
+    keep[idx[:n].long()] = True
+    assert torch.equal(part.reshape(B * N, D)[keep], full.reshape(B * N, D)[keep])
