@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--ramp-ms", type=float, default=150.0,
                     help="untimed clock ramp before the W warm-up steps: the same step() repeated for this many "
                          "milliseconds (0 disables)")
-    ap.add_argument("--mode", choices=["auto", "f32t", "f32", "f16x2"], default="auto",
+    ap.add_argument("--mode", choices=["auto", "f32t", "f32x3", "f32", "f16x2"], default="auto",
                     help="schedule / arithmetic of the fused encoder (include/impnn.h); auto = exact f32: the "
                          "per-bond-type form f32t, else the pull form f32.  f16x2 (narrower products) on request only")
     args = ap.parse_args()
@@ -338,7 +338,7 @@ def main():
             # labelled extras: the other encoder modes on the same batch, single stream, with their own error against
             # the timed mode's result (never `value`: "f16x2" is narrower arithmetic than the reference's f32)
             ref_c, ref_a = m.encode_pooled(d_in, fused=True)
-            for other in ("f32", "f16x2"):
+            for other in ("f32t", "f32x3", "f32", "f16x2"):
                 if other == mode_used:
                     continue
                 m.encoder_mode = other
@@ -379,19 +379,24 @@ def main():
         last_e = np.where(ok, conn.max(axis=2) + 1, 0).max(axis=1)
         kept_rows += int(np.maximum(last_id, last_e).sum())
         valid_edges += int(ok.sum())
-    msg_flops = 2 * D * D * valid_edges if mode_used == "f32t" else 2 * K * D * D * kept_rows
+    msg_flops = 2 * D * D * valid_edges if mode_used in ("f32t", "f32x3") else 2 * K * D * D * kept_rows
     executed_flops = S * (12 * D * D * kept_rows + msg_flops)
     arith = {"f16x2": "f32 in/out/accumulate; every f32 GEMM product formed from fp16 hi/lo splits (3 "
                       "v_mfma_f32_16x16x32_f16 per f32 product, product error ~2^-21: NARROWER than the reference's f32)",
              "f32": "exact f32 products on v_mfma_f32_16x16x4_f32 (pull form: agg = sum_k W_k G_k)",
              "f32t": "exact f32 products: per-bond-type messages (models/layers.py:108-112 in the reference's own order) "
                      "on v_mfma_f32_4x4x1_16b_f32, GatedUpdate on v_mfma_f32_16x16x4_f32; f32 accumulate, f32 in/out",
+             "f32x3": "as f32t, with the GatedUpdate GEMMs on the bf16 matrix pipe: every f32 operand carried exactly as three "
+                      "bf16 terms, all nine cross products accumulated in f32 (9 v_mfma_f32_16x16x32_bf16 per 8 f32 MFMAs) - "
+                      "the f32 products themselves, summed in another order; opt-in, not the default",
              "layered": "f32, one launch per reference layer"}[mode_used]
     out = {
         "metric": "molecule-graph pairs/sec (fwd), batch 4096 per MI355X",  # BASELINE.json's metric; 1 pair = 2 graphs
         "value": value, "unit": "graph-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if mode_used != "f16x2" else "f16x2 (split-fp16 products, f32 accumulate)", "data": "synthetic",
+        "dtype": {"f16x2": "f16x2 (split-fp16 products, f32 accumulate)",
+                  "f32x3": "f32 (GatedUpdate products as exact bf16x3 triples on the bf16 pipe, f32 accumulate)"}.get(mode_used, "f32"),
+        "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[1]: message-passing forward (embedding gather -> {S}x"
                                f"(BondMatrixMessage, Reduce, GatedUpdate) -> GlobalSumPool), cation+anion, synthetic "
                                f"padded graphs N<={N} E<={E}, D={D}, K={K}, batch {B} pairs/GPU, schedule={args.schedule}",
@@ -430,10 +435,14 @@ def main():
         # SURVEY 8(d) algorithmic flops; f16x2 -> its executed fp16 MFMA flops (3 per f32 product) against 2.5 PFLOP/s
         if mode_used == "f16x2":
             flops_for_frac, peak, what = 3.0 * executed_flops, PEAK_F16_MFMA_TFLOPS, "executed fp16 MFMA flops (3 per f32 product)"
+        elif mode_used == "f32x3":
+            flops_for_frac, peak, what = (9.0 * S * 12 * D * D * kept_rows, PEAK_F16_MFMA_TFLOPS,
+                                          "executed bf16 MFMA flops of the GatedUpdate GEMMs (9 per f32 product; the "
+                                          "messages run beside them on the f32 pipe)")
         else:
             flops_for_frac, peak, what = float(flops_launch), PEAK_F32_MFMA_TFLOPS, "SURVEY 8(d) algorithmic f32 flops"
         ach = flops_for_frac / (k_ms * 1e-3) / 1e12
-        kname = "encoder_typed_kernel" if mode_used == "f32t" else "encoder_fused_kernel"
+        kname = "encoder_typed_kernel" if mode_used in ("f32t", "f32x3") else "encoder_fused_kernel"
         out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                            "frac": ach / peak, "traffic": pmc_field("hbm_bytes_per_launch", kname),
                            "kernel_ms": k_ms,

@@ -144,6 +144,11 @@ int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, i
  *                                 A[v] = sum_k bond_table[v,k] W[k], on v_mfma_f32_4x4x1_16b_f32, exact f32 products;
  *                                 in-edge messages summed in edge-slot order.  atom_dim 32, ANY bond_dim (K = D^2 of
  *                                 train_melting_point.py:146 included), Vb <= 256, E <= 255.
+ *    IMPNN_ENCODER_F32X3_TYPED (3): mode 2 with the GatedUpdate GEMMs on the bf16 matrix pipe: every f32 operand is carried
+ *                                 EXACTLY as three bf16 terms (3 x 8 significant bits, fp32's exponent range) and all nine
+ *                                 cross products are accumulated in f32 (9 x v_mfma_f32_16x16x32_bf16 per 8 f32 MFMAs):
+ *                                 the products are the f32 products, only their summation order differs.  Messages
+ *                                 stay on the f32 4x4x1 MFMA.  Same records, prepared buffer of its own.  Opt-in.
  *  `workgroups` - persistent workgroups of the launch: 0 = default (environment IMPNN_ENCODER_WORKGROUPS if set, else
  *  one per compute unit), n = min(max(n, 16), CUs).  It fixes the workspace layout, so the size query, the plan and
  *  the run of one batch must agree - impnn_encoder_plan returns what it used in its plan info and impnn_encoder_run
@@ -152,6 +157,7 @@ int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, i
 #define IMPNN_ENCODER_F32 0
 #define IMPNN_ENCODER_F16X2 1
 #define IMPNN_ENCODER_F32_TYPED 2
+#define IMPNN_ENCODER_F32X3_TYPED 3
 int64_t impnn_encoder_step_floats(int32_t D, int32_t K);
 int impnn_encoder_workspace_bytes(int32_t n_ions, int32_t B, int32_t N, int32_t E, int32_t D,
                                   int32_t K, int32_t S, int32_t Vb, int32_t mode, int32_t workgroups,
@@ -246,7 +252,7 @@ int impnn_model_head_loss_bwd(int32_t kind, const float* pooled_cat, const float
  *      order the two with events; every batch in flight needs its own workspace.
  *      impnn_encoder_plan fills `info` (host memory, plain data) with the shape, record kind and workgroup count
  *      it planned for; impnn_encoder_run takes its launch geometry from `info` and returns IMPNN_E_BADARG when its
- *      own shape arguments or the record kind of `mode` (modes 0/1 share one, mode 2 has its own) differ.  The
+ *      own shape arguments or the record kind of `mode` (modes 0/1 share one, modes 2/3 share the other) differ.  The
  *      workspace itself starts with the same facts (device side): an encoder kernel that finds a plan made for
  *      another geometry writes NaN to `pooled` instead of reading records at wrong offsets.
  *      impnn_encoder_fused_prepared(...) == impnn_encoder_plan(...) then impnn_encoder_run(...). */

@@ -174,7 +174,7 @@ int64_t impnn_encoder_step_floats(int32_t D, int32_t K) {
 namespace {
 constexpr int32_t kInfoMagic = 0x706c616e;  // "plan"
 // impnn_encoder_plan_info.v: magic, mode class (0 pull records / 1 typed records), n_ions, B, N, E, S, Vb, nwg
-inline int mode_class(int mode) { return mode == 2 ? 1 : 0; }
+inline int mode_class(int mode) { return mode >= 2 ? 1 : 0; }
 }  // namespace
 
 int impnn_encoder_workspace_bytes(int32_t n_ions, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K,
@@ -182,7 +182,7 @@ int impnn_encoder_workspace_bytes(int32_t n_ions, int32_t B, int32_t N, int32_t 
   REQUIRE(bytes, "null pointer");
   REQUIRE(n_ions >= 1 && n_ions <= 2 && B >= 0 && N > 0 && E >= 0 && D > 0 && K > 0 && S >= 0 && Vb > 0,
           "bad shape");
-  REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (f32), 1 (f16x2) or 2 (f32 typed)");
+  REQUIRE(mode >= 0 && mode <= 3, "mode must be 0 (f32), 1 (f16x2), 2 (f32 typed) or 3 (f32x3 typed)");
   REQUIRE(workgroups >= 0, "workgroups must be >= 0 (0: default)");
   if (!encoder_fused_supported(mode, N, E, D, K, S, Vb))
     return fail(IMPNN_E_UNSUPPORTED, "encoder_fused: mode=%d shape N=%d E=%d D=%d K=%d S=%d Vb=%d not covered", mode,
@@ -203,7 +203,7 @@ static int encoder_common(const char* fn, int32_t n_ions, const int32_t* const* 
     if (!(cond)) return fail(IMPNN_E_BADARG, "%s: %s", fn, what); \
   } while (0)
   REQ(n_ions >= 1 && n_ions <= 2, "n_ions must be 1 or 2");
-  REQ(mode >= 0 && mode <= 2, "mode must be 0 (f32), 1 (f16x2) or 2 (f32 typed)");
+  REQ(mode >= 0 && mode <= 3, "mode must be 0 (f32), 1 (f16x2), 2 (f32 typed) or 3 (f32x3 typed)");
   REQ(workgroups >= 0, "workgroups must be >= 0 (0: default)");
   REQ(B >= 0 && N > 0 && E >= 0 && D > 0 && K > 0 && S >= 0 && Va > 0 && Vb > 0, "bad shape");
   const bool planning = (phases & 1) != 0, running = (phases & 2) != 0;
@@ -292,7 +292,7 @@ int impnn_encoder_run(int32_t n_ions, const int32_t* const* atom_ids, const floa
 }
 
 size_t impnn_encoder_prepared_bytes(int32_t S, int32_t Vb, int32_t mode) {
-  if (mode < 0 || mode > 2 || Vb <= 0) return 0;
+  if (mode < 0 || mode > 3 || Vb <= 0) return 0;
   return encoder_prepared_bytes(mode, S, Vb);
 }
 
@@ -300,11 +300,11 @@ int impnn_encoder_prepare_weights(const float* weights, const float* bond_table,
                                   int32_t Vb, int32_t mode, void* prepared, size_t prepared_bytes,
                                   impnn_stream_t stream) {
   REQUIRE(D > 0 && K > 0 && S >= 0 && Vb > 0, "bad shape");
-  REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (f32), 1 (f16x2) or 2 (f32 typed)");
-  if (!encoder_fused_supported(mode, 1, 0, D, K, S, mode == 2 ? Vb : 1))
+  REQUIRE(mode >= 0 && mode <= 3, "mode must be 0 (f32), 1 (f16x2), 2 (f32 typed) or 3 (f32x3 typed)");
+  if (!encoder_fused_supported(mode, 1, 0, D, K, S, mode >= 2 ? Vb : 1))
     return fail(IMPNN_E_UNSUPPORTED, "encoder_prepare_weights: mode=%d D=%d K=%d Vb=%d not covered", mode, D, K, Vb);
   if (S == 0) return IMPNN_OK;
-  REQUIRE(weights && prepared && (mode != 2 || bond_table), "null pointer");
+  REQUIRE(weights && prepared && (mode < 2 || bond_table), "null pointer");
   REQUIRE(aligned16(prepared), "prepared buffer must be 16B aligned");
   if (prepared_bytes < encoder_prepared_bytes(mode, S, Vb))
     return fail(IMPNN_E_WORKSPACE, "encoder_prepare_weights: buffer %zu < %zu bytes", prepared_bytes,

@@ -518,14 +518,14 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_fused_kernel
 }  // namespace enc
 
 bool encoder_typed_supported(int N, int E, int D, int S, int Vb);
-size_t encoder_typed_prepared_bytes(int S, int Vb);
-int launch_encoder_typed_prepare(const float* weights, const float* bond_table, int K, int S, int Vb, void* prepared,
-                                 hipStream_t s);
+size_t encoder_typed_prepared_bytes(int S, int Vb, bool x3);
+int launch_encoder_typed_prepare(const float* weights, const float* bond_table, int K, int S, int Vb, bool x3,
+                                 void* prepared, hipStream_t s);
 int launch_encoder_typed_run(const EncoderArgs& a, const enc::Ws& w, hipStream_t s);
 
 bool encoder_fused_supported(int mode, int N, int E, int D, int K, int S, int Vb) {
   using namespace enc;
-  if (mode == 2) return K >= 1 && encoder_typed_supported(N, E, D, S, Vb);
+  if (mode == 2 || mode == 3) return K >= 1 && encoder_typed_supported(N, E, D, S, Vb);
   if (mode != 0 && mode != 1) return false;
   if (D != kD || K < 1 || K > kKMax || S < 0) return false;
   if (N < 1 || N > 0xffff || E < 0) return false;
@@ -580,18 +580,18 @@ int encoder_workgroups(int n_ions, int B, int requested) {
 }
 
 size_t encoder_fused_workspace_bytes(int mode, int n_ions, int B, int N, int E, int S, int Vb, int nwg) {
-  return enc::ws_layout(n_ions, B, N, E, S, Vb, nwg, mode == 2).total;
+  return enc::ws_layout(n_ions, B, N, E, S, Vb, nwg, mode >= 2, mode == 3).total;
 }
 
 size_t encoder_prepared_bytes(int mode, int S, int Vb) {
-  if (mode == 2) return encoder_typed_prepared_bytes(S, Vb);
+  if (mode >= 2) return encoder_typed_prepared_bytes(S, Vb, mode == 3);
   return (size_t)(S > 0 ? S : 1) * enc::kImgSlot * sizeof(float);
 }
 
 int launch_encoder_prepare(const float* weights, const float* bond_table, int D, int K, int S, int Vb, int mode,
                            void* prepared, hipStream_t s) {
   if (S <= 0) return IMPNN_OK;
-  if (mode == 2) return launch_encoder_typed_prepare(weights, bond_table, K, S, Vb, prepared, s);
+  if (mode >= 2) return launch_encoder_typed_prepare(weights, bond_table, K, S, Vb, mode == 3, prepared, s);
   enc::ImageParams ip{};
   ip.weights = weights;
   ip.img = static_cast<float*>(prepared);
@@ -612,8 +612,8 @@ int launch_encoder_fused(const EncoderArgs& a, hipStream_t s) {
 // a.nwg: the resolved workgroup count (encoder_workgroups) - the same value for the plan and the run of a batch.
 int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
   using namespace enc;
-  const bool typed = a.mode == 2;
-  const Ws w = ws_layout(a.n_ions, a.B, a.N, a.E, a.S, a.Vb, a.nwg, typed);
+  const bool typed = a.mode >= 2;
+  const Ws w = ws_layout(a.n_ions, a.B, a.N, a.E, a.S, a.Vb, a.nwg, typed, a.mode == 3);
   if (!aligned16(a.workspace)) return fail(IMPNN_E_BADARG, "encoder_fused: workspace must be 16B aligned");
   if (!plan_phase && !aligned16(a.atom_table)) return fail(IMPNN_E_BADARG, "encoder_fused: atom_table must be 16B aligned");
   char* base = static_cast<char*>(a.workspace);

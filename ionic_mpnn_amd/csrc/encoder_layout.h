@@ -99,14 +99,24 @@ constexpr int kTUpdFloats = 3 * kD * kUpdRS + 5 * kD;  // 6688
 constexpr int kTUpdSlot = 2 * kThreads * 4;             // 8192 floats
 constexpr int kTUpdLds = 6912;                          // floats kept in LDS (>= kTUpdFloats, multiple of 128)
 static_assert(kTUpdFloats <= kTUpdLds && kTUpdLds <= kTUpdSlot, "typed update image");
+// mode 3 ("f32x3"): the update GEMMs on the bf16 matrix pipe with every f32 operand carried EXACTLY as three bf16 terms
+// (x = b0 + b1 + b2: 3 x 8 significant bits, fp32's exponent range) and all nine cross products accumulated in f32.
+// Image: 12 blocks (gate, T, half) x 3 planes x 512 bf16 in MFMA A-operand order (feat_of, as the f16x2 image), then
+// the 5 f32 vectors.
+constexpr int kXUpdHalfs = 3 * 2 * 2 * 3 * 512;               // 18432 bf16 = 36 KB
+constexpr int kXVecFloatOff = kXUpdHalfs / 2;                  // 9216
+constexpr int kXUpdFloats = kXVecFloatOff + 5 * kD;            // 9376
+constexpr int kXUpdSlot = 3 * kThreads * 4;                    // 12288 floats: three 16-byte loads per thread
+constexpr int kXUpdLds = 9472;                                 // floats kept in LDS
+static_assert(kXUpdFloats <= kXUpdLds && kXUpdLds <= kXUpdSlot, "x3 update image");
 // type matrices of one (ion, step): Vb x 1024 floats, each in 4x4x1-MFMA B-operand order:
 //   A[v][r][k] at v*1024 + (k >> 2)*128 + r*4 + (k & 3)   (lane l loads the 4 k-quads 4*(l >> 5) + i of row l & 31:
 //   a wave's load i is two contiguous 512 B runs)
 constexpr int kTMatFloats = kD * kD;
 // prepared buffer of one ion: S update slots | S x Vb type matrices | one canonical (Vb,32,32) scratch
-inline size_t typed_prepared_floats(int S, int Vb) {
+inline size_t typed_prepared_floats(int S, int Vb, bool x3 = false) {
   const size_t s = S > 0 ? S : 1;
-  return s * kTUpdSlot + s * (size_t)Vb * kTMatFloats + (size_t)Vb * kTMatFloats;
+  return s * (x3 ? kXUpdSlot : kTUpdSlot) + s * (size_t)Vb * kTMatFloats + (size_t)Vb * kTMatFloats;
 }
 
 // chunk descriptor (int4): {first molecule, molecules, 0, rows | ion << 16}
@@ -135,7 +145,7 @@ struct PlanHeader {
 };
 constexpr int32_t kPlanMagic = 0x696d706e;  // "impn"
 
-inline Ws ws_layout(int n_ions, int B, int N, int E, int S, int Vb, int nwg, bool typed) {
+inline Ws ws_layout(int n_ions, int B, int N, int E, int S, int Vb, int nwg, bool typed, bool x3 = false) {
   Ws w{};
   const int vrmax = vr_max_of(N, E, typed);
   w.rec_bytes = typed ? kTRecBytes : kRecBytes;
@@ -147,7 +157,7 @@ inline Ws ws_layout(int n_ions, int B, int N, int E, int S, int Vb, int nwg, boo
   w.max_sub = (int)(share_rows / win) + 2;
   size_t off = 256;  // plan header
   w.img_off = off;
-  off = align_up(off + (typed ? (size_t)n_ions * typed_prepared_floats(S, Vb)
+  off = align_up(off + (typed ? (size_t)n_ions * typed_prepared_floats(S, Vb, x3)
                               : (size_t)n_ions * (S > 0 ? S : 1) * kImgSlot) * sizeof(float), 256);
   w.rows_off = off;
   off = align_up(off + (size_t)n_ions * B * sizeof(int32_t), 256);
@@ -210,8 +220,8 @@ struct EncParams {
 struct TImageParams {
   const float* weights;  // S steps, canonical layout
   const float* bond_table;
-  float* prepared;       // typed_prepared_floats(S, Vb)
-  int K, S, Vb;
+  float* prepared;       // typed_prepared_floats(S, Vb, x3)
+  int K, S, Vb, x3;
   int64_t step_floats;
 };
 
@@ -226,6 +236,7 @@ struct TEncParams {
   const PlanHeader* header;
   int n_ions, B, S, Va, Vb, max_sub;
   int atab_lds;
+  int upd_slot;  // floats between the update images of consecutive steps (kTUpdSlot or kXUpdSlot)
   float ln_eps;
   unsigned long long* stamps;
 };

@@ -183,9 +183,10 @@ __global__ void weight_image_kernel(ImageParams p) {
 __global__ void typed_image_kernel(TImageParams p, int s) {
   const int t_begin = blockIdx.x * blockDim.x + threadIdx.x, t_stride = gridDim.x * blockDim.x;
   const int S = p.S > 0 ? p.S : 1;
-  float* upd = p.prepared + (size_t)s * kTUpdSlot;
-  float* tmat = p.prepared + (size_t)S * kTUpdSlot + (size_t)s * p.Vb * kTMatFloats;
-  const float* canon = p.prepared + (size_t)S * kTUpdSlot + (size_t)S * p.Vb * kTMatFloats;
+  const size_t uslot = p.x3 ? kXUpdSlot : kTUpdSlot;
+  float* upd = p.prepared + (size_t)s * uslot;
+  float* tmat = p.prepared + (size_t)S * uslot + (size_t)s * p.Vb * kTMatFloats;
+  const float* canon = p.prepared + (size_t)S * uslot + (size_t)S * p.Vb * kTMatFloats;
   const float* w = p.weights + (int64_t)s * p.step_floats;
   const float* Wz = w + (int64_t)p.K * kD * kD;  // (64,32)
   const float* bz = Wz + 2 * kD * kD;
@@ -200,6 +201,36 @@ __global__ void typed_image_kernel(TImageParams p, int s) {
     // destination index: v*1024 + kq*128 + r*4 + c   <-  A[v][r][4*kq + c]
     const int v = t >> 10, rem = t & 1023, kq = rem >> 7, r = (rem >> 2) & 31, c = rem & 3;
     tmat[t] = canon[(size_t)v * kTMatFloats + r * kD + 4 * kq + c];
+  }
+  if (p.x3) {  // mode 3: the gate kernels as three bf16 planes (w = b0 + b1 + b2 exactly), MFMA A-operand order
+    unsigned short* planes = reinterpret_cast<unsigned short*>(upd);
+    for (int t = t_begin; t < kXUpdHalfs / 3; t += t_stride) {
+      // t = (blk * 64 + lane) * 8 + j,  blk = (gate*2 + T)*2 + half; value W_gate[(32 half + feat_of(q, j)) * 32 + 16 T + i]
+      const int j = t & 7, ln = (t >> 3) & 63, blk = t >> 9;
+      const int q = ln >> 4, i = ln & 15, f = feat_of(q, j);
+      const int half = blk & 1, T = (blk >> 1) & 1, gate = blk >> 2;
+      const float* Wg = gate == 0 ? Wz : (gate == 1 ? Wr : Wh);
+      const float wv = Wg[(int64_t)(half * kD + f) * kD + 16 * T + i];
+      const unsigned u0 = __float_as_uint(wv) & 0xffff0000u;
+      const float r1 = wv - __uint_as_float(u0);
+      const unsigned u1 = __float_as_uint(r1) & 0xffff0000u;
+      const float r2 = r1 - __uint_as_float(u1);
+      const unsigned u2 = __float_as_uint(r2);  // <= 8 significant bits left: its low half is zero
+      const int base = (blk * 3) * 512 + ln * 8 + j;
+      planes[base] = (unsigned short)(u0 >> 16);
+      planes[base + 512] = (unsigned short)(u1 >> 16);
+      planes[base + 1024] = (unsigned short)(u2 >> 16);
+    }
+    for (int t = t_begin; t < kXUpdSlot - kXVecFloatOff; t += t_stride) {
+      float val = 0.f;
+      if (t < 5 * kD) {
+        const int v = t / kD, i = t - v * kD;
+        const float* src = v == 0 ? bz : v == 1 ? br : v == 2 ? bh : v == 3 ? gamma : beta;
+        val = src[i];
+      }
+      upd[kXVecFloatOff + t] = val;
+    }
+    return;
   }
   constexpr int nupd = 3 * kD * kUpdRS;
   for (int t = t_begin; t < kTUpdSlot; t += t_stride) {
@@ -758,7 +789,7 @@ int launch_weight_image(const ImageParams& ip, int S, hipStream_t s) {
 
 int launch_typed_image(const TImageParams& ip, hipStream_t s) {
   const int S = ip.S > 0 ? ip.S : 1;
-  float* canon = ip.prepared + (size_t)S * kTUpdSlot + (size_t)S * ip.Vb * kTMatFloats;
+  float* canon = ip.prepared + (size_t)S * (ip.x3 ? kXUpdSlot : kTUpdSlot) + (size_t)S * ip.Vb * kTMatFloats;
   for (int st = 0; st < ip.S; ++st) {
     if (int rc = launch_bond_type_matrices(ip.bond_table, ip.weights + (int64_t)st * ip.step_floats, canon, ip.Vb, ip.K,
                                            kD, s))

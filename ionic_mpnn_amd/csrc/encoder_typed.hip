@@ -41,23 +41,80 @@ __device__ __forceinline__ f32x4 any4() {
 }
 
 constexpr int kOffUpd = 0;
-constexpr int kOffH = kOffUpd + kTUpdLds;
-constexpr int kOffMsg = kOffH + kRCap * kHS;
-constexpr int kOffRec = kOffMsg + kTMsgFloats;
-constexpr int kOffTab = kOffRec + kTRecBytes / 4;
-constexpr size_t kTLdsFixedBytes = sizeof(float) * (size_t)kOffTab;
-static_assert(kTLdsFixedBytes <= 160 * 1024, "LDS budget");
-static_assert(kTRecBytes == 12 * kThreads, "record prefetch: 8 + 4 bytes per thread");
+constexpr int off_h(bool x3) { return kOffUpd + (x3 ? kXUpdLds : kTUpdLds); }
+constexpr int off_msg(bool x3) { return off_h(x3) + kRCap * kHS; }
+constexpr int off_rec(bool x3) { return off_msg(x3) + kTMsgFloats; }
+constexpr int off_tab(bool x3) { return off_rec(x3) + kTRecBytes / 4; }
+constexpr size_t lds_fixed_bytes(bool x3) { return sizeof(float) * (size_t)off_tab(x3); }
+static_assert(lds_fixed_bytes(true) <= 160 * 1024, "LDS budget");
 
-template <bool STAMPS>
+// ---- mode 3 ("f32x3"): f32 GEMM products on the bf16 matrix pipe without narrowing them.  An f32 value is the exact
+// sum of three bf16 terms (bf16 keeps fp32's exponent; 3 x 8 significant bits): b0 = the upper half of the word, b1 =
+// the upper half of the exact residual x - b0, b2 = what is left (<= 8 bits).  All nine cross products of two such
+// triples are exact in the MFMA's f32 accumulator, so a GEMM differs from the f32-MFMA one only in the order the
+// (exact) products are added.  v_mfma_f32_16x16x32_bf16 is 16 cycles for 32 k; nine of them replace eight
+// v_mfma_f32_16x16x4_f32 of 32 cycles - on a pipe that, unlike the f32 one, co-executes with the VALU.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct B3 {
+  bf16x8 p0, p1, p2;
+};
+// two values -> their three packed bf16 pairs (5.5 VALU per value: and, sub, and, sub per value; three perms per pair)
+__device__ __forceinline__ void split_pair(float x, float y, unsigned& w0, unsigned& w1, unsigned& w2) {
+  const unsigned xb = __builtin_bit_cast(unsigned, x), yb = __builtin_bit_cast(unsigned, y);
+  const float x1 = x - __builtin_bit_cast(float, xb & 0xffff0000u), y1 = y - __builtin_bit_cast(float, yb & 0xffff0000u);
+  const unsigned x1b = __builtin_bit_cast(unsigned, x1), y1b = __builtin_bit_cast(unsigned, y1);
+  const float x2 = x1 - __builtin_bit_cast(float, x1b & 0xffff0000u), y2 = y1 - __builtin_bit_cast(float, y1b & 0xffff0000u);
+  // pack the upper halves: low 16 bits <- x, high 16 bits <- y   (v_perm_b32: bytes [y3 y2 x3 x2])
+  w0 = __builtin_amdgcn_perm(yb, xb, 0x07060302u);
+  w1 = __builtin_amdgcn_perm(y1b, x1b, 0x07060302u);
+  w2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, y2), __builtin_bit_cast(unsigned, x2), 0x07060302u);
+}
+__device__ __forceinline__ B3 split8x3(f32x4 a, f32x4 b) {
+  union {
+    bf16x8 v;
+    unsigned u[4];
+  } q0, q1, q2;
+  split_pair(a[0], a[1], q0.u[0], q1.u[0], q2.u[0]);
+  split_pair(a[2], a[3], q0.u[1], q1.u[1], q2.u[1]);
+  split_pair(b[0], b[1], q0.u[2], q1.u[2], q2.u[2]);
+  split_pair(b[2], b[3], q0.u[3], q1.u[3], q2.u[3]);
+  B3 r;
+  r.p0 = q0.v;
+  r.p1 = q1.v;
+  r.p2 = q2.v;
+  return r;
+}
+__device__ __forceinline__ f32x4 mfmab(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// acc += W (three planes at blk, blk + 512, blk + 1024) * b: all nine cross products, smallest first.
+// (Alternating two accumulators over the nine products was measured: 31 spilled VGPRs, slower.)
+__device__ __forceinline__ void mma9(f32x4& acc, const __bf16* blk, int lane, const B3& b) {
+  const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(blk + lane * 8);
+  const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(blk + 512 + lane * 8);
+  const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(blk + 1024 + lane * 8);
+  acc = mfmab(a2, b.p2, acc);
+  acc = mfmab(a1, b.p2, acc);
+  acc = mfmab(a2, b.p1, acc);
+  acc = mfmab(a0, b.p2, acc);
+  acc = mfmab(a2, b.p0, acc);
+  acc = mfmab(a1, b.p1, acc);
+  acc = mfmab(a0, b.p1, acc);
+  acc = mfmab(a1, b.p0, acc);
+  acc = mfmab(a0, b.p0, acc);
+}
+
+template <bool STAMPS, bool X3>
 __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel(TEncParams p) {
   extern __shared__ __align__(16) float smem[];
+  constexpr int kUpdLds = X3 ? kXUpdLds : kTUpdLds, kUpdSlot = X3 ? kXUpdSlot : kTUpdSlot;
+  constexpr int kNPf = X3 ? 3 : 2;  // 16-byte loads per thread that carry one update image
   float* const wupd = smem + kOffUpd;
-  float* const wvec = wupd + 3 * kD * kUpdRS;
-  float* const hbuf = smem + kOffH;
-  float* const msg = smem + kOffMsg;
-  unsigned char* const recl = reinterpret_cast<unsigned char*>(smem + kOffRec);
-  float* const atab = smem + kOffTab;  // Va rows + one zero row at the h buffer's stride (when it fits)
+  float* const wvec = wupd + (X3 ? kXVecFloatOff : 3 * kD * kUpdRS);
+  float* const hbuf = smem + off_h(X3);
+  float* const msg = smem + off_msg(X3);
+  unsigned char* const recl = reinterpret_cast<unsigned char*>(smem + off_rec(X3));
+  float* const atab = smem + off_tab(X3);  // Va rows + one zero row at the h buffer's stride (when it fits)
   const uint16_t* const r_rowdeg = reinterpret_cast<const uint16_t*>(recl + kTRecRowdeg);
   const unsigned char* const r_tilemax = recl + kTRecTilemax;
   const uint16_t* const r_moloff = reinterpret_cast<const uint16_t*>(recl + kTRecMoloff);
@@ -126,11 +183,11 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
       rec_n4 = reinterpret_cast<const uint32_t*>(rn + 8 * kThreads)[tid];
       dsc_next = reinterpret_cast<const int4*>(p.desc)[cn];
     }
-    f32x4 pf0, pf1;
+    f32x4 pf[kNPf];
     const bool need_image = p.S > 0 && !image_ready;  // workgroup-uniform
     if (need_image) {
-      pf0 = ld4(upd_g + 4 * tid);
-      pf1 = ld4(upd_g + 4 * (tid + kThreads));
+#pragma unroll
+      for (int i = 0; i < kNPf; ++i) pf[i] = ld4(upd_g + 4 * (tid + i * kThreads));
     }
     lds_barrier();
     if (!p.atab_lds || p.S == 0) {  // 4 threads per placed row, 2 x 16 B each; slack rows: zeros
@@ -150,8 +207,9 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
       st4(hbuf + row * kHS + 8 * sub + 4, v1);
     }
     if (need_image) {
-      st4(wupd + 4 * tid, pf0);
-      if (4 * (tid + kThreads) < kTUpdLds) st4(wupd + 4 * (tid + kThreads), pf1);
+#pragma unroll
+      for (int i = 0; i < kNPf; ++i)
+        if (4 * (tid + i * kThreads) < kUpdLds) st4(wupd + 4 * (tid + i * kThreads), pf[i]);
     }
     image_ready = p.S > 0;
     if (tid == 0) *run_ctr = 0;  // (the record's bytes there are not written by the plan)
@@ -165,7 +223,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
     for (int s = 0; s < p.S; ++s) {
       const bool g0 = p.atab_lds && s == 0;  // step 0 reads h0 = atom_table[id] straight from the LDS table
       const int sn = (s + 1) < p.S ? (s + 1) : 0;  // the last step fetches the step-0 image for the next chunk
-      const float* nxt = upd_g + (int64_t)sn * kTUpdSlot;
+      const float* nxt = upd_g + (int64_t)sn * kUpdSlot;
       const float* tm_s = tmat_g + (size_t)s * p.Vb * kTMatFloats;
 
       // ---- message phase: m_e = A[type_e] h[src_e], one group of <= 4 edges of one bond type per 16 MFMAs.
@@ -315,14 +373,36 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
         const f32x4 h0 = ld4(smem + own);
         const f32x4 h1 = ld4(smem + own + 16);
         // next step's update image starts its flight now
-        pf0 = ld4(nxt + 4 * tid);
-        pf1 = ld4(nxt + 4 * (tid + kThreads));
+#pragma unroll
+        for (int i = 0; i < kNPf; ++i) pf[i] = ld4(nxt + 4 * (tid + i * kThreads));
         pf_issued = true;
 
         // ---- gates z, r (models/layers.py:144-147) and candidate (:150-151): out^T = W^T [h | agg]^T
         f32x4 z0 = ld4(wvec + 0 * kD + 4 * q), z1 = ld4(wvec + 0 * kD + 16 + 4 * q);
         f32x4 r0 = ld4(wvec + 1 * kD + 4 * q), r1 = ld4(wvec + 1 * kD + 16 + 4 * q);
         f32x4 t0 = ld4(wvec + 2 * kD + 4 * q), t1 = ld4(wvec + 2 * kD + 16 + 4 * q);
+        if constexpr (X3) {
+          const __bf16* wb = reinterpret_cast<const __bf16*>(wupd);  // block ((gate*2 + T)*2 + half): 3 x 512 bf16
+          const B3 sh = split8x3(h0, h1);
+          const B3 sa = split8x3(agg0, agg1);
+          mma9(z0, wb + ((0 * 2 + 0) * 2 + 0) * 1536, lane, sh);
+          mma9(z1, wb + ((0 * 2 + 1) * 2 + 0) * 1536, lane, sh);
+          mma9(r0, wb + ((1 * 2 + 0) * 2 + 0) * 1536, lane, sh);
+          mma9(r1, wb + ((1 * 2 + 1) * 2 + 0) * 1536, lane, sh);
+          mma9(z0, wb + ((0 * 2 + 0) * 2 + 1) * 1536, lane, sa);
+          mma9(z1, wb + ((0 * 2 + 1) * 2 + 1) * 1536, lane, sa);
+          mma9(r0, wb + ((1 * 2 + 0) * 2 + 1) * 1536, lane, sa);
+          mma9(r1, wb + ((1 * 2 + 1) * 2 + 1) * 1536, lane, sa);
+          z0 = sigmoid4<false>(z0);
+          z1 = sigmoid4<false>(z1);
+          const f32x4 rh0 = sigmoid4<false>(r0) * h0;  // :149
+          const f32x4 rh1 = sigmoid4<false>(r1) * h1;
+          const B3 srh = split8x3(rh0, rh1);
+          mma9(t0, wb + ((2 * 2 + 0) * 2 + 0) * 1536, lane, srh);
+          mma9(t1, wb + ((2 * 2 + 1) * 2 + 0) * 1536, lane, srh);
+          mma9(t0, wb + ((2 * 2 + 0) * 2 + 1) * 1536, lane, sa);
+          mma9(t1, wb + ((2 * 2 + 1) * 2 + 1) * 1536, lane, sa);
+        } else {
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -361,6 +441,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
             }
           }
         }
+        }
         __builtin_amdgcn_s_setprio(0);
         // ---- blend, LayerNorm, residual  (models/layers.py:153-155); (1-z) h + z t == h + z (t - h)
         f32x4 n0 = z0 * (tanh4<false>(t0) - h0) + h0;
@@ -385,12 +466,13 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
         st4(hbuf + row * kHS + 16 + 4 * q, o1);
       }
       if (!pf_issued) {  // waves without a tile in this chunk still carry their share of the image
-        pf0 = ld4(nxt + 4 * tid);
-        pf1 = ld4(nxt + 4 * (tid + kThreads));
+#pragma unroll
+        for (int i = 0; i < kNPf; ++i) pf[i] = ld4(nxt + 4 * (tid + i * kThreads));
       }
       __syncthreads();
-      st4(wupd + 4 * tid, pf0);
-      if (4 * (tid + kThreads) < kTUpdLds) st4(wupd + 4 * (tid + kThreads), pf1);
+#pragma unroll
+      for (int i = 0; i < kNPf; ++i)
+        if (4 * (tid + i * kThreads) < kUpdLds) st4(wupd + 4 * (tid + i * kThreads), pf[i]);
       if (stamp && c == c_begin && s < 2 && tid == 0) stamp[14 + s] = __builtin_amdgcn_s_memtime();
     }
     if (stamp && tid == 0) {
@@ -452,10 +534,12 @@ bool encoder_typed_supported(int N, int E, int D, int S, int Vb) {
   return true;
 }
 
-size_t encoder_typed_prepared_bytes(int S, int Vb) { return enc::typed_prepared_floats(S, Vb) * sizeof(float); }
+size_t encoder_typed_prepared_bytes(int S, int Vb, bool x3) {
+  return enc::typed_prepared_floats(S, Vb, x3) * sizeof(float);
+}
 
-int launch_encoder_typed_prepare(const float* weights, const float* bond_table, int K, int S, int Vb, void* prepared,
-                                 hipStream_t s) {
+int launch_encoder_typed_prepare(const float* weights, const float* bond_table, int K, int S, int Vb, bool x3,
+                                 void* prepared, hipStream_t s) {
   if (S <= 0) return IMPNN_OK;
   enc::TImageParams ip{};
   ip.weights = weights;
@@ -464,6 +548,7 @@ int launch_encoder_typed_prepare(const float* weights, const float* bond_table, 
   ip.K = K;
   ip.S = S;
   ip.Vb = Vb;
+  ip.x3 = x3 ? 1 : 0;
   ip.step_floats = impnn_encoder_step_floats(enc::kD, K);
   return enc::launch_typed_image(ip, s);
 }
@@ -473,18 +558,20 @@ int launch_encoder_typed_run(const EncoderArgs& a, const enc::Ws& w, hipStream_t
   char* base = static_cast<char*>(a.workspace);
   TEncParams ep{};
   const size_t S1 = a.S > 0 ? a.S : 1;
+  const bool x3 = a.mode == 3;
+  const size_t uslot = x3 ? kXUpdSlot : kTUpdSlot;
   for (int g = 0; g < a.n_ions; ++g) {
     const float* prep;
     if (a.prepared[g]) {
       if (!aligned16(a.prepared[g])) return fail(IMPNN_E_BADARG, "encoder_fused: prepared weights must be 16B aligned");
       prep = static_cast<const float*>(a.prepared[g]);
     } else {  // canonical weights: build the images into the workspace first
-      float* img = reinterpret_cast<float*>(base + w.img_off) + (size_t)g * typed_prepared_floats(a.S, a.Vb);
-      if (int rc = launch_encoder_typed_prepare(a.weights[g], a.bond_table, a.K, a.S, a.Vb, img, s)) return rc;
+      float* img = reinterpret_cast<float*>(base + w.img_off) + (size_t)g * typed_prepared_floats(a.S, a.Vb, x3);
+      if (int rc = launch_encoder_typed_prepare(a.weights[g], a.bond_table, a.K, a.S, a.Vb, x3, img, s)) return rc;
       prep = img;
     }
     ep.upd[g] = prep;
-    ep.tmat[g] = prep + S1 * kTUpdSlot;
+    ep.tmat[g] = prep + S1 * uslot;
     ep.pooled[g] = a.pooled[g];
   }
   ep.atom_table = a.atom_table;
@@ -500,9 +587,11 @@ int launch_encoder_typed_run(const EncoderArgs& a, const enc::Ws& w, hipStream_t
     void* sp = debug_stamp_buffer(&sb);
     if (sp && sb >= (size_t)w.nwg * 32 * sizeof(unsigned long long)) ep.stamps = static_cast<unsigned long long*>(sp);
   }
-  void (*kern)(TEncParams) = ep.stamps ? encoder_typed_kernel<true> : encoder_typed_kernel<false>;
-  if (int rc = ensure_lds_limit((const void*)kern, ep.stamps ? 5 : 4)) return rc;
-  size_t lds = kTLdsFixedBytes;
+  ep.upd_slot = (int)uslot;
+  void (*kern)(TEncParams) = x3 ? (ep.stamps ? encoder_typed_kernel<true, true> : encoder_typed_kernel<false, true>)
+                                : (ep.stamps ? encoder_typed_kernel<true, false> : encoder_typed_kernel<false, false>);
+  if (int rc = ensure_lds_limit((const void*)kern, (ep.stamps ? 5 : 4) + (x3 ? 2 : 0))) return rc;
+  size_t lds = lds_fixed_bytes(x3);
   const size_t atab_bytes = ((size_t)a.Va + 1) * kHS * sizeof(float);
   ep.atab_lds = lds + atab_bytes <= 160 * 1024;
   if (ep.atab_lds) lds += atab_bytes;

@@ -75,7 +75,7 @@ class MPNNModel:
         self._packed = None
         self._prepared = {}
         self._split_deg_limit = None
-        self.encoder_mode = "auto"  # "auto" | "f32t" | "f32" | "f16x2" (ops.encoder_fused)
+        self.encoder_mode = "auto"  # "auto" | "f32t" | "f32x3" | "f32" | "f16x2" (ops.encoder_fused)
         self.encoder_workgroups = 0  # persistent workgroups per encoder launch (0: library default, one per CU)
 
     # ------------------------------------------------------------------ construction
@@ -270,7 +270,7 @@ class MPNNModel:
             if sup("f16x2") and (self._split_deg_limit is None or E <= self._split_deg_limit):
                 return "f16x2"
             want = "auto"
-        if want in ("f32t", "f32"):
+        if want in ("f32t", "f32", "f32x3"):
             return want if sup(want) else None
         for m in ("f32t", "f32"):
             if sup(m):

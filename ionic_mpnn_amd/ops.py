@@ -318,7 +318,7 @@ def _workspace(device, nbytes):
     return ws
 
 
-ENCODER_MODES = {"f32": 0, "f16x2": 1, "f32t": 2}
+ENCODER_MODES = {"f32": 0, "f16x2": 1, "f32t": 2, "f32x3": 3}
 FP16_MAX = 65504.0
 SPLIT_SX, SPLIT_SW = 16.0, 256.0  # kSX / kSW of encoder_fused.hip
 
@@ -383,7 +383,8 @@ def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=L
     step-weight tensors (pack_step_weights), or None when `prepared` (list of
     prepare_encoder_weights outputs built for the same `mode`) is given.  Returns a list of pooled
     (B,D) tensors.
-    mode: "f32t" (per-bond-type messages, exact f32 MFMA, any bond_dim), "f32" (pull form, exact f32 MFMA,
+    mode: "f32t" (per-bond-type messages, exact f32 MFMA, any bond_dim), "f32x3" (the same with the GatedUpdate GEMMs
+    as exact three-term bf16 products on the bf16 matrix pipe; opt-in), "f32" (pull form, exact f32 MFMA,
     bond_dim <= 8) or "f16x2" (pull form, split-fp16 MFMA, f32 accumulate; the caller vouches for
     the range condition of include/impnn.h - ionic_mpnn_amd.model does via split_mode_degree_limit).
     workgroups: persistent workgroups of the launch (0: library default, one per CU).

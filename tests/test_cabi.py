@@ -67,9 +67,10 @@ def test_encoder_shape_coverage_is_reported():
     assert b"not covered" in lib.impnn_last_error_string()
     assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 300, 32, 8, 3, 72, TYPED, 0, C.byref(need)) == -2   # E > 255
     assert lib.impnn_encoder_workspace_bytes(3, 16, 40, 80, 32, 8, 3, 72, F32, 0, C.byref(need)) == -1
-    assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 80, 32, 8, 3, 72, 3, 0, C.byref(need)) == -1       # no mode 3
+    assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 80, 32, 8, 3, 72, 3, 0, C.byref(need)) == 0        # f32x3
+    assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 80, 32, 8, 3, 72, 4, 0, C.byref(need)) == -1       # no mode 4
     assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 80, 32, 8, 3, 72, F32, -1, C.byref(need)) == -1
-    assert lib.impnn_encoder_prepared_bytes(3, 72, TYPED) > lib.impnn_encoder_prepared_bytes(3, 72, F32) > 0
+    assert lib.impnn_encoder_prepared_bytes(3, 72, 3) > lib.impnn_encoder_prepared_bytes(3, 72, TYPED) > lib.impnn_encoder_prepared_bytes(3, 72, F32) > 0
 
 
 def test_encoder_sizing_has_no_hidden_state():

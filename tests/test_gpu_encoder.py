@@ -26,7 +26,7 @@ def make_model(w, Va, Vb, D=32, K=8, fp=32, mix=20, mode="auto"):
     return m
 
 
-MODES = ["f32t", "f32", "f16x2"]
+MODES = ["f32t", "f32x3", "f32", "f16x2"]
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -57,7 +57,7 @@ def test_fused_encoder_random_shapes(N, E, K, S, B, seed, mode):
                                min_atoms=min(3, N), seed=seed)
     w = weights.init_weights("viscosity", Va, Vb, atom_dim=32, bond_dim=K, num_steps=S, seed=seed + 100, perturb=True)
     m = make_model(w, Va, Vb, K=K, mode=mode)
-    if mode == "f32t" and E > 255:
+    if mode in ("f32t", "f32x3") and E > 255:
         assert not m.fused_supported(N, E)  # typed records carry in-degrees as 8 bits; "auto" takes the pull form
         m.encoder_mode = "auto"
     assert m.fused_supported(N, E)

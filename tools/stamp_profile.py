@@ -52,7 +52,7 @@ print(f"cycles per workgroup: total mean {tot.mean():.0f} max {tot.max()} min {t
       f"steps {steps.mean():.0f} pools {pool.mean():.0f}")
 print(f"per chunk: prologue {(pro / nch).mean():.0f}  steps {(steps / nch).mean():.0f}  pool {(pool / nch).mean():.0f}")
 
-if mode == "f32t":
+if mode in ("f32t", "f32x3"):
     # typed encoder: stamp 14 = end of step 0, 16+w = wave w done with its message batches (step 1, first chunk),
     # 12 = mid-step barrier released, 15 = end of step 1
     t0 = st[:, 14]
