@@ -103,7 +103,7 @@ int impnn_gated_update(const float* h, const float* agg, const float* Wz, const 
  *      skip them: impnn_kept_rows gives, per molecule, r_b = 1 + max(last n with atom_ids[b,n] > 0, largest atom
  *      index on a valid edge) (the kept rows are closed under "is a source of": skipping is exact), and
  *      impnn_row_index_fill turns r and its inclusive prefix sum into the flat list b*N + [0, r_b) and its length
- *      (*n_rows, device memory - no host round trip; the launch is sized for max_rows = B*N).  atom_dim 64 / 128. */
+ *      (*n_rows, device memory - no host round trip; the launch is sized for max_rows = B*N).  atom_dim 32 / 64 / 128. */
 int impnn_gated_update_rows(const float* h, const float* agg, const float* Wz, const float* bz,
                             const float* Wr, const float* br, const float* Wh, const float* bh,
                             const float* gamma, const float* beta, float ln_eps, float* out,

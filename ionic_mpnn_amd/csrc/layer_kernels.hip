@@ -452,8 +452,10 @@ __global__ __launch_bounds__(256) void gated_update_d32_kernel(
     const float* __restrict__ h, const float* __restrict__ agg, const float* __restrict__ Wz,
     const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
     const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float eps, float* __restrict__ out, int64_t rows) {
+    const float* __restrict__ beta, float eps, float* __restrict__ out, int64_t rows,
+    const int32_t* __restrict__ ridx, const int32_t* __restrict__ nrows_dev) {
   constexpr int D = 32;
+  if (nrows_dev) rows = *nrows_dev;  // row list (impnn_gated_update_rows): rows ridx[0 .. *nrows_dev) only
   __shared__ __align__(16) float wimg[3 * D * kGuRS + 5 * D];
   for (int t = threadIdx.x; t < 3 * D * 2 * D; t += blockDim.x) {
     const int gate = t / (2 * D * D), rem = t - gate * 2 * D * D;
@@ -474,7 +476,8 @@ __global__ __launch_bounds__(256) void gated_update_d32_kernel(
   const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
   for (int64_t tile = wave_id; tile < ntiles; tile += nwaves) {
     const int64_t row = tile * 16 + a;
-    const int64_t rl = row < rows ? row : rows - 1;  // clamped load address; the store is masked
+    int64_t rl = row < rows ? row : rows - 1;  // clamped load address; the store is masked
+    if (ridx) rl = ridx[rl];
     const f32x4_t h0 = ldv4(h + rl * D + 4 * q), h1 = ldv4(h + rl * D + 16 + 4 * q);
     const f32x4_t a0 = ldv4(agg + rl * D + 4 * q), a1 = ldv4(agg + rl * D + 16 + 4 * q);
     f32x4_t z0 = ldv4(wvec + 4 * q), z1 = ldv4(wvec + 16 + 4 * q);
@@ -549,9 +552,9 @@ __global__ __launch_bounds__(256) void gated_update_d32_kernel(
       o0[i] = n0[i] * inv * g0[i] + b0[i] + h0[i];
       o1[i] = n1[i] * inv * g1[i] + b1[i] + h1[i];
     }
-    if (row < rows) {
-      *reinterpret_cast<f32x4_t*>(out + row * D + 4 * q) = o0;
-      *reinterpret_cast<f32x4_t*>(out + row * D + 16 + 4 * q) = o1;
+    if (row < rows) {  // (rl is the row itself, or its entry of the row list)
+      *reinterpret_cast<f32x4_t*>(out + rl * D + 4 * q) = o0;
+      *reinterpret_cast<f32x4_t*>(out + rl * D + 16 + 4 * q) = o1;
     }
   }
 }
@@ -1278,13 +1281,16 @@ int launch_gated_update(const float* h, const float* agg, const float* Wz, const
                         const float* gamma, const float* beta, float eps, float* out, int64_t rows,
                         int D, hipStream_t s, const int32_t* ridx, const int32_t* nrows_dev) {
   if (rows == 0) return IMPNN_OK;
-  if (ridx && !(D % 64 == 0 && D <= 128))
-    return fail(IMPNN_E_UNSUPPORTED, "gated_update: a row list is supported for atom_dim 64 and 128 only");
+  if (ridx && !(D == 32 || (D % 64 == 0 && D <= 128)))
+    return fail(IMPNN_E_UNSUPPORTED, "gated_update: a row list is supported for atom_dim 32, 64 and 128 only");
+  if (ridx && D == 32 && !(aligned16(h) && aligned16(agg) && aligned16(out)))
+    return fail(IMPNN_E_BADARG, "gated_update: row-list variant needs 16-byte aligned tensors");
   if (D == 32 && aligned16(h) && aligned16(agg) && aligned16(out)) {
     const int64_t tiles = (rows + 15) / 16;
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > 256 * 4) blocks = 256 * 4;  // grid-stride: the weight transpose is paid once per workgroup
-    gated_update_d32_kernel<<<(unsigned)blocks, 256, 0, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, out, rows);
+    gated_update_d32_kernel<<<(unsigned)blocks, 256, 0, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, out, rows,
+                                                             ridx, nrows_dev);
     return check_launch("gated_update_d32");
   }
   if (D % 16 == 0 && D >= 48 && D <= 128) {  // matrix cores; the kernels stream through LDS in 16-row slices

@@ -265,7 +265,7 @@ def gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps=LN_EPS, rows=N
     out = torch.empty_like(ts[0])
     nrows = ts[0].numel() // D
     with torch.cuda.device(h.device):
-        if rows is not None and D in (64, 128):
+        if rows is not None and D in (32, 64, 128):
             check(_lib.load().impnn_gated_update_rows(*[ptr(t) for t in ts], float(eps), ptr(out), ptr(rows[0]),
                                                       ptr(rows[1]), nrows, D, stream_ptr()))
         else:

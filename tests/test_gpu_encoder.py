@@ -521,3 +521,25 @@ def test_typed_encoder_any_bond_dim(K, Vb):
     ra = O.encode(w, "an", inp["an_atom"], inp["an_bond"], inp["an_connectivity"], pooled_only=True)
     assert_close(pc.cpu().numpy(), rc, what=f"cat pooled K={K} Vb={Vb}")
     assert_close(pa.cpu().numpy(), ra, what="an pooled")
+
+
+def test_f32x3_is_as_accurate_as_the_f32_mfma():
+    """Mode "f32x3" carries every f32 operand of the GatedUpdate GEMMs as an exact sum of three bf16 terms and keeps all
+    nine cross products, so its error against the fp64 oracle must be of the size of the exact-f32 mode's own
+    (f32 accumulation in another order) - measured elementwise, not only against the tensor's scale."""
+    Va, Vb = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB
+    inp = synthetic.make_batch(384, seed=41)
+    w = weights.init_weights("viscosity", Va, Vb, num_steps=4, seed=42, perturb=True)
+    ref = np.concatenate([O.encode(w, p, inp[f"{p}_atom"], inp[f"{p}_bond"], inp[f"{p}_connectivity"], pooled_only=True)
+                          for p in ("cat", "an")])
+    err = {}
+    for mode in ("f32t", "f32x3"):
+        m = make_model(w, Va, Vb, mode=mode)
+        pc, pa = m.encode_pooled(to_dev(inp), fused=True)
+        got = np.concatenate([pc.cpu().numpy(), pa.cpu().numpy()]).astype(np.float64)
+        d = np.abs(got - ref)
+        err[mode] = (float(d.max() / np.abs(ref).max()), float(np.sqrt(np.mean(d * d)) / np.sqrt(np.mean(ref * ref))),
+                     float(np.max(d / np.maximum(np.abs(ref), 1e-3 * np.abs(ref).max()))))
+    for i in range(3):
+        assert err["f32x3"][i] <= 2.0 * err["f32t"][i] + 1e-7, err
+    assert err["f32x3"][0] <= 1e-5 and err["f32t"][0] <= 1e-5

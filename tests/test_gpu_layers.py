@@ -245,7 +245,7 @@ def test_reduce_small_batch_kernel_is_bitwise_the_large_batch_kernel(D, N, E):
     np.testing.assert_array_equal(small.cpu().numpy(), ref)
 
 
-@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("D", [32, 64, 128])
 def test_gated_update_on_kept_rows_only(D):
     """impnn_kept_rows / impnn_row_index_fill / impnn_gated_update_rows (the model's layered path at wide states):
     the row list is exactly the encoder's kept rows, the listed rows equal the full GatedUpdate bit for bit, every
