@@ -11,7 +11,8 @@ for f in glob.glob(f"{out}/*/**/*counter_collection.csv", recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row["Kernel_Name"]
-            short = ("encoder_typed" if "encoder_typed" in k else "encoder_fused" if "encoder_fused" in k else
+            short = ("encoder_typed_x3" if "encoder_typed" in k and ", true>" in k else
+                     "encoder_typed" if "encoder_typed" in k else "encoder_fused" if "encoder_fused" in k else
                      "plan_stats" if "plan_stats" in k else "plan_chunks" if "plan_chunks" in k else None)
             if short:
                 acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
