@@ -391,58 +391,66 @@ __global__ __launch_bounds__(kBlock) void bmm_message_typed_seg_kernel(
 __global__ __launch_bounds__(1024) void bmm_message_typed_seg_mfma_kernel(
     const float* __restrict__ h, const int32_t* __restrict__ conn, const float* __restrict__ A,
     float* __restrict__ m_out, const int32_t* __restrict__ start, const int32_t* __restrict__ segbase,
-    const int32_t* __restrict__ order, int N, int E, int D, int Vb) {
+    const int32_t* __restrict__ order, int N, int E, int D, int Vb, int segs_per_wg) {
   extern __shared__ __align__(16) float smem[];
   __shared__ int64_t outrow[kSeg];
-  const int seg = blockIdx.x;
-  if (seg >= segbase[Vb]) return;
-  int lo = 0, hi = Vb - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (segbase[mid] <= seg) lo = mid; else hi = mid - 1;
-  }
-  const int ty = lo;
-  const int p0 = start[ty] + (seg - segbase[ty]) * kSeg;
-  const int n = min(kSeg, start[ty + 1] - p0);
-  if (n <= 0) return;
+  const int nseg = segbase[Vb];
   const int tid = threadIdx.x;
   const int LD = D + 4;            // 16-byte aligned rows, bank-staggered
   float* As = smem;                // D x LD
   float* xm = As + D * LD;         // kSeg x LD, rows beyond n are zero
-  // 16-byte loads throughout (D is a multiple of 16, rows of A / h / the LDS tiles are 16-byte aligned): the segment's
-  // time is its 64 KB of A[type] and its gathered source rows, not its 64 MFMAs per wave
   const int D4 = D >> 2;
-  const float* Aty = A + (int64_t)ty * D * D;
-  for (int t = tid; t < D * D4; t += (int)blockDim.x) {
-    const int r = t / D4, c4 = t - r * D4;
-    stv4(As + r * LD + 4 * c4, ldv4(Aty + (int64_t)r * D + 4 * c4));
-  }
-  if (tid < kSeg) outrow[tid] = tid < n ? (int64_t)order[p0 + tid] : 0;
-  __syncthreads();
-  for (int t = tid; t < kSeg * D4; t += (int)blockDim.x) {
-    const int e = t / D4, c4 = t - e * D4;
-    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-    if (e < n) {
-      const int64_t be = outrow[e];
-      v = ldv4(h + ((be / E) * N + conn[be * 2]) * D + 4 * c4);
-    }
-    stv4(xm + e * LD + 4 * c4, v);
-  }
-  __syncthreads();
   const int lane = tid & 63, wave = tid >> 6, a = lane & 15, q = lane >> 4;
-  const int mt = D >> 4, et = (n + 15) >> 4;          // output tiles: features x edges
-  for (int tile = wave; tile < mt * et; tile += (int)blockDim.x >> 6) {
-    const int T = tile % mt, Et = tile / mt;
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    const float* arow = As + (16 * T + a) * LD + 4 * q;
-    const float* xrow = xm + (16 * Et + a) * LD + 4 * q;
-    for (int u = 0; u < mt; ++u) {
-      const f32x4_t av = ldv4(arow + 16 * u), xv = ldv4(xrow + 16 * u);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc = mfma_f32(av[r], xv[r], acc);
+  // A workgroup walks `segs_per_wg` consecutive segments: segments of one type are numbered consecutively, so the
+  // type's matrix (D*D*4 bytes - 64 KB at D = 128: the segment's dominant cost, not its MFMAs) stays in LDS until the
+  // type changes instead of being copied once per 64 edges.
+  int held = -1;
+  for (int seg = blockIdx.x * segs_per_wg; seg < (blockIdx.x + 1) * segs_per_wg && seg < nseg; ++seg) {
+    int lo = 0, hi = Vb - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (segbase[mid] <= seg) lo = mid; else hi = mid - 1;
     }
-    const int e = 16 * Et + a;                        // accumulator: feature 16T + 4q + reg of edge e
-    if (e < n) stv4(m_out + outrow[e] * D + 16 * T + 4 * q, acc);
+    const int ty = lo;
+    const int p0 = start[ty] + (seg - segbase[ty]) * kSeg;
+    const int n = min(kSeg, start[ty + 1] - p0);
+    if (n <= 0) continue;  // (workgroup-uniform)
+    __syncthreads();       // the previous segment's MFMAs are done with xm / outrow (and As, if the type changes)
+    // 16-byte loads throughout (D is a multiple of 16, rows of A / h / the LDS tiles are 16-byte aligned)
+    if (ty != held) {
+      held = ty;
+      const float* Aty = A + (int64_t)ty * D * D;
+      for (int t = tid; t < D * D4; t += (int)blockDim.x) {
+        const int r = t / D4, c4 = t - r * D4;
+        stv4(As + r * LD + 4 * c4, ldv4(Aty + (int64_t)r * D + 4 * c4));
+      }
+    }
+    if (tid < kSeg) outrow[tid] = tid < n ? (int64_t)order[p0 + tid] : 0;
+    __syncthreads();
+    for (int t = tid; t < kSeg * D4; t += (int)blockDim.x) {
+      const int e = t / D4, c4 = t - e * D4;
+      f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+      if (e < n) {
+        const int64_t be = outrow[e];
+        v = ldv4(h + ((be / E) * N + conn[be * 2]) * D + 4 * c4);
+      }
+      stv4(xm + e * LD + 4 * c4, v);
+    }
+    __syncthreads();
+    const int mt = D >> 4, et = (n + 15) >> 4;          // output tiles: features x edges
+    for (int tile = wave; tile < mt * et; tile += (int)blockDim.x >> 6) {
+      const int T = tile % mt, Et = tile / mt;
+      f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+      const float* arow = As + (16 * T + a) * LD + 4 * q;
+      const float* xrow = xm + (16 * Et + a) * LD + 4 * q;
+      for (int u = 0; u < mt; ++u) {
+        const f32x4_t av = ldv4(arow + 16 * u), xv = ldv4(xrow + 16 * u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc = mfma_f32(av[r], xv[r], acc);
+      }
+      const int e = 16 * Et + a;                        // accumulator: feature 16T + 4q + reg of edge e
+      if (e < n) stv4(m_out + outrow[e] * D + 16 * T + 4 * q, acc);
+    }
   }
 }
 
@@ -2138,8 +2146,11 @@ int launch_bmm_message_typed_sorted(const float* h, const int32_t* bond_ids, con
       (void)hipFuncSetAttribute((const void*)bmm_message_typed_seg_mfma_kernel,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
     // wide states: 16 waves (4 per SIMD) share the segment's 32 output tiles, so LDS reads overlap the MFMAs
-    bmm_message_typed_seg_mfma_kernel<<<(int)max_segs, D >= 64 ? 1024 : kBlock, lm, s>>>(h, conn, A, m, start, segbase,
-                                                                                          order, N, E, D, Vb);
+    // wide states: several segments per workgroup (the matrix copy is amortised); keep >= ~4 workgroups per CU of work
+    int spw = D >= 64 ? (int)(max_segs / 1024) : 1;
+    spw = spw < 1 ? 1 : (spw > 8 ? 8 : spw);
+    bmm_message_typed_seg_mfma_kernel<<<(int)((max_segs + spw - 1) / spw), D >= 64 ? 1024 : kBlock, lm, s>>>(
+        h, conn, A, m, start, segbase, order, N, E, D, Vb, spw);
     return check_launch("bmm_message_typed_seg_mfma");
   }
   const size_t lds = sizeof(float) * ((size_t)D * (D + 1) + (size_t)kSeg * D);
