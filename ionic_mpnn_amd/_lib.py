@@ -8,7 +8,10 @@ from pathlib import Path
 
 import torch
 
-_LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libimpnn.so"
+import os
+
+# IMPNN_LIB: another build of the library (diagnostics: tools/ab_bench.py style A/B runs); default: the in-tree one
+_LIB_PATH = Path(os.environ.get("IMPNN_LIB") or Path(__file__).resolve().parent / "csrc" / "libimpnn.so")
 _lock = threading.Lock()
 _lib = None
 

@@ -749,12 +749,23 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
   float* part = ws + 3 * 16 * LDW;  // 2 x 4 x 64 row partials (sum, squared deviation) of LayerNorm
   const int64_t row0 = (int64_t)blockIdx.x * 64;
   if (row0 >= rows) return;
-  for (int t = tid; t < 64 * D; t += 1024) {
-    const int r = t / D, c = t - r * D;
-    const bool in = row0 + r < rows;
-    const int64_t src = in ? (ridx ? (int64_t)ridx[row0 + r] : row0 + r) : 0;
-    cs[r * LDC + c] = in ? h[src * D + c] : 0.f;
-    cs[r * LDC + D + c] = in ? agg[src * D + c] : 0.f;
+  {  // the tile of [h | agg]: 16-byte loads, all of a thread's requests in flight before the first LDS store
+    constexpr int kQ = 64 * (D / 4) / 1024;  // quads of h (and of agg) per thread
+    f32x4_t hv[kQ], av[kQ];
+#pragma unroll
+    for (int i = 0; i < kQ; ++i) {
+      const int t = tid + 1024 * i, r = t / (D / 4), c4 = t - r * (D / 4);
+      const bool in = row0 + r < rows;
+      const int64_t src = in ? (ridx ? (int64_t)ridx[row0 + r] : row0 + r) : 0;
+      hv[i] = in ? ldv4(h + src * D + 4 * c4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      av[i] = in ? ldv4(agg + src * D + 4 * c4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < kQ; ++i) {
+      const int t = tid + 1024 * i, r = t / (D / 4), c4 = t - r * (D / 4);
+      *reinterpret_cast<f32x4_t*>(cs + r * LDC + 4 * c4) = hv[i];
+      *reinterpret_cast<f32x4_t*>(cs + r * LDC + D + 4 * c4) = av[i];
+    }
   }
   f32x4_t z[NL], rg[NL];
 #pragma unroll
@@ -768,49 +779,72 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
   // Kernel slices: global -> registers TWO slices ahead -> a ring of three LDS buffers.  One slice ahead was not
   // enough: all 256 CUs stream the same 16 KB slice at the same time (one L2 channel group), a slice took ~5.5 K cycles
   // against 2 K of MFMA work, each iteration waiting out its own L2 round trip in front of the barrier.
-  constexpr int kP1 = 16 * 2 * D / 1024, kP2 = 16 * D / 1024;
-  float preA[kP1], preB[kP1];
-  auto fetch1 = [&](int u, float (&pre)[kP1]) {
+  // A thread moves the four input rows 4qq .. 4qq+3 of one column: four coalesced 4-byte loads, ONE conflict-free 16-byte
+  // LDS store (the slice layout keeps those four side by side).  Inside an iteration the order is: LDS reads of this
+  // slice's operands, LDS store of the next slice, MFMAs - the four waves of a SIMD finish their MFMAs together, so a
+  // store placed after them was fully exposed in front of the barrier (55 us of 439 at D = 128).
+  constexpr int kI1 = 4 * 2 * D, kI2 = 4 * D;  // (qq, column) items of a slice: phase 1 [Wz | Wr], phase 2 Wh
+  static_assert(kI1 <= 1024, "one item per thread");
+  const int it_qq = tid / (2 * D), it_c = tid - it_qq * (2 * D);
+  f32x4_t preA, preB;
+  auto fetch1 = [&](int u, f32x4_t& pre) {
+    if (tid < kI1) {
+      const float* src = (it_c < D ? Wz + it_c : Wr + (it_c - D)) + (int64_t)(16 * u + 4 * it_qq) * D;
 #pragma unroll
-    for (int i = 0; i < kP1; ++i) {
-      const int t = tid + 1024 * i, jj = t / (2 * D), c = t - jj * 2 * D;
-      pre[i] = c < D ? Wz[(int64_t)(16 * u + jj) * D + c] : Wr[(int64_t)(16 * u + jj) * D + c - D];
+      for (int r = 0; r < 4; ++r) pre[r] = src[r * D];
     }
   };
-  auto park1 = [&](float* dst, const float (&pre)[kP1]) {
-#pragma unroll
-    for (int i = 0; i < kP1; ++i) {
-      const int t = tid + 1024 * i, jj = t / (2 * D), c = t - jj * 2 * D;
-      dst[(((jj >> 2) * LDW + c) << 2) + (jj & 3)] = pre[i];
-    }
+  auto park1 = [&](float* dst, const f32x4_t& pre) {
+    if (tid < kI1) *reinterpret_cast<f32x4_t*>(dst + ((it_qq * LDW + it_c) << 2)) = pre;
   };
-  auto mma1 = [&](int u) {
+  struct Ops1 {
+    f32x4_t av, bzv[NL], brv[NL];
+  };
+  auto read1 = [&](int u, Ops1& o) {
     const float* cur = ws + (u % 3) * 16 * LDW;
-    const f32x4_t av = ldv4(crow + 16 * u);
+    o.av = ldv4(crow + 16 * u);
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL) {
       const int T = fg * NL + TL;
-      const f32x4_t bzv = ldv4(cur + ((q * LDW + 16 * T + a) << 2)), brv = ldv4(cur + ((q * LDW + D + 16 * T + a) << 2));
+      o.bzv[TL] = ldv4(cur + ((q * LDW + 16 * T + a) << 2));
+      o.brv[TL] = ldv4(cur + ((q * LDW + D + 16 * T + a) << 2));
+    }
+  };
+  auto mma1 = [&](const Ops1& o) {
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        z[TL] = mfma_f32(av[r], bzv[r], z[TL]);
-        rg[TL] = mfma_f32(av[r], brv[r], rg[TL]);
+        z[TL] = mfma_f32(o.av[r], o.bzv[TL][r], z[TL]);
+        rg[TL] = mfma_f32(o.av[r], o.brv[TL][r], rg[TL]);
       }
-    }
   };
   fetch1(0, preA);
   fetch1(1, preB);
   park1(ws, preA);  // slice 0
   __syncthreads();
-  // iteration u: slice u is in LDS buffer u % 3, slice u + 1 in registers (fetched one iteration ago), slice u + 2 is requested
+  // iteration u: slice u is in LDS buffer u % 3, slice u + 1 in registers (requested one iteration ago), slice u + 2 is
+  // requested; buffer (u + 1) % 3 was last read at iteration u - 2, two barriers ago
+#ifdef IMPNN_DIAG_GU_NOLOOPS
+  for (int u = 0; u < 0; u += 2) {
+#else
   for (int u = 0; u < 2 * NT; u += 2) {
-    if (u + 2 < 2 * NT) fetch1(u + 2, preA);          // preA was parked at the end of the previous iteration (or above)
-    mma1(u);
-    park1(ws + ((u + 1) % 3) * 16 * LDW, preB);       // slice u + 1; that buffer was last read at iteration u - 2
+#endif
+    Ops1 o;
+    // (scheduling fences: left alone, the compiler sinks the store and the requests below the MFMAs again)
+    if (u + 2 < 2 * NT) fetch1(u + 2, preA);          // preA was parked in the previous iteration (or above)
+    read1(u, o);
+    __builtin_amdgcn_sched_barrier(0);
+    park1(ws + ((u + 1) % 3) * 16 * LDW, preB);
+    __builtin_amdgcn_sched_barrier(0);
+    mma1(o);
     __syncthreads();
     if (u + 3 < 2 * NT) fetch1(u + 3, preB);
-    mma1(u + 1);
+    read1(u + 1, o);
+    __builtin_amdgcn_sched_barrier(0);
     if (u + 2 < 2 * NT) park1(ws + ((u + 2) % 3) * 16 * LDW, preA);
+    __builtin_amdgcn_sched_barrier(0);
+    mma1(o);
     __syncthreads();
   }
   // z, r -> sigmoid; r * h into LDS (every wave only touches its own 16 rows)
@@ -819,8 +853,8 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int rl = 16 * wave + 4 * q + g, f = 16 * (fg * NL + TL) + a;
-      z[TL][g] = sigmoidf_(z[TL][g]);
-      rhs[rl * LDR + f] = sigmoidf_(rg[TL][g]) * cs[rl * LDC + f];
+      z[TL][g] = fsig(z[TL][g]);
+      rhs[rl * LDR + f] = fsig(rg[TL][g]) * cs[rl * LDC + f];
     }
   f32x4_t tt[NL];
 #pragma unroll
@@ -829,42 +863,55 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
     tt[TL] = f32x4_t{b2, b2, b2, b2};
   }
   const float* rrow = rhs + (16 * wave + a) * LDR + 4 * q;
-  auto fetch2 = [&](int u, float (&pre)[kP1]) {
+  const int it2_qq = tid / D, it2_c = tid - it2_qq * D;
+  auto fetch2 = [&](int u, f32x4_t& pre) {
+    if (tid < kI2) {
+      const float* src = Wh + (int64_t)(16 * u + 4 * it2_qq) * D + it2_c;
 #pragma unroll
-    for (int i = 0; i < kP2; ++i) {
-      const int t = tid + 1024 * i, jj = t / D, c = t - jj * D;
-      pre[i] = Wh[(int64_t)(16 * u + jj) * D + c];
+      for (int r = 0; r < 4; ++r) pre[r] = src[r * D];
     }
   };
-  auto park2 = [&](float* dst, const float (&pre)[kP1]) {
-#pragma unroll
-    for (int i = 0; i < kP2; ++i) {
-      const int t = tid + 1024 * i, jj = t / D, c = t - jj * D;
-      dst[(((jj >> 2) * LDW + c) << 2) + (jj & 3)] = pre[i];
-    }
+  auto park2 = [&](float* dst, const f32x4_t& pre) {
+    if (tid < kI2) *reinterpret_cast<f32x4_t*>(dst + ((it2_qq * LDW + it2_c) << 2)) = pre;
   };
-  auto mma2 = [&](int u) {
+  struct Ops2 {
+    f32x4_t av, bv[NL];
+  };
+  auto read2 = [&](int u, Ops2& o) {
     const float* cur = ws + (u % 3) * 16 * LDW;
-    const f32x4_t av = u < NT ? ldv4(rrow + 16 * u) : ldv4(crow + 16 * u);  // [r*h | agg]
+    o.av = u < NT ? ldv4(rrow + 16 * u) : ldv4(crow + 16 * u);  // [r*h | agg]
 #pragma unroll
-    for (int TL = 0; TL < NL; ++TL) {
-      const f32x4_t bv = ldv4(cur + ((q * LDW + 16 * (fg * NL + TL) + a) << 2));
+    for (int TL = 0; TL < NL; ++TL) o.bv[TL] = ldv4(cur + ((q * LDW + 16 * (fg * NL + TL) + a) << 2));
+  };
+  auto mma2 = [&](const Ops2& o) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tt[TL] = mfma_f32(av[r], bv[r], tt[TL]);
-    }
+    for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tt[TL] = mfma_f32(o.av[r], o.bv[TL][r], tt[TL]);
   };
   fetch2(0, preA);
   fetch2(1, preB);
   park2(ws, preA);
   __syncthreads();
+#ifdef IMPNN_DIAG_GU_NOLOOPS
+  for (int u = 0; u < 0; u += 2) {
+#else
   for (int u = 0; u < 2 * NT; u += 2) {
+#endif
+    Ops2 o;
     if (u + 2 < 2 * NT) fetch2(u + 2, preA);
-    mma2(u);
+    read2(u, o);
+    __builtin_amdgcn_sched_barrier(0);
     park2(ws + ((u + 1) % 3) * 16 * LDW, preB);
+    __builtin_amdgcn_sched_barrier(0);
+    mma2(o);
     __syncthreads();
     if (u + 3 < 2 * NT) fetch2(u + 3, preB);
-    mma2(u + 1);
+    read2(u + 1, o);
+    __builtin_amdgcn_sched_barrier(0);
     if (u + 2 < 2 * NT) park2(ws + ((u + 2) % 3) * 16 * LDW, preA);
+    __builtin_amdgcn_sched_barrier(0);
+    mma2(o);
     __syncthreads();
   }
   // blend, LayerNorm over the D features of each row (partials of the 4 feature groups meet in LDS), residual
@@ -874,7 +921,7 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const float hv = cs[(16 * wave + 4 * q + g) * LDC + 16 * (fg * NL + TL) + a];
-      const float n = (1.0f - z[TL][g]) * hv + z[TL][g] * tanhf(tt[TL][g]);
+      const float n = (1.0f - z[TL][g]) * hv + z[TL][g] * ftanh(tt[TL][g]);
       tt[TL][g] = n;
       sum[g] += n;
     }
