@@ -44,7 +44,7 @@ extern "C" {
 typedef void* impnn_stream_t; /* hipStream_t */
 
 /* library identity: returns IMPNN_ABI_VERSION */
-#define IMPNN_ABI_VERSION 2
+#define IMPNN_ABI_VERSION 3
 int impnn_abi_version(void);
 /* text of the calling thread's last error ("" if none) */
 const char* impnn_last_error_string(void);
@@ -143,7 +143,12 @@ int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, i
  *                                 (models/layers.py:108-112): m_e = A[bond id of e] h[src_e] with
  *                                 A[v] = sum_k bond_table[v,k] W[k], on v_mfma_f32_4x4x1_16b_f32, exact f32 products;
  *                                 in-edge messages summed in edge-slot order.  atom_dim 32, ANY bond_dim (K = D^2 of
- *                                 train_melting_point.py:146 included), Vb <= 256, E <= 255.
+ *                                 train_melting_point.py:146 included), Vb <= 256, E <= 255: one persistent kernel with
+ *                                 the node state in LDS.  atom_dim 64 / 128 (train_viscosity.py with atom_dim=128,
+ *                                 num_steps=6), N <= 256, E <= 512, Vb <= 512: the same arithmetic as a short sequence
+ *                                 of launches per call on compact kept rows (per type-run GEMMs for the messages,
+ *                                 slot-order sums, GatedUpdate on 128-row tiles; csrc/encoder_wide.hip); `workgroups`
+ *                                 is ignored there.
  *    IMPNN_ENCODER_F32X3_TYPED (3): mode 2 with the GatedUpdate GEMMs on the bf16 matrix pipe: every f32 operand is carried
  *                                 EXACTLY as three bf16 terms (3 x 8 significant bits, fp32's exponent range) and all nine
  *                                 cross products are accumulated in f32 (9 x v_mfma_f32_16x16x32_bf16 per 8 f32 MFMAs):
@@ -176,9 +181,10 @@ int impnn_encoder_fused(int32_t n_ions, const int32_t* const* atom_ids,
  *      calls (inference; every step of an epoch's evaluation) builds it once per ion and per mode and passes it to
  *      impnn_encoder_fused_prepared, which then launches only the two plan kernels and the encoder.
  *      impnn_encoder_fused (above) takes the canonical weights and rebuilds the image in the workspace on every call.
- *      `prepared`: device buffer of impnn_encoder_prepared_bytes(S, Vb, mode) bytes, 16B aligned;
+ *      `prepared`: device buffer of impnn_encoder_prepared_bytes(D, S, Vb, mode) bytes (0: shape not covered by the
+ *      mode), 16B aligned;
  *      `bond_table` (Vb,K) is read by mode 2 only (may be NULL otherwise). */
-size_t impnn_encoder_prepared_bytes(int32_t S, int32_t Vb, int32_t mode);
+size_t impnn_encoder_prepared_bytes(int32_t D, int32_t S, int32_t Vb, int32_t mode);
 int impnn_encoder_prepare_weights(const float* weights, const float* bond_table, int32_t D, int32_t K,
                                   int32_t S, int32_t Vb, int32_t mode, void* prepared,
                                   size_t prepared_bytes, impnn_stream_t stream);

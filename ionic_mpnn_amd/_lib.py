@@ -39,7 +39,7 @@ SIGNATURES = {
     "impnn_encoder_fused": (C.c_int, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, i32, vp, i32,
                                       C.POINTER(vp), i32, C.POINTER(vp), i32, i32, i32, i32, i32, i32, f32, i32, vp,
                                       sz, vp]),
-    "impnn_encoder_prepared_bytes": (sz, [i32, i32, i32]),
+    "impnn_encoder_prepared_bytes": (sz, [i32, i32, i32, i32]),
     "impnn_encoder_prepare_weights": (C.c_int, [vp, vp, i32, i32, i32, i32, i32, vp, sz, vp]),
     "impnn_encoder_fused_prepared": (C.c_int, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, i32, vp, i32,
                                                C.POINTER(vp), i32, C.POINTER(vp), i32, i32, i32, i32, i32, i32, f32,
@@ -80,7 +80,7 @@ SIGNATURES = {
     "impnn_debug_set_stamp_buffer": (C.c_int, [vp, sz]),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 IMPNN_E_UNSUPPORTED = -2
 
 

@@ -13,7 +13,7 @@ from pathlib import Path
 
 CSRC = Path(__file__).resolve().parent / "csrc"
 LIB = CSRC / "libimpnn.so"
-SOURCES = ["api.hip", "layer_kernels.hip", "loader_kernels.hip", "train_kernels.hip", "encoder_plan.hip", "encoder_fused.hip", "encoder_typed.hip"]
+SOURCES = ["api.hip", "layer_kernels.hip", "loader_kernels.hip", "train_kernels.hip", "encoder_plan.hip", "encoder_fused.hip", "encoder_typed.hip", "encoder_wide.hip"]
 ARCH = "gfx950"
 
 

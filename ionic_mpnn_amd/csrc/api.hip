@@ -187,7 +187,7 @@ int impnn_encoder_workspace_bytes(int32_t n_ions, int32_t B, int32_t N, int32_t 
   if (!encoder_fused_supported(mode, N, E, D, K, S, Vb))
     return fail(IMPNN_E_UNSUPPORTED, "encoder_fused: mode=%d shape N=%d E=%d D=%d K=%d S=%d Vb=%d not covered", mode,
                 N, E, D, K, S, Vb);
-  *bytes = encoder_fused_workspace_bytes(mode, n_ions, B, N, E, S, Vb, encoder_workgroups(n_ions, B, workgroups));
+  *bytes = encoder_fused_workspace_bytes(mode, n_ions, B, N, E, D, S, Vb, encoder_workgroups(n_ions, B, workgroups));
   return IMPNN_OK;
 }
 
@@ -253,7 +253,7 @@ static int encoder_common(const char* fn, int32_t n_ions, const int32_t* const* 
   a.ln_eps = ln_eps;
   a.workspace = workspace;
   a.workspace_bytes = workspace_bytes;
-  const size_t need = encoder_fused_workspace_bytes(mode, n_ions, B, N, E, S, Vb, nwg);
+  const size_t need = encoder_fused_workspace_bytes(mode, n_ions, B, N, E, D, S, Vb, nwg);
   if (need > 0 && (!workspace || workspace_bytes < need))
     return fail(IMPNN_E_WORKSPACE, "%s: workspace %zu < %zu bytes", fn, workspace_bytes, need);
   return launch_encoder_fused(a, as_stream(stream));
@@ -291,9 +291,10 @@ int impnn_encoder_run(int32_t n_ions, const int32_t* const* atom_ids, const floa
                         workspace_bytes, stream, 2);
 }
 
-size_t impnn_encoder_prepared_bytes(int32_t S, int32_t Vb, int32_t mode) {
-  if (mode < 0 || mode > 3 || Vb <= 0) return 0;
-  return encoder_prepared_bytes(mode, S, Vb);
+size_t impnn_encoder_prepared_bytes(int32_t D, int32_t S, int32_t Vb, int32_t mode) {
+  if (mode < 0 || mode > 3 || Vb <= 0 || D <= 0) return 0;
+  if (!encoder_fused_supported(mode, 1, 0, D, 1, S, mode >= 2 ? Vb : 1)) return 0;
+  return encoder_prepared_bytes(mode, D, S, Vb);
 }
 
 int impnn_encoder_prepare_weights(const float* weights, const float* bond_table, int32_t D, int32_t K, int32_t S,
@@ -306,9 +307,9 @@ int impnn_encoder_prepare_weights(const float* weights, const float* bond_table,
   if (S == 0) return IMPNN_OK;
   REQUIRE(weights && prepared && (mode < 2 || bond_table), "null pointer");
   REQUIRE(aligned16(prepared), "prepared buffer must be 16B aligned");
-  if (prepared_bytes < encoder_prepared_bytes(mode, S, Vb))
+  if (prepared_bytes < encoder_prepared_bytes(mode, D, S, Vb))
     return fail(IMPNN_E_WORKSPACE, "encoder_prepare_weights: buffer %zu < %zu bytes", prepared_bytes,
-                encoder_prepared_bytes(mode, S, Vb));
+                encoder_prepared_bytes(mode, D, S, Vb));
   return launch_encoder_prepare(weights, bond_table, D, K, S, Vb, mode, prepared, as_stream(stream));
 }
 

@@ -130,12 +130,19 @@ struct EncoderArgs {
 };
 bool encoder_fused_supported(int mode, int N, int E, int D, int K, int S, int Vb);
 int encoder_workgroups(int n_ions, int B, int requested);
-size_t encoder_fused_workspace_bytes(int mode, int n_ions, int B, int N, int E, int S, int Vb, int nwg);
+size_t encoder_fused_workspace_bytes(int mode, int n_ions, int B, int N, int E, int D, int S, int Vb, int nwg);
 int launch_encoder_fused(const EncoderArgs& a, hipStream_t s);
 int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase);
-size_t encoder_prepared_bytes(int mode, int S, int Vb);
+size_t encoder_prepared_bytes(int mode, int D, int S, int Vb);
 int launch_encoder_prepare(const float* weights, const float* bond_table, int D, int K, int S, int Vb, int mode,
                            void* prepared, hipStream_t s);
 int ensure_lds_limit(const void* kern, int slot);
+// ---- wide states (encoder_wide.hip: atom_dim 64 / 128 behind the same entries, mode 2)
+bool encoder_wide_supported(int N, int E, int D, int K, int S, int Vb);
+size_t encoder_wide_workspace_bytes(int n_ions, int B, int N, int E, int D, int S, int Vb);
+size_t encoder_wide_prepared_bytes(int D, int S, int Vb);
+int launch_encoder_wide_prepare(const float* weights, const float* bond_table, int D, int K, int S, int Vb,
+                                void* prepared, hipStream_t s);
+int launch_encoder_wide(const EncoderArgs& a, hipStream_t s);
 
 }  // namespace impnn

@@ -1,0 +1,973 @@
+// encode() for wide atom states (atom_dim 64 / 128: BASELINE config 5, train_viscosity.py:166-190 with atom_dim=128,
+// num_steps=6) behind the encoder entries of include/impnn.h, mode IMPNN_ENCODER_F32_TYPED.
+//
+// At D = 128 a row of node state is 512 bytes and a GatedUpdate weight set 394 KB: nothing of the D = 32 encoder's
+// "everything of a chunk in LDS" scheme carries over, and the work is GEMM-shaped and compute-bound in exact f32
+// (12 D^2 flop per kept row and step for the update, 2 D^2 per valid edge for the message; 300 GFLOP per 4096-pair
+// forward against ~0.3 GB of compulsory traffic per step).  So the path is a short sequence of launches per call, BOTH
+// ions in every launch, all of it on a compact row space:
+//
+//   plan (graph only, once per batch)
+//     wide_count      one wave per molecule: kept rows r_b (rows that can send, receive or be pooled - the same rule as
+//                     the D = 32 encoders, encoder_plan.hip) and the histogram of valid edges by (ion, bond type)
+//     wide_scan       one workgroup: compact row base of every molecule (an ion starts at a multiple of 128 rows),
+//                     per-type runs of the type-sorted edge list and their tiles
+//     wide_place      valid edges into their type's run (source row per sorted position) and, per kept row, the
+//                     positions of its in-edges IN EDGE-SLOT ORDER (the reference's sequential scatter_nd order,
+//                     models/layers.py:74-82)
+//   run
+//     wide_embed      h[row] = atom_table[atom id]                               (a1)
+//     S x  wide_message   m[p] = A[type_p] h[src_p]: one GEMM per type run, 64-edge tiles, the type's matrix resident
+//                         in LDS, next tile's rows in flight under the MFMAs      (a2 + a4, models/layers.py:100-117)
+//          wide_reduce    agg[row] = sum of its in-edge messages, slot order      (a5)
+//          wide_update    GatedUpdate on 128-row tiles, [h|agg] and the gate kernels streamed through LDS in
+//                         16/32-deep k slices, h updated in place                 (a7, models/layers.py:142-156)
+//     wide_pool       pooled[b] = sum_n h[b,n] [atom_ids[b,n] > 0], ascending n   (a8)
+//
+// Every product is an exact f32 product on v_mfma_f32_16x16x4_f32; every sum has a fixed order that does not depend
+// on where a molecule sits in the batch, so results are bitwise reproducible and independent of sharding.
+#include "common.h"
+
+namespace impnn {
+namespace wide {
+
+constexpr int kRT = 128;       // rows of a GatedUpdate tile; an ion's rows start at a multiple of it
+constexpr int kMaxN = 256;     // atoms per molecule (LDS tables of wide_place)
+constexpr int kMaxE = 512;     // edge slots per molecule
+constexpr int kMaxVb = 512;    // bond vocabulary (types of both ions: one per thread of wide_scan)
+constexpr int kMolPerWg = 16;  // molecules of a wide_count / wide_place workgroup (4 waves x 4)
+
+// meta words (device): rows of ion g, first compact row of ion g, valid edges, message tiles
+enum { kMetaRows = 0, kMetaBase = 2, kMetaEnd = 4, kMetaValid = 5, kMetaTiles = 6, kMetaWords = 16 };
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t ldv4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
+__device__ __forceinline__ void stv4(float* p, f32x4_t v) { *reinterpret_cast<f32x4_t*>(p) = v; }
+__device__ __forceinline__ f32x4_t mfma_f32(float a, float b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float fsig(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * x));
+}
+__device__ __forceinline__ float ftanh(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177793f * x));
+}
+__device__ __forceinline__ float row16_sum_f(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, true));
+  return v;
+}
+
+constexpr size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ------------------------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------------------------
+struct Ws {
+  size_t meta, kept, rowbase, cnt, tstart, tilebase, cursor, srcrow, rowinfo, csr, h, agg, m, img, total;
+  int64_t rmax, vmax;
+  int nT;
+};
+
+inline int tile_edges(int D) { return D >= 128 ? 64 : 128; }
+
+// floats of one step of a prepared image: Vb type matrices (D x D, row-major [i][j]) | [Wz|Wr] slices | Wh slices |
+// bz br bh gamma beta
+inline size_t step_floats(int D, int Vb) { return (size_t)Vb * D * D + 6 * (size_t)D * D + 5 * (size_t)D; }
+inline size_t prepared_bytes(int D, int S, int Vb) { return align_up((size_t)(S > 0 ? S : 1) * step_floats(D, Vb) * 4, 256); }
+
+inline Ws ws_layout(int n_ions, int B, int N, int E, int D, int S, int Vb) {
+  Ws w{};
+  const int64_t mols = (int64_t)n_ions * B;
+  w.nT = n_ions * Vb;
+  w.rmax = mols * N + (int64_t)n_ions * kRT;
+  w.vmax = mols * E + 2 * tile_edges(D);
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o += align_up(bytes, 256);
+    return at;
+  };
+  w.meta = take(kMetaWords * 4);
+  w.cnt = take((size_t)(w.nT + 1) * 4);  // (meta and cnt are zeroed together)
+  w.kept = take((size_t)mols * 4);
+  w.rowbase = take((size_t)mols * 4);
+  w.tstart = take((size_t)(w.nT + 1) * 4);
+  w.tilebase = take((size_t)(w.nT + 1) * 4);
+  w.cursor = take((size_t)(w.nT + 1) * 4);
+  w.srcrow = take((size_t)w.vmax * 4);
+  w.rowinfo = take((size_t)w.rmax * 8);
+  w.csr = take((size_t)w.vmax * 4);
+  w.h = take((size_t)w.rmax * D * 4);
+  w.agg = take((size_t)w.rmax * D * 4);
+  w.m = take((size_t)w.vmax * D * 4);
+  w.img = take((size_t)n_ions * prepared_bytes(D, S, Vb));
+  w.total = o;
+  return w;
+}
+
+struct Inputs {
+  const int32_t* atom_ids[2];
+  const int32_t* bond_ids[2];
+  const int32_t* conn[2];
+  int n_ions, B, N, E, Va, Vb;
+};
+
+__device__ __forceinline__ int valid_type(const int32_t* conn, const int32_t* bond_ids, int64_t be, int N, int Vb,
+                                          int& src, int& tgt) {
+  src = conn[be * 2];
+  tgt = conn[be * 2 + 1];
+  const int ty = bond_ids[be];
+  return (src > 0 && tgt > 0 && src < N && tgt < N && (unsigned)ty < (unsigned)Vb) ? ty : -1;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// plan kernels
+// ------------------------------------------------------------------------------------------------------------
+__global__ void wide_zero_kernel(int32_t* __restrict__ p, int n) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) p[t] = 0;
+}
+
+// One wave per molecule (4 in turn): kept rows, and the workgroup's histogram of valid edges by (ion, type) - counted
+// in LDS, one global atomic per type the workgroup saw.
+__global__ __launch_bounds__(256) void wide_count_kernel(Inputs in, int32_t* __restrict__ kept,
+                                                         int32_t* __restrict__ cnt) {
+  __shared__ int32_t lh[2 * kMaxVb];
+  const int nT = in.n_ions * in.Vb;
+  for (int t = threadIdx.x; t < nT; t += 256) lh[t] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mols = in.n_ions * in.B;
+  for (int i = 0; i < kMolPerWg / 4; ++i) {
+    const int mol = blockIdx.x * kMolPerWg + wave * (kMolPerWg / 4) + i;
+    if (mol >= mols) break;
+    const int g = mol >= in.B ? 1 : 0, b = mol - g * in.B;
+    const int32_t* ids = in.atom_ids[g] + (int64_t)b * in.N;
+    int r = 0;
+    for (int n = lane; n < in.N; n += 64)
+      if (ids[n] > 0) r = n + 1;
+    for (int e = lane; e < in.E; e += 64) {
+      int sv, tv;
+      const int ty = valid_type(in.conn[g], in.bond_ids[g], (int64_t)b * in.E + e, in.N, in.Vb, sv, tv);
+      if (ty >= 0) {
+        const int mx = (sv > tv ? sv : tv) + 1;
+        r = r > mx ? r : mx;
+        atomicAdd(&lh[g * in.Vb + ty], 1);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int t = __shfl_xor(r, o);
+      r = r > t ? r : t;
+    }
+    if (lane == 0) kept[mol] = r;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < nT; t += 256)
+    if (lh[t]) atomicAdd(&cnt[t], lh[t]);
+}
+
+// One workgroup of 1024 threads: (a) exclusive scan of the kept rows per ion (an ion's first row is a multiple of kRT),
+// (b) per-type runs and tiles.
+__global__ __launch_bounds__(1024) void wide_scan_kernel(const int32_t* __restrict__ kept, int32_t* __restrict__ rowbase,
+                                                         const int32_t* __restrict__ cnt, int32_t* __restrict__ tstart,
+                                                         int32_t* __restrict__ cursor, int32_t* __restrict__ tilebase,
+                                                         int32_t* __restrict__ meta, int n_ions, int B, int nT, int te) {
+  __shared__ int32_t wsum[16], wsum2[16];
+  __shared__ int32_t carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int base = 0;
+  for (int g = 0; g < n_ions; ++g) {
+    const int per = (B + 1023) / 1024;
+    const int lo = tid * per, hi = lo + per < B ? lo + per : B;
+    int s = 0;
+    for (int b = lo; b < hi; ++b) s += kept[g * B + b];
+    int inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(inc, o);
+      if (lane >= o) inc += u;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    int run = base + off + inc - s;
+    for (int b = lo; b < hi; ++b) {
+      rowbase[g * B + b] = run;
+      run += kept[g * B + b];
+    }
+    if (tid == 1023) carry = off + inc;
+    __syncthreads();
+    const int rows = carry;
+    if (tid == 0) {
+      meta[kMetaRows + g] = rows;
+      meta[kMetaBase + g] = base;
+      meta[kMetaEnd] = base + rows;
+    }
+    base = (base + rows + kRT - 1) / kRT * kRT;
+    __syncthreads();
+  }
+  {  // types: nT <= 1024, one per thread
+    const int c = tid < nT ? cnt[tid] : 0;
+    const int tl = (c + te - 1) / te;
+    int ic = c, it = tl;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int uc = __shfl_up(ic, o), ut = __shfl_up(it, o);
+      if (lane >= o) {
+        ic += uc;
+        it += ut;
+      }
+    }
+    if (lane == 63) {
+      wsum[wave] = ic;
+      wsum2[wave] = it;
+    }
+    __syncthreads();
+    int oc = 0, ot = 0;
+    for (int w = 0; w < wave; ++w) {
+      oc += wsum[w];
+      ot += wsum2[w];
+    }
+    ic += oc;
+    it += ot;
+    if (tid < nT) {
+      tstart[tid] = ic - c;
+      cursor[tid] = ic - c;
+      tilebase[tid] = it - tl;
+    }
+    if (tid == 1023) {  // threads past nT carry zeros: the last inclusive values are the totals
+      tstart[nT] = ic;
+      tilebase[nT] = it;
+      meta[kMetaValid] = ic;
+      meta[kMetaTiles] = it;
+    }
+  }
+}
+
+// Places the valid edges of kMolPerWg molecules: a range per (ion, type) is reserved with one global atomic per
+// workgroup, positions inside it come from LDS atomics (where an edge lands inside its run does not matter: nothing
+// is summed across sorted positions).  Then, per molecule, the in-edge lists of its kept rows in edge-slot order:
+// rowinfo[row] = (first entry, in-degree), entries at the molecule's own E-slot segment of `csr`.
+__global__ __launch_bounds__(256) void wide_place_kernel(Inputs in, const int32_t* __restrict__ kept,
+                                                         const int32_t* __restrict__ rowbase,
+                                                         int32_t* __restrict__ cursor, int32_t* __restrict__ srcrow,
+                                                         int2* __restrict__ rowinfo, int32_t* __restrict__ csr) {
+  __shared__ int32_t lh[2 * kMaxVb];
+  __shared__ int16_t tg_s[4][kMaxE];   // target row of a slot, -1 = not a valid edge
+  __shared__ int32_t pos_s[4][kMaxE];  // its sorted position
+  __shared__ int32_t deg_s[4][kMaxN], off_s[4][kMaxN];
+  const int nT = in.n_ions * in.Vb;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mols = in.n_ions * in.B;
+  for (int t = threadIdx.x; t < nT; t += 256) lh[t] = 0;
+  __syncthreads();
+  for (int i = 0; i < kMolPerWg / 4; ++i) {
+    const int mol = blockIdx.x * kMolPerWg + wave * (kMolPerWg / 4) + i;
+    if (mol >= mols) break;
+    const int g = mol >= in.B ? 1 : 0, b = mol - g * in.B;
+    for (int e = lane; e < in.E; e += 64) {
+      int sv, tv;
+      const int ty = valid_type(in.conn[g], in.bond_ids[g], (int64_t)b * in.E + e, in.N, in.Vb, sv, tv);
+      if (ty >= 0) atomicAdd(&lh[g * in.Vb + ty], 1);
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < nT; t += 256) {
+    const int c = lh[t];
+    lh[t] = c ? atomicAdd(&cursor[t], c) : 0;
+  }
+  __syncthreads();
+  for (int i = 0; i < kMolPerWg / 4; ++i) {
+    const int mol = blockIdx.x * kMolPerWg + wave * (kMolPerWg / 4) + i;
+    if (mol >= mols) break;
+    const int g = mol >= in.B ? 1 : 0, b = mol - g * in.B;
+    const int r = kept[mol], rb = rowbase[mol];
+    for (int n = lane; n < r; n += 64) deg_s[wave][n] = 0;
+    for (int e = lane; e < in.E; e += 64) {
+      int sv, tv;
+      const int ty = valid_type(in.conn[g], in.bond_ids[g], (int64_t)b * in.E + e, in.N, in.Vb, sv, tv);
+      int16_t tg = -1;
+      if (ty >= 0) {
+        const int p = atomicAdd(&lh[g * in.Vb + ty], 1);
+        srcrow[p] = rb + sv;
+        pos_s[wave][e] = p;
+        tg = (int16_t)tv;
+        atomicAdd(&deg_s[wave][tv], 1);
+      }
+      tg_s[wave][e] = tg;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // this wave's LDS writes and atomics have landed
+    __builtin_amdgcn_wave_barrier();
+    // exclusive scan of the in-degrees over the kept rows (r <= kMaxN = 4 x 64)
+    int run = 0;
+    for (int n0 = 0; n0 < r; n0 += 64) {
+      const int n = n0 + lane;
+      const int d = n < r ? deg_s[wave][n] : 0;
+      int inc = d;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+      }
+      if (n < r) {
+        off_s[wave][n] = run + inc - d;
+        rowinfo[rb + n] = make_int2((int)((int64_t)mol * in.E) + run + inc - d, d);
+      }
+      run += __shfl(inc, 63);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // slot order inside a row's list: rank = earlier valid slots with the same target
+    for (int e = lane; e < in.E; e += 64) {
+      const int tg = tg_s[wave][e];
+      if (tg < 0) continue;
+      int rank = 0;
+      for (int e2 = 0; e2 < e; ++e2) rank += tg_s[wave][e2] == tg ? 1 : 0;
+      csr[(int64_t)mol * in.E + off_s[wave][tg] + rank] = pos_s[wave][e];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// run kernels
+// ------------------------------------------------------------------------------------------------------------
+// a1: one wave per molecule (4 in turn), a row per D/4 lanes; an id outside the vocabulary gives a zero row.
+__global__ __launch_bounds__(256) void wide_embed_kernel(Inputs in, const int32_t* __restrict__ kept,
+                                                         const int32_t* __restrict__ rowbase,
+                                                         const float* __restrict__ table, float* __restrict__ h, int D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int mols = in.n_ions * in.B, qd = D >> 2, rpw = 64 / qd;
+  const int sub = lane / qd, c4 = lane - sub * qd;
+  for (int i = 0; i < kMolPerWg / 4; ++i) {
+    const int mol = blockIdx.x * kMolPerWg + wave * (kMolPerWg / 4) + i;
+    if (mol >= mols) break;
+    const int g = mol >= in.B ? 1 : 0, b = mol - g * in.B;
+    const int r = kept[mol], rb = rowbase[mol];
+    const int32_t* ids = in.atom_ids[g] + (int64_t)b * in.N;
+    for (int n = sub; n < r; n += rpw) {
+      const int id = ids[n];
+      f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)id < (unsigned)in.Va) v = ldv4(table + (int64_t)id * D + 4 * c4);
+      stv4(h + (int64_t)(rb + n) * D + 4 * c4, v);
+    }
+  }
+}
+
+// a4 over the type-sorted edge list.  A workgroup walks a contiguous range of TE-edge tiles; tiles of one type are
+// consecutive, so the type's D x D matrix (64 KB at D = 128) stays in LDS until the type changes.  Output tile =
+// (features on M) x (edges on N): lane (a, q) of the accumulator of feature tile T holds features 16T + 4q .. +3 of
+// edge a - one 16-byte store per tile.  The next tile's source rows (and, at a type change, the next matrix) are
+// requested before the MFMAs of the current tile and stored to the other LDS buffer after them.
+struct MsgParams {
+  const float* h;
+  float* m;
+  const float* img[2];      // prepared images; the type matrices of this step start at img[g] + mat_off
+  size_t mat_off;
+  const int32_t* srcrow;
+  const int32_t* tstart;
+  const int32_t* tilebase;
+  const int32_t* meta;
+  int nT, Vb;
+};
+
+template <int NT, int TE>
+__global__ __launch_bounds__(1024) void wide_message_kernel(MsgParams p) {
+  constexpr int D = 16 * NT, LD = D + 4, QD = D / 4;
+  constexpr int EG = TE / 16, FG = 16 / EG, NLW = NT / FG;  // edge tiles, feature groups, feature tiles per wave
+  constexpr int kX = TE * QD / 1024, kB = D * QD / 1024;    // 16-byte pieces per thread: a tile of rows, the matrix
+  static_assert(kX >= 1 && kB >= 1 && NLW >= 1, "tile shape");
+  extern __shared__ __align__(16) float smem[];
+  float* Bm = smem;               // D x LD
+  float* Xb = Bm + D * LD;        // 2 x TE x LD
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = lane & 15, q = lane >> 4;
+  const int et = wave % EG, fg = wave / EG;
+  const int ntiles = p.meta[kMetaTiles];
+  const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t0 = blockIdx.x * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+  if (t0 >= t1) return;
+  // type of the first tile: largest t with tilebase[t] <= t0 (empty types share a base with their successor: skip on)
+  int ty;
+  {
+    int lo = 0, hi = p.nT - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (p.tilebase[mid] <= t0) lo = mid; else hi = mid - 1;
+    }
+    ty = lo;
+  }
+  auto mat_of = [&](int t) {
+    const int g = t >= p.Vb ? 1 : 0;
+    return p.img[g] + p.mat_off + (size_t)(t - g * p.Vb) * D * D;
+  };
+  f32x4_t xr[kX], br[kB];
+  auto fetch_x = [&](int p0, int n) {
+#pragma unroll
+    for (int i = 0; i < kX; ++i) {
+      const int idx = tid + 1024 * i, e = idx / QD, c4 = idx - e * QD;
+      xr[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if (e < n) xr[i] = ldv4(p.h + (int64_t)p.srcrow[p0 + e] * D + 4 * c4);
+    }
+  };
+  auto park_x = [&](float* X) {
+#pragma unroll
+    for (int i = 0; i < kX; ++i) {
+      const int idx = tid + 1024 * i, e = idx / QD, c4 = idx - e * QD;
+      stv4(X + e * LD + 4 * c4, xr[i]);
+    }
+  };
+  auto fetch_b = [&](int t) {
+    const float* A = mat_of(t);
+#pragma unroll
+    for (int i = 0; i < kB; ++i) br[i] = ldv4(A + (size_t)(tid + 1024 * i) * 4);
+  };
+  auto park_b = [&]() {
+#pragma unroll
+    for (int i = 0; i < kB; ++i) {
+      const int idx = tid + 1024 * i, r = idx / QD, c4 = idx - r * QD;
+      stv4(Bm + r * LD + 4 * c4, br[i]);
+    }
+  };
+  int tile = t0;
+  while (p.tilebase[ty + 1] <= tile) ++ty;
+  int p0 = p.tstart[ty] + (tile - p.tilebase[ty]) * TE;
+  int n = min(TE, p.tstart[ty + 1] - p0);
+  fetch_x(p0, n);
+  fetch_b(ty);
+  park_x(Xb);
+  park_b();
+  __syncthreads();
+  int cur = 0;
+  for (;;) {
+    const bool more = tile + 1 < t1;
+    int ty2 = ty, p02 = 0, n2 = 0;
+    if (more) {
+      while (p.tilebase[ty2 + 1] <= tile + 1) ++ty2;
+      p02 = p.tstart[ty2] + (tile + 1 - p.tilebase[ty2]) * TE;
+      n2 = min(TE, p.tstart[ty2 + 1] - p02);
+      fetch_x(p02, n2);
+      if (ty2 != ty) fetch_b(ty2);
+    }
+    {
+      const float* X = Xb + cur * TE * LD;
+      f32x4_t acc[NLW];
+#pragma unroll
+      for (int TL = 0; TL < NLW; ++TL) acc[TL] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const float* xrow = X + (16 * et + a) * LD + 4 * q;
+      const float* arow = Bm + (16 * (fg * NLW) + a) * LD + 4 * q;
+#pragma unroll 2
+      for (int u = 0; u < NT; ++u) {
+        const f32x4_t xv = ldv4(xrow + 16 * u);
+        f32x4_t av[NLW];
+#pragma unroll
+        for (int TL = 0; TL < NLW; ++TL) av[TL] = ldv4(arow + 16 * TL * LD + 16 * u);
+#pragma unroll
+        for (int TL = 0; TL < NLW; ++TL)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[TL] = mfma_f32(av[TL][r], xv[r], acc[TL]);
+      }
+      const int e = 16 * et + a;
+      if (e < n) {
+        float* dst = p.m + (int64_t)(p0 + e) * D + 16 * (fg * NLW) + 4 * q;
+#pragma unroll
+        for (int TL = 0; TL < NLW; ++TL) stv4(dst + 16 * TL, acc[TL]);
+      }
+    }
+    if (!more) break;
+    park_x(Xb + (cur ^ 1) * TE * LD);
+    if (ty2 != ty) {      // (workgroup-uniform)
+      __syncthreads();    // every wave is done with the old matrix
+      park_b();
+    }
+    __syncthreads();
+    cur ^= 1;
+    ++tile;
+    ty = ty2;
+    p0 = p02;
+    n = n2;
+  }
+}
+
+// a5 on the compact rows: D/4 lanes per row, the in-edge messages added in edge-slot order with 4 rows in flight.
+__global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restrict__ m, const int2* __restrict__ rowinfo,
+                                                          const int32_t* __restrict__ csr, float* __restrict__ agg,
+                                                          const int32_t* __restrict__ meta, int n_ions, int D) {
+  const int qd = D >> 2;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t row = t / qd;
+  const int c4 = (int)(t - row * qd);
+  if (row >= meta[kMetaEnd]) return;
+  if (n_ions > 1 && row >= meta[kMetaRows] && row < meta[kMetaBase + 1]) return;  // the gap in front of ion 1
+  const int2 ri = rowinfo[row];
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  int i = 0;
+  for (; i + 4 <= ri.y; i += 4) {
+    const int p0 = csr[ri.x + i], p1 = csr[ri.x + i + 1], p2 = csr[ri.x + i + 2], p3 = csr[ri.x + i + 3];
+    const f32x4_t v0 = ldv4(m + (int64_t)p0 * D + 4 * c4), v1 = ldv4(m + (int64_t)p1 * D + 4 * c4);
+    const f32x4_t v2 = ldv4(m + (int64_t)p2 * D + 4 * c4), v3 = ldv4(m + (int64_t)p3 * D + 4 * c4);
+    acc += v0;
+    acc += v1;
+    acc += v2;
+    acc += v3;
+  }
+  for (; i < ri.y; ++i) acc += ldv4(m + (int64_t)csr[ri.x + i] * D + 4 * c4);
+  stv4(agg + row * D + 4 * c4, acc);
+}
+
+// a7 on 128-row tiles of the compact row space, h updated in place.
+//   phase 1   [z|r] pre-activations = [h|agg] (128 x 2D) x [Wz|Wr] (2D x 2D): 2 NT slices of 16 k; a slice of the rows
+//             (8 KB, MFMA operand order [k quad][row][4]) and of the kernels (16 KB at D = 128, the image's own order)
+//             goes global -> registers (two slices ahead) -> one of two LDS stages; one barrier per slice, 32 MFMAs
+//             per wave between barriers (wave = 32 rows x 2 NL feature tiles).
+//   phase 2   candidate = [r*h|agg] x Wh: NT steps of 32 k; r*h comes from LDS (written once after phase 1), agg and
+//             Wh through the stages.
+//   epilogue  blend, LayerNorm (row sums across the four feature groups through LDS), residual.
+// h of the accumulator positions is read once into registers (for r*h, the blend and the residual).
+struct GuParams {
+  float* h;
+  const float* agg;
+  const float* img[2];  // the step's GatedUpdate image starts at img[g] + gu_off
+  size_t gu_off;
+  const int32_t* meta;
+  float eps;
+  int n_ions;
+};
+
+template <int NT>
+__global__ __launch_bounds__(1024) void wide_update_kernel(GuParams p) {
+  constexpr int D = 16 * NT, R = kRT, NL = NT / 4, LDR = D + 4;
+  constexpr int A1 = 4 * R * 4;       // floats of a 16-k slice of the rows
+  constexpr int B1 = 4 * 2 * D * 4;   // ... of [Wz|Wr]
+  constexpr int B2 = 4 * D * 4;       // ... of Wh
+  constexpr int ST = (A1 + B1) > (2 * A1 + 2 * B2) ? (A1 + B1) : (2 * A1 + 2 * B2);  // stage floats
+  static_assert(B1 / 4 <= 1024 && 2 * B2 / 4 <= 1024, "one 16-byte piece per thread");
+  extern __shared__ __align__(16) float smem[];
+  float* stage = smem;                 // 2 x ST
+  float* rhs = stage + 2 * ST;         // R x LDR : r * h
+  float* part = rhs + R * LDR;         // 2 x 4 x R LayerNorm partials
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, a = lane & 15, q = lane >> 4;
+  const int rg = wv & 3, fg = wv >> 2;  // row group (32 rows), feature group (NL tiles of z, r and the candidate)
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  const int end = p.meta[kMetaEnd];
+  if (row0 >= end) return;
+  const int g = (p.n_ions > 1 && row0 >= p.meta[kMetaBase + 1]) ? 1 : 0;
+  const int64_t row_end = p.meta[kMetaBase + g] + p.meta[kMetaRows + g];  // rows of this tile beyond it are padding
+  if (row0 >= row_end) return;
+  const float* img = p.img[g] + p.gu_off;
+  const float* P1 = img;
+  const float* P2 = img + 4 * D * D;
+  const float* bias = img + 6 * D * D;  // bz br bh gamma beta
+  // (padding rows of the last tile of an ion lie inside the workspace; whatever they hold stays in their own rows)
+  const int a_row = (tid & 511) >> 2, a_c4 = tid & 3, a_sub = tid >> 9;
+  const float* hsrc = p.h + (row0 + a_row) * D + 4 * a_c4;
+  const float* gsrc = p.agg + (row0 + a_row) * D + 4 * a_c4;
+  struct Pre {
+    f32x4_t av, bv;
+  };
+  Pre preA, preB;
+  auto fetch1 = [&](int u, Pre& pre) {
+    if (tid < B1 / 4) pre.bv = ldv4(P1 + (size_t)u * B1 + tid * 4);
+    if (tid < 512) pre.av = ldv4((u < NT ? hsrc : gsrc - D) + 16 * u);
+  };
+  auto park1 = [&](float* st, const Pre& pre) {
+    if (tid < B1 / 4) stv4(st + A1 + tid * 4, pre.bv);
+    if (tid < 512) stv4(st + (a_c4 * R + a_row) * 4, pre.av);
+  };
+  f32x4_t z[2][NL], rr[2][NL];
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL) {
+    const int f = 16 * (fg * NL + TL) + a;
+    const float b0 = bias[f], b1 = bias[D + f];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      z[rt][TL] = f32x4_t{b0, b0, b0, b0};
+      rr[rt][TL] = f32x4_t{b1, b1, b1, b1};
+    }
+  }
+  struct Ops1 {
+    f32x4_t av[2], bz[NL], br[NL];
+  };
+  auto read1 = [&](const float* st, Ops1& o) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) o.av[rt] = ldv4(st + (q * R + 32 * rg + 16 * rt + a) * 4);
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL) {
+      o.bz[TL] = ldv4(st + A1 + (q * 2 * D + 16 * (fg * NL + TL) + a) * 4);
+      o.br[TL] = ldv4(st + A1 + (q * 2 * D + D + 16 * (fg * NL + TL) + a) * 4);
+    }
+  };
+  auto mma1 = [&](const Ops1& o) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int TL = 0; TL < NL; ++TL) {
+          z[rt][TL] = mfma_f32(o.av[rt][r], o.bz[TL][r], z[rt][TL]);
+          rr[rt][TL] = mfma_f32(o.av[rt][r], o.br[TL][r], rr[rt][TL]);
+        }
+  };
+  fetch1(0, preA);
+  fetch1(1, preB);
+  park1(stage, preA);
+  __syncthreads();
+  // h at this lane's accumulator positions (rows 4q + g of both row tiles, feature a of its NL tiles): requested under
+  // the last two slices of phase 1 - held from the start they cost 16 registers the phase does not have
+  float hreg[2][NL][4];
+  auto load_hreg = [&]() {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          hreg[rt][TL][gq] = p.h[(row0 + 32 * rg + 16 * rt + 4 * q + gq) * D + 16 * (fg * NL + TL) + a];
+  };
+  // iteration u: slice u is in stage u & 1, slice u + 1 in registers, slice u + 2 is requested; stage (u + 1) & 1 was
+  // last read in iteration u - 1, whose closing barrier every wave has passed
+  auto pair1 = [&](int u) {
+    Ops1 o;
+    if (u + 2 < 2 * NT) fetch1(u + 2, preA);
+    read1(stage, o);
+    __builtin_amdgcn_sched_barrier(0);
+    park1(stage + ST, preB);
+    __builtin_amdgcn_sched_barrier(0);
+    mma1(o);
+    __syncthreads();
+    if (u + 3 < 2 * NT) fetch1(u + 3, preB);
+    read1(stage + ST, o);
+    __builtin_amdgcn_sched_barrier(0);
+    if (u + 2 < 2 * NT) park1(stage, preA);
+    __builtin_amdgcn_sched_barrier(0);
+    mma1(o);
+    __syncthreads();
+  };
+  for (int u = 0; u < 2 * NT - 2; u += 2) pair1(u);
+  load_hreg();
+  pair1(2 * NT - 2);
+  // ---- phase 2
+  auto fetch2 = [&](int v, Pre& pre) {
+    if (tid < 2 * B2 / 4) pre.bv = ldv4(P2 + (size_t)v * 2 * B2 + tid * 4);
+    if (2 * v >= NT) pre.av = ldv4(gsrc + (32 * v - D) + 16 * a_sub);
+  };
+  auto park2 = [&](int v, float* st, const Pre& pre) {
+    if (tid < 2 * B2 / 4) stv4(st + 2 * A1 + tid * 4, pre.bv);
+    if (2 * v >= NT) stv4(st + a_sub * A1 + (a_c4 * R + a_row) * 4, pre.av);
+  };
+  fetch2(0, preA);
+  if (NT > 1) fetch2(1, preB);
+  // gates; r * h into LDS (phase 2 reads the rows of this wave's row group written by all four feature groups)
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        z[rt][TL][gq] = fsig(z[rt][TL][gq]);
+        rhs[(32 * rg + 16 * rt + 4 * q + gq) * LDR + 16 * (fg * NL + TL) + a] = fsig(rr[rt][TL][gq]) * hreg[rt][TL][gq];
+      }
+  f32x4_t tt[2][NL];
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL) {
+    const float b2 = bias[2 * D + 16 * (fg * NL + TL) + a];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) tt[rt][TL] = f32x4_t{b2, b2, b2, b2};
+  }
+  park2(0, stage, preA);
+  __syncthreads();
+  struct Ops2 {
+    f32x4_t av[2], bv[NL];
+  };
+  auto read2 = [&](int v, int sub, const float* st, Ops2& o) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+      o.av[rt] = 2 * v < NT ? ldv4(rhs + (32 * rg + 16 * rt + a) * LDR + 16 * (2 * v + sub) + 4 * q)
+                            : ldv4(st + sub * A1 + (q * R + 32 * rg + 16 * rt + a) * 4);
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL) o.bv[TL] = ldv4(st + 2 * A1 + sub * B2 + (q * D + 16 * (fg * NL + TL) + a) * 4);
+  };
+  auto mma2 = [&](const Ops2& o) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int TL = 0; TL < NL; ++TL) tt[rt][TL] = mfma_f32(o.av[rt][r], o.bv[TL][r], tt[rt][TL]);
+  };
+  for (int v = 0; v < NT; v += 2) {
+    Ops2 o0, o1;
+    if (v + 2 < NT) fetch2(v + 2, preA);
+    read2(v, 0, stage, o0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (v + 1 < NT) park2(v + 1, stage + ST, preB);
+    read2(v, 1, stage, o1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma2(o0);
+    mma2(o1);
+    __syncthreads();
+    if (v + 1 >= NT) break;
+    if (v + 3 < NT) fetch2(v + 3, preB);
+    read2(v + 1, 0, stage + ST, o0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (v + 2 < NT) park2(v + 2, stage, preA);
+    read2(v + 1, 1, stage + ST, o1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma2(o0);
+    mma2(o1);
+    __syncthreads();
+  }
+  // ---- blend, LayerNorm over the D features of a row, residual (models/layers.py:150-156)
+  float sum[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      float s = 0.f;
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL) {
+        const float hv = hreg[rt][TL][gq];
+        const float nv = (1.0f - z[rt][TL][gq]) * hv + z[rt][TL][gq] * ftanh(tt[rt][TL][gq]);
+        tt[rt][TL][gq] = nv;
+        s += nv;
+      }
+      sum[rt][gq] = row16_sum_f(s);
+      if (a == 0) part[fg * R + 32 * rg + 16 * rt + 4 * q + gq] = sum[rt][gq];
+    }
+  __syncthreads();
+  float mean[2][4], inv[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int rl = 32 * rg + 16 * rt + 4 * q + gq;
+      mean[rt][gq] = ((part[rl] + part[R + rl]) + (part[2 * R + rl] + part[3 * R + rl])) * (1.0f / D);
+      float vs = 0.f;
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL) {
+        const float d = tt[rt][TL][gq] - mean[rt][gq];
+        vs = fmaf(d, d, vs);
+      }
+      vs = row16_sum_f(vs);
+      if (a == 0) part[4 * R + fg * R + rl] = vs;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int rl = 4 * R + 32 * rg + 16 * rt + 4 * q + gq;
+      inv[rt][gq] = 1.0f / sqrtf(((part[rl] + part[R + rl]) + (part[2 * R + rl] + part[3 * R + rl])) * (1.0f / D) + p.eps);
+    }
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL) {
+    const int f = 16 * (fg * NL + TL) + a;
+    const float gm = bias[3 * D + f], bt = bias[4 * D + f];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int64_t row = row0 + 32 * rg + 16 * rt + 4 * q + gq;
+        if (row < row_end)
+          p.h[row * D + f] = (tt[rt][TL][gq] - mean[rt][gq]) * inv[rt][gq] * gm + bt + hreg[rt][TL][gq];
+      }
+  }
+}
+
+// a8: one thread per 16-byte piece of a pooled row, 4 rows in flight, ascending n.
+__global__ __launch_bounds__(256) void wide_pool_kernel(Inputs in, const int32_t* __restrict__ kept,
+                                                        const int32_t* __restrict__ rowbase,
+                                                        const float* __restrict__ h, float* __restrict__ pooled0,
+                                                        float* __restrict__ pooled1, int D) {
+  const int qd = D >> 2;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t mol = t / qd;
+  const int c4 = (int)(t - mol * qd);
+  if (mol >= (int64_t)in.n_ions * in.B) return;
+  const int g = mol >= in.B ? 1 : 0, b = (int)(mol - (int64_t)g * in.B);
+  const int r = kept[mol];
+  const int32_t* ids = in.atom_ids[g] + (int64_t)b * in.N;
+  const float* src = h + (int64_t)rowbase[mol] * D + 4 * c4;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+  int n = 0;
+  for (; n + 4 <= r; n += 4) {
+    const f32x4_t v0 = ldv4(src + (int64_t)n * D), v1 = ldv4(src + (int64_t)(n + 1) * D);
+    const f32x4_t v2 = ldv4(src + (int64_t)(n + 2) * D), v3 = ldv4(src + (int64_t)(n + 3) * D);
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    acc += ids[n] > 0 ? v0 : zero;
+    acc += ids[n + 1] > 0 ? v1 : zero;
+    acc += ids[n + 2] > 0 ? v2 : zero;
+    acc += ids[n + 3] > 0 ? v3 : zero;
+  }
+  for (; n < r; ++n)
+    if (ids[n] > 0) acc += ldv4(src + (int64_t)n * D);
+  stv4((g ? pooled1 : pooled0) + (int64_t)b * D + 4 * c4, acc);
+}
+
+// The GatedUpdate part of a prepared step: [Wz|Wr] and Wh in slice order [16-k slice][k quad][column][k & 3], then
+// the five vectors.  src = the step's canonical weights behind bond_transform (include/impnn.h).
+__global__ void wide_gu_image_kernel(const float* __restrict__ src, float* __restrict__ dst, int D) {
+  const float* Wz = src;
+  const float* bz = Wz + 2 * D * D;
+  const float* Wr = bz + D;
+  const float* br = Wr + 2 * D * D;
+  const float* Wh = br + D;
+  const float* bh = Wh + 2 * D * D;
+  const float* gamma = bh + D;
+  const float* beta = gamma + D;
+  const int n1 = 4 * D * D, n2 = 2 * D * D, total = n1 + n2 + 5 * D;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    float v;
+    if (t < n1) {
+      const int r = t & 3, c = (t >> 2) % (2 * D), qq = ((t >> 2) / (2 * D)) & 3, u = (t >> 2) / (2 * D) >> 2;
+      const int k = 16 * u + 4 * qq + r;
+      v = c < D ? Wz[k * D + c] : Wr[k * D + c - D];
+    } else if (t < n1 + n2) {
+      const int s = t - n1;
+      const int r = s & 3, c = (s >> 2) % D, qq = ((s >> 2) / D) & 3, u = (s >> 2) / D >> 2;
+      v = Wh[(16 * u + 4 * qq + r) * D + c];
+    } else {
+      const int s = t - n1 - n2, which = s / D, f = s - which * D;
+      const float* vec = which == 0 ? bz : which == 1 ? br : which == 2 ? bh : which == 3 ? gamma : beta;
+      v = vec[f];
+    }
+    dst[t] = v;
+  }
+}
+
+}  // namespace wide
+
+// ------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------
+bool encoder_wide_supported(int N, int E, int D, int K, int S, int Vb) {
+  using namespace wide;
+  return (D == 64 || D == 128) && K >= 1 && S >= 0 && N >= 1 && N <= kMaxN && E >= 0 && E <= kMaxE && Vb >= 1 &&
+         Vb <= kMaxVb;
+}
+
+size_t encoder_wide_workspace_bytes(int n_ions, int B, int N, int E, int D, int S, int Vb) {
+  return wide::ws_layout(n_ions, B, N, E, D, S, Vb).total;
+}
+
+size_t encoder_wide_prepared_bytes(int D, int S, int Vb) { return wide::prepared_bytes(D, S, Vb); }
+
+int launch_encoder_wide_prepare(const float* weights, const float* bond_table, int D, int K, int S, int Vb,
+                                void* prepared, hipStream_t s) {
+  using namespace wide;
+  float* img = static_cast<float*>(prepared);
+  const size_t canon = (size_t)impnn_encoder_step_floats(D, K);
+  for (int st = 0; st < S; ++st) {
+    const float* w = weights + (size_t)st * canon;
+    float* dst = img + (size_t)st * step_floats(D, Vb);
+    if (int rc = launch_bond_type_matrices(bond_table, w, dst, Vb, K, D, s)) return rc;
+    wide_gu_image_kernel<<<64, 256, 0, s>>>(w + (size_t)K * D * D, dst + (size_t)Vb * D * D, D);
+    if (int rc = check_launch("encoder_wide_prepare")) return rc;
+  }
+  return IMPNN_OK;
+}
+
+namespace {
+template <typename K>
+int raise_lds(K kern, size_t bytes) {
+  if (bytes <= 64 * 1024) return IMPNN_OK;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return fail(IMPNN_E_LAUNCH, "encoder_wide: cannot raise the LDS limit: %s", hipGetErrorString(e));
+  return IMPNN_OK;
+}
+}  // namespace
+
+int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
+  using namespace wide;
+  const Ws w = ws_layout(a.n_ions, a.B, a.N, a.E, a.D, a.S, a.Vb);
+  if (!aligned16(a.workspace)) return fail(IMPNN_E_BADARG, "encoder_fused: workspace must be 16B aligned");
+  char* base = static_cast<char*>(a.workspace);
+  auto I = [&](size_t off) { return reinterpret_cast<int32_t*>(base + off); };
+  auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
+  Inputs in{};
+  for (int g = 0; g < a.n_ions; ++g) {
+    in.atom_ids[g] = a.atom_ids[g];
+    in.bond_ids[g] = a.bond_ids[g];
+    in.conn[g] = a.conn[g];
+  }
+  in.n_ions = a.n_ions; in.B = a.B; in.N = a.N; in.E = a.E; in.Va = a.Va; in.Vb = a.Vb;
+  const int mols = a.n_ions * a.B;
+  const int mol_wgs = (mols + kMolPerWg - 1) / kMolPerWg;
+  const int te = tile_edges(a.D);
+  if (a.phases & 1) {
+    const int nz = (int)((w.kept - w.meta) / 4);  // meta and the type counters
+    wide_zero_kernel<<<(nz + 255) / 256, 256, 0, s>>>(I(w.meta), nz);
+    wide_count_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.cnt));
+    wide_scan_kernel<<<1, 1024, 0, s>>>(I(w.kept), I(w.rowbase), I(w.cnt), I(w.tstart), I(w.cursor), I(w.tilebase),
+                                        I(w.meta), a.n_ions, a.B, w.nT, te);
+    wide_place_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.rowbase), I(w.cursor), I(w.srcrow),
+                                              reinterpret_cast<int2*>(base + w.rowinfo), I(w.csr));
+    if (int rc = check_launch("encoder_wide plan")) return rc;
+  }
+  if (!(a.phases & 2)) return IMPNN_OK;
+  if (!aligned16(a.atom_table)) return fail(IMPNN_E_BADARG, "encoder_fused: atom_table must be 16B aligned");
+  const float* img[2] = {nullptr, nullptr};
+  for (int g = 0; g < a.n_ions && a.S > 0; ++g) {
+    if (a.prepared[g]) {
+      if (!aligned16(a.prepared[g])) return fail(IMPNN_E_BADARG, "encoder_fused: prepared weights must be 16B aligned");
+      img[g] = static_cast<const float*>(a.prepared[g]);
+    } else {
+      float* dst = reinterpret_cast<float*>(base + w.img + (size_t)g * prepared_bytes(a.D, a.S, a.Vb));
+      if (int rc = launch_encoder_wide_prepare(a.weights[g], a.bond_table, a.D, a.K, a.S, a.Vb, dst, s)) return rc;
+      img[g] = dst;
+    }
+  }
+  if (a.n_ions == 1) img[1] = img[0];
+  profile_record_start(s);
+  wide_embed_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.rowbase), a.atom_table, F(w.h), a.D);
+  const int cus = 256;
+  const size_t msg_lds = ((size_t)a.D * (a.D + 4) + 2 * (size_t)te * (a.D + 4)) * 4;
+  const int nt = a.D / 16;
+  constexpr int R = kRT;
+  const size_t a1 = 4 * R * 4, b1 = 4 * 2 * (size_t)a.D * 4, b2 = 4 * (size_t)a.D * 4;
+  const size_t st = (a1 + b1) > (2 * a1 + 2 * b2) ? (a1 + b1) : (2 * a1 + 2 * b2);
+  const size_t gu_lds = (2 * st + (size_t)R * (a.D + 4) + 8 * R) * 4;
+  if (a.D == 128) {
+    if (int rc = raise_lds(wide_message_kernel<8, 64>, msg_lds)) return rc;
+    if (int rc = raise_lds(wide_update_kernel<8>, gu_lds)) return rc;
+  } else {
+    if (int rc = raise_lds(wide_message_kernel<4, 128>, msg_lds)) return rc;
+    if (int rc = raise_lds(wide_update_kernel<4>, gu_lds)) return rc;
+  }
+  const int64_t red_threads = w.rmax * (a.D / 4);
+  const int gu_grid = (int)(w.rmax / R);
+  for (int stp = 0; stp < a.S; ++stp) {
+    const size_t step_off = (size_t)stp * step_floats(a.D, a.Vb);
+    MsgParams mp{};
+    mp.h = F(w.h); mp.m = F(w.m);
+    mp.img[0] = img[0]; mp.img[1] = img[1];
+    mp.mat_off = step_off;
+    mp.srcrow = I(w.srcrow); mp.tstart = I(w.tstart); mp.tilebase = I(w.tilebase); mp.meta = I(w.meta);
+    mp.nT = w.nT; mp.Vb = a.Vb;
+    if (a.E > 0) {
+      if (nt == 8) wide_message_kernel<8, 64><<<cus, 1024, msg_lds, s>>>(mp);
+      else wide_message_kernel<4, 128><<<cus, 1024, msg_lds, s>>>(mp);
+    }
+    wide_reduce_kernel<<<(unsigned)((red_threads + 255) / 256), 256, 0, s>>>(
+        F(w.m), reinterpret_cast<const int2*>(base + w.rowinfo), I(w.csr), F(w.agg), I(w.meta), a.n_ions, a.D);
+    GuParams gp{};
+    gp.h = F(w.h); gp.agg = F(w.agg);
+    gp.img[0] = img[0]; gp.img[1] = img[1];
+    gp.gu_off = step_off + (size_t)a.Vb * a.D * a.D;
+    gp.meta = I(w.meta); gp.eps = a.ln_eps; gp.n_ions = a.n_ions;
+    if (nt == 8) wide_update_kernel<8><<<gu_grid, 1024, gu_lds, s>>>(gp);
+    else wide_update_kernel<4><<<gu_grid, 1024, gu_lds, s>>>(gp);
+  }
+  const int64_t pool_threads = (int64_t)mols * (a.D / 4);
+  wide_pool_kernel<<<(unsigned)((pool_threads + 255) / 256), 256, 0, s>>>(in, I(w.kept), I(w.rowbase), F(w.h),
+                                                                         a.pooled[0], a.n_ions > 1 ? a.pooled[1] : nullptr,
+                                                                         a.D);
+  profile_record_stop(s);
+  return check_launch("encoder_wide");
+}
+
+}  // namespace impnn

@@ -364,7 +364,7 @@ def prepare_encoder_weights(packed, bond_table, D, K, num_steps, mode="f32t"):
     packed, bond_table = f32c(packed), f32c(bond_table)
     S, Vb = int(num_steps), int(bond_table.shape[0])
     lib = _lib.load()
-    nbytes = int(lib.impnn_encoder_prepared_bytes(S, Vb, ENCODER_MODES[mode]))
+    nbytes = int(lib.impnn_encoder_prepared_bytes(D, S, Vb, ENCODER_MODES[mode]))
     out = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=packed.device)
     with torch.cuda.device(packed.device):
         rc = lib.impnn_encoder_prepare_weights(ptr(packed), ptr(bond_table), D, K, S, Vb, ENCODER_MODES[mode],
@@ -427,7 +427,7 @@ def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=L
               ptr(atom_table), Va, ptr(bond_table), Vb)
     with torch.cuda.device(dev):
         if prepared is not None:
-            if len(prepared) != n or any(int(t.numel()) < int(lib.impnn_encoder_prepared_bytes(S, Vb, mode_i))
+            if len(prepared) != n or any(int(t.numel()) < int(lib.impnn_encoder_prepared_bytes(D, S, Vb, mode_i))
                                          for t in prepared):
                 raise ValueError("prepared weight images do not match (n_ions, num_steps, bond vocabulary, mode)")
             check(lib.impnn_encoder_fused_prepared(n, *common, mk(prepared), mode_i, mk(pooled), B, N, E,

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 def test_identity():
     lib = _lib.load()
-    assert lib.impnn_abi_version() == 2
+    assert lib.impnn_abi_version() == 3
     assert lib.impnn_target_arch() == b"gfx950"
     assert lib.impnn_encoder_step_floats(32, 8) == 8 * 1024 + 3 * (2048 + 32) + 64
 
@@ -60,7 +60,14 @@ def test_encoder_shape_coverage_is_reported():
     for mode in (F32, F16X2, TYPED):
         assert lib.impnn_encoder_workspace_bytes(2, 4096, 40, 80, 32, 8, 3, 72, mode, 0, C.byref(need)) == 0
         assert 0 < need.value < (64 << 20)
-        assert lib.impnn_encoder_workspace_bytes(2, 4096, 40, 80, 128, 8, 3, 72, mode, 0, C.byref(need)) == -2   # D=128
+        # wide states (train_viscosity.py with atom_dim=128): the per-bond-type mode only (csrc/encoder_wide.hip)
+        rc = lib.impnn_encoder_workspace_bytes(2, 4096, 40, 80, 128, 8, 6, 72, mode, 0, C.byref(need))
+        assert rc == (0 if mode == TYPED else -2)
+    assert (256 << 20) < need.value < (2 << 30)
+    assert lib.impnn_encoder_workspace_bytes(2, 64, 40, 80, 64, 8, 3, 72, TYPED, 0, C.byref(need)) == 0        # D=64
+    assert lib.impnn_encoder_workspace_bytes(2, 64, 40, 80, 48, 8, 3, 72, TYPED, 0, C.byref(need)) == -2       # D=48
+    assert lib.impnn_encoder_workspace_bytes(2, 64, 40, 600, 128, 8, 3, 72, TYPED, 0, C.byref(need)) == -2     # E > 512
+    assert lib.impnn_encoder_workspace_bytes(2, 64, 40, 80, 128, 8, 3, 72, 3, 0, C.byref(need)) == -2          # no f32x3
     # K = D*D (train_melting_point.py:146): the typed mode covers it (BASELINE config 3), the pull form does not
     assert lib.impnn_encoder_workspace_bytes(2, 8192, 40, 80, 32, 1024, 4, 72, TYPED, 0, C.byref(need)) == 0
     assert lib.impnn_encoder_workspace_bytes(2, 4096, 40, 80, 32, 1024, 3, 72, F32, 0, C.byref(need)) == -2
@@ -70,7 +77,9 @@ def test_encoder_shape_coverage_is_reported():
     assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 80, 32, 8, 3, 72, 3, 0, C.byref(need)) == 0        # f32x3
     assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 80, 32, 8, 3, 72, 4, 0, C.byref(need)) == -1       # no mode 4
     assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 80, 32, 8, 3, 72, F32, -1, C.byref(need)) == -1
-    assert lib.impnn_encoder_prepared_bytes(3, 72, 3) > lib.impnn_encoder_prepared_bytes(3, 72, TYPED) > lib.impnn_encoder_prepared_bytes(3, 72, F32) > 0
+    assert lib.impnn_encoder_prepared_bytes(32, 3, 72, 3) > lib.impnn_encoder_prepared_bytes(32, 3, 72, TYPED) > lib.impnn_encoder_prepared_bytes(32, 3, 72, F32) > 0
+    assert lib.impnn_encoder_prepared_bytes(128, 6, 72, TYPED) == 6 * (72 * 128 * 128 + 6 * 128 * 128 + 5 * 128) * 4
+    assert lib.impnn_encoder_prepared_bytes(128, 6, 72, F32) == 0 and lib.impnn_encoder_prepared_bytes(48, 6, 72, TYPED) == 0
 
 
 def test_encoder_sizing_has_no_hidden_state():

@@ -1,0 +1,179 @@
+"""Wide atom states (atom_dim 64 / 128) through the encoder entries: csrc/encoder_wide.hip against the oracle
+(oracle/mpnn_oracle.py, the restatement of models/layers.py:57-164 and train_viscosity.py:166-190) and against the
+layer-at-a-time HIP kernels.  Tolerance 1e-5 relative (BASELINE.json north_star), conftest.assert_close."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close
+from ionic_mpnn_amd import model as MM
+from ionic_mpnn_amd import ops, synthetic, weights
+from oracle import mpnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = torch.device("cuda:0")
+
+
+def to_dev(inputs):
+    return {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in inputs.items()}
+
+
+def make_model(w, Va, Vb, D, K=8):
+    m = MM.build_model(Va, Vb, atom_dim=D, bond_dim=K, num_steps=weights.num_steps_of(w), device=DEV)
+    m.load_weights(w)
+    return m
+
+
+def oracle_pooled(w, inp):
+    return (O.encode(w, "cat", inp["cat_atom"], inp["cat_bond"], inp["cat_connectivity"], pooled_only=True),
+            O.encode(w, "an", inp["an_atom"], inp["an_bond"], inp["an_connectivity"], pooled_only=True))
+
+
+@pytest.mark.parametrize("D,N,E,K,S,B,seed", [(128, 40, 80, 8, 3, 37, 1), (128, 40, 80, 8, 6, 130, 2),
+                                              (64, 40, 80, 8, 3, 65, 3), (64, 12, 20, 4, 2, 100, 4),
+                                              (128, 7, 30, 1, 1, 50, 5), (128, 40, 80, 5, 0, 30, 6),
+                                              (64, 1, 0, 8, 2, 9, 7), (128, 100, 240, 8, 1, 16, 8),
+                                              (64, 128, 512, 3, 1, 5, 9), (128, 256, 40, 2, 2, 3, 10)])
+def test_wide_encoder_random_shapes(D, N, E, K, S, B, seed):
+    Va, Vb = 30, 11
+    inp = synthetic.make_batch(B, max_atoms=N, max_edges=E, atom_vocab_size=Va, bond_vocab_size=Vb,
+                               min_atoms=min(3, N), seed=seed)
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=D, bond_dim=K, num_steps=S, seed=seed + 100, perturb=True)
+    m = make_model(w, Va, Vb, D, K)
+    assert m.resolve_encoder_mode(N, E) == "f32t"
+    pc, pa = m.encode_pooled(to_dev(inp), fused=True)
+    rc, ra = oracle_pooled(w, inp)
+    assert_close(pc.cpu().numpy(), rc, what="cat pooled")
+    assert_close(pa.cpu().numpy(), ra, what="an pooled")
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_wide_encoder_adversarial_graphs(D):
+    """Edges that name padding atoms, self loops, 4x duplicated bonds (trainer expansion), id-0 holes, all-padding
+    molecules, one atom with 64 in-edges, bond ids outside the vocabulary - the general contract."""
+    rng = np.random.default_rng(42)
+    B, N, E, Va, Vb, K, S = 48, 24, 64, 20, 7, 8, 3
+    ids = rng.integers(0, Va, size=(B, N)).astype(np.int32)
+    ids[0] = 0
+    conn = rng.integers(0, N, size=(B, E, 2)).astype(np.int32)
+    conn[1] = 5
+    conn[2, :, 1] = 3
+    conn[:, 48:] = 0
+    bond = rng.integers(0, Vb, size=(B, E)).astype(np.int32)
+    e4, b4 = O.preprocess_edges_and_bonds([[(0, 1), (1, 0), (1, 2), (2, 1), (2, 3), (3, 2)]] * 4,
+                                          [[1, 1, 2, 2, 3, 3]] * 4, E // 2)
+    conn[3:7], bond[3:7] = e4, b4
+    inp = {"cat_atom": ids, "cat_bond": bond, "cat_connectivity": conn,
+           "an_atom": ids[::-1].copy(), "an_bond": bond[::-1].copy(), "an_connectivity": conn[::-1].copy()}
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=D, bond_dim=K, num_steps=S, seed=9, perturb=True)
+    m = make_model(w, Va, Vb, D, K)
+    pc, pa = m.encode_pooled(to_dev(inp), fused=True)
+    rc, ra = oracle_pooled(w, inp)
+    assert_close(pc.cpu().numpy(), rc, what="cat pooled")
+    assert_close(pa.cpu().numpy(), ra, what="an pooled")
+    assert float(pc[0].abs().max()) == 0.0
+
+
+@pytest.fixture(scope="module")
+def wide_full():
+    """BASELINE.json configs[4]'s forward shape at a size the module can afford several times: D=128, S=6."""
+    Va, Vb, B = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, 1024
+    inp = synthetic.make_batch(B, seed=41)
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=128, bond_dim=8, num_steps=6, seed=42, perturb=True)
+    m = make_model(w, Va, Vb, 128)
+    d = to_dev(inp)
+    pc, pa = m.encode_pooled(d, fused=True)
+    torch.cuda.synchronize()
+    return inp, w, m, d, pc.clone(), pa.clone()
+
+
+def test_wide_sampled_molecules_vs_oracle(wide_full):
+    inp, w, m, d, pc, pa = wide_full
+    idx = np.random.default_rng(3).choice(1024, size=20, replace=False)
+    sub = {k: v[idx] for k, v in inp.items()}
+    rc, ra = oracle_pooled(w, sub)
+    assert_close(pc.cpu().numpy()[idx], rc, what="cat pooled (sample)")
+    assert_close(pa.cpu().numpy()[idx], ra, what="an pooled (sample)")
+    y = m(d).cpu().numpy()[idx]
+    assert_close(y, O.viscosity_forward(w, sub), what="log_eta (sample)")
+
+
+def test_wide_run_to_run_and_shard_concat_bitwise(wide_full):
+    inp, w, m, d, pc, pa = wide_full
+    c2, a2 = m.encode_pooled(d, fused=True)
+    assert torch.equal(c2, pc) and torch.equal(a2, pa)
+    h = 1024 // 2 - 7
+    c0, a0 = m.encode_pooled({k: v[:h].contiguous() for k, v in d.items()}, fused=True)
+    c1, a1 = m.encode_pooled({k: v[h:].contiguous() for k, v in d.items()}, fused=True)
+    assert torch.equal(torch.cat([c0, c1]), pc) and torch.equal(torch.cat([a0, a1]), pa)
+
+
+def test_wide_permutation_and_padding_invariance(wide_full):
+    inp, w, m, d, pc, pa = wide_full
+    perm = torch.from_numpy(np.random.default_rng(5).permutation(1024)).to(DEV)
+    cp, ap = m.encode_pooled({k: v[perm].contiguous() for k, v in d.items()}, fused=True)
+    assert torch.equal(cp, pc[perm]) and torch.equal(ap, pa[perm])
+    # more padding (N 40 -> 56, E 80 -> 100) changes nothing, bit for bit
+    wide = {}
+    for k, v in d.items():
+        if k.endswith("_atom"):
+            wide[k] = torch.nn.functional.pad(v, (0, 16))
+        elif k.endswith("_bond"):
+            wide[k] = torch.nn.functional.pad(v, (0, 20))
+        elif k.endswith("_connectivity"):
+            wide[k] = torch.nn.functional.pad(v, (0, 0, 0, 20))
+        else:
+            wide[k] = v
+    cw, aw = m.encode_pooled(wide, fused=True)
+    assert torch.equal(cw, pc) and torch.equal(aw, pa)
+
+
+def test_wide_equals_layered_hip(wide_full):
+    inp, w, m, d, pc, pa = wide_full
+    sub = {k: v[:256].contiguous() for k, v in d.items()}
+    lc, la = m.encode_pooled(sub, fused=False)
+    assert_close(lc.cpu().numpy(), pc[:256].cpu().numpy(), what="layered vs wide cat")
+    assert_close(la.cpu().numpy(), pa[:256].cpu().numpy(), what="layered vs wide an")
+
+
+@pytest.mark.parametrize("D", [64, 128])
+def test_wide_prepared_per_call_and_single_ion_agree_bitwise(D):
+    Va, Vb, K, S, B = 30, 11, 8, 3, 70
+    inp = synthetic.make_batch(B, atom_vocab_size=Va, bond_vocab_size=Vb, seed=12)
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=D, bond_dim=K, num_steps=S, seed=13, perturb=True)
+    m = make_model(w, Va, Vb, D, K)
+    d = to_dev(inp)
+    ions = [(d["cat_atom"], d["cat_bond"], d["cat_connectivity"]), (d["an_atom"], d["an_bond"], d["an_connectivity"])]
+    at, bt = m.atom_emb.embeddings, m.bond_emb.embeddings
+    prep = m._prepared_weights("f32t")
+    p2 = ops.encoder_fused(ions, at, bt, None, S, mode="f32t", prepared=prep)
+    q2 = ops.encoder_fused(ions, at, bt, m._packed_weights(), S, mode="f32t")
+    assert torch.equal(p2[0], q2[0]) and torch.equal(p2[1], q2[1])
+    # one ion branch per call: the same rows, bit for bit
+    for g in (0, 1):
+        one = ops.encoder_fused([ions[g]], at, bt, None, S, mode="f32t", prepared=[prep[g]])
+        assert torch.equal(one[0], p2[g])
+
+
+def test_wide_atom_ids_outside_the_vocabulary_give_zero_rows():
+    Va, Vb, D, K, S, B = 30, 11, 128, 8, 2, 20
+    inp = synthetic.make_batch(B, atom_vocab_size=Va, bond_vocab_size=Vb, seed=21)
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=D, bond_dim=K, num_steps=S, seed=22, perturb=True)
+    m = make_model(w, Va, Vb, D, K)
+    bad = {k: v.copy() for k, v in inp.items()}
+    bad["cat_atom"][3, 1] = Va + 5          # TF-GPU gather semantics: a zero row (ops.DEBUG_VALIDATE raises instead)
+    pc, _ = m.encode_pooled(to_dev(bad), fused=True)
+    wz = {k: v.copy() for k, v in w.items()}
+    ext = np.zeros((Va + 6, D), np.float32)
+    ext[:Va] = w["atom_embedding"]
+    wz["atom_embedding"] = ext
+    rc = O.encode(wz, "cat", bad["cat_atom"], bad["cat_bond"], bad["cat_connectivity"], pooled_only=True)
+    assert_close(pc.cpu().numpy(), rc, what="cat pooled with an out-of-vocabulary id")
+
+
+def test_wide_pipelined_plan_run_matches_single_call(wide_full):
+    inp, w, m, d, pc, pa = wide_full
+    plan = m.plan_batch(d)
+    c, a = m.encode_pooled(d, plan=plan)
+    assert torch.equal(c, pc) and torch.equal(a, pa)

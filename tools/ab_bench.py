@@ -54,7 +54,7 @@ prep = {}
 def call(lib):
     if hasattr(lib, "impnn_encoder_fused_prepared"):
         if id(lib) not in prep:
-            nb = int(lib.impnn_encoder_prepared_bytes(S, btab.shape[0], ops.ENCODER_MODES[args.mode]))
+            nb = int(lib.impnn_encoder_prepared_bytes(32, S, btab.shape[0], ops.ENCODER_MODES[args.mode]))
             bufs = [torch.empty(nb, dtype=torch.uint8, device=dev) for _ in range(2)]
             for bf, pk in zip(bufs, packed):
                 assert lib.impnn_encoder_prepare_weights(pk.data_ptr(), btab.data_ptr(), 32, 8, S, btab.shape[0],
