@@ -10,7 +10,7 @@
 //   plan (graph only, once per batch)
 //     wide_count      one wave per molecule: kept rows r_b (rows that can send, receive or be pooled - the same rule as
 //                     the D = 32 encoders, encoder_plan.hip) and the histogram of valid edges by (ion, bond type)
-//     wide_scan       one workgroup: compact row base of every molecule (an ion starts at a multiple of 128 rows),
+//     wide_scan       one workgroup: compact row base of every molecule (an ion starts at a multiple of 64 rows),
 //                     per-type runs of the type-sorted edge list and their tiles
 //     wide_place      valid edges into their type's run (source row per sorted position) and, per kept row, the
 //                     positions of its in-edges IN EDGE-SLOT ORDER (the reference's sequential scatter_nd order,
@@ -20,8 +20,8 @@
 //     S x  wide_message   m[p] = A[type_p] h[src_p]: one GEMM per type run, 64-edge tiles, the type's matrix resident
 //                         in LDS, next tile's rows in flight under the MFMAs      (a2 + a4, models/layers.py:100-117)
 //          wide_reduce    agg[row] = sum of its in-edge messages, slot order      (a5)
-//          wide_update    GatedUpdate on 128-row tiles, [h|agg] and the gate kernels streamed through LDS in
-//                         16/32-deep k slices, h updated in place                 (a7, models/layers.py:142-156)
+//          wide_update    GatedUpdate on 64-row tiles (two workgroups per CU), [h|agg] and the gate kernels
+//                         streamed through LDS in 16-deep k slices, h updated in place (a7, models/layers.py:142-156)
 //     wide_pool       pooled[b] = sum_n h[b,n] [atom_ids[b,n] > 0], ascending n   (a8)
 //
 // Every product is an exact f32 product on v_mfma_f32_16x16x4_f32; every sum has a fixed order that does not depend
@@ -31,7 +31,7 @@
 namespace impnn {
 namespace wide {
 
-constexpr int kRT = 128;       // rows of a GatedUpdate tile; an ion's rows start at a multiple of it
+constexpr int kRT = 64;        // rows of a GatedUpdate tile; an ion's rows start at a multiple of it
 constexpr int kMaxN = 256;     // atoms per molecule (LDS tables of wide_place)
 constexpr int kMaxE = 512;     // edge slots per molecule
 constexpr int kMaxVb = 512;    // bond vocabulary (types of both ions: one per thread of wide_scan)
@@ -62,6 +62,22 @@ __device__ __forceinline__ float row16_sum_f(float v) {
 
 constexpr size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// In-kernel stamps (diagnostics builds only; tools/wide_stamps.py): thread 0 of a workgroup writes s_memtime into
+// word `slot` of its 8-word record.  In the product build the macro is empty and no stamp executes.
+#ifdef IMPNN_DIAG_WIDE_STAMPS
+#define WIDE_STAMP(buf, slot)                                                                     \
+  do {                                                                                            \
+    if ((buf) && threadIdx.x == 0) (buf)[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define WIDE_STAMP_REAL(buf, slot)                                                                    \
+  do {                                                                                                \
+    if ((buf) && threadIdx.x == 0) (buf)[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define WIDE_STAMP(buf, slot) do { } while (0)
+#define WIDE_STAMP_REAL(buf, slot) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------------------
 // workspace
 // ------------------------------------------------------------------------------------------------------------
@@ -83,7 +99,7 @@ inline Ws ws_layout(int n_ions, int B, int N, int E, int D, int S, int Vb) {
   const int64_t mols = (int64_t)n_ions * B;
   w.nT = n_ions * Vb;
   w.rmax = mols * N + (int64_t)n_ions * kRT;
-  w.vmax = mols * E + 2 * tile_edges(D);
+  w.vmax = mols * E + (int64_t)(w.nT + 2) * tile_edges(D);  // a type's run is padded to whole tiles
   size_t o = 0;
   auto take = [&](size_t bytes) {
     const size_t at = o;
@@ -174,7 +190,8 @@ __global__ __launch_bounds__(256) void wide_count_kernel(Inputs in, int32_t* __r
 __global__ __launch_bounds__(1024) void wide_scan_kernel(const int32_t* __restrict__ kept, int32_t* __restrict__ rowbase,
                                                          const int32_t* __restrict__ cnt, int32_t* __restrict__ tstart,
                                                          int32_t* __restrict__ cursor, int32_t* __restrict__ tilebase,
-                                                         int32_t* __restrict__ meta, int n_ions, int B, int nT, int te) {
+                                                         int32_t* __restrict__ srcrow, int32_t* __restrict__ meta,
+                                                         int n_ions, int B, int nT, int te) {
   __shared__ int32_t wsum[16], wsum2[16];
   __shared__ int32_t carry;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -234,13 +251,15 @@ __global__ __launch_bounds__(1024) void wide_scan_kernel(const int32_t* __restri
     }
     ic += oc;
     it += ot;
-    if (tid < nT) {
-      tstart[tid] = ic - c;
-      cursor[tid] = ic - c;
+    if (tid < nT) {  // a type's run starts at a whole tile: position = te x tile
+      tstart[tid] = (it - tl) * te;
+      cursor[tid] = (it - tl) * te;
       tilebase[tid] = it - tl;
+      // the padding positions behind the run read row 0 in wide_message (any row inside the workspace would do)
+      for (int pz = (it - tl) * te + c; pz < it * te; ++pz) srcrow[pz] = 0;
     }
     if (tid == 1023) {  // threads past nT carry zeros: the last inclusive values are the totals
-      tstart[nT] = ic;
+      tstart[nT] = it * te;
       tilebase[nT] = it;
       meta[kMetaValid] = ic;
       meta[kMetaTiles] = it;
@@ -370,10 +389,10 @@ struct MsgParams {
   const float* img[2];      // prepared images; the type matrices of this step start at img[g] + mat_off
   size_t mat_off;
   const int32_t* srcrow;
-  const int32_t* tstart;
   const int32_t* tilebase;
   const int32_t* meta;
   int nT, Vb;
+  unsigned long long* stamps;  // diagnostics builds only (IMPNN_DIAG_WIDE_STAMPS)
 };
 
 template <int NT, int TE>
@@ -385,34 +404,35 @@ __global__ __launch_bounds__(1024) void wide_message_kernel(MsgParams p) {
   extern __shared__ __align__(16) float smem[];
   float* Bm = smem;               // D x LD
   float* Xb = Bm + D * LD;        // 2 x TE x LD
+  int32_t* tb_s = reinterpret_cast<int32_t*>(Xb + 2 * TE * LD);  // tilebase[0 .. nT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = lane & 15, q = lane >> 4;
   const int et = wave % EG, fg = wave / EG;
   const int ntiles = p.meta[kMetaTiles];
   const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
   const int t0 = blockIdx.x * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
   if (t0 >= t1) return;
-  // type of the first tile: largest t with tilebase[t] <= t0 (empty types share a base with their successor: skip on)
-  int ty;
-  {
-    int lo = 0, hi = p.nT - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (p.tilebase[mid] <= t0) lo = mid; else hi = mid - 1;
-    }
-    ty = lo;
-  }
+  WIDE_STAMP(p.stamps, 0);
+  WIDE_STAMP_REAL(p.stamps, 5);
+  for (int t = tid; t <= p.nT; t += 1024) tb_s[t] = p.tilebase[t];
+  __syncthreads();
   auto mat_of = [&](int t) {
     const int g = t >= p.Vb ? 1 : 0;
     return p.img[g] + p.mat_off + (size_t)(t - g * p.Vb) * D * D;
   };
+  // A type's run starts at a multiple of TE sorted positions (wide_scan), so tile t is positions [t TE, (t + 1) TE):
+  // positions past the type's last edge are padding - their source row is row 0 (wide_scan), their messages are
+  // computed and stored like any other and never read.  No load or store of the loop is conditional, which lets the
+  // compiler count outstanding memory operations instead of draining them: source rows are requested TWO tiles ahead
+  // (sr2), the rows themselves one tile ahead (xr), the stores of a tile drain under the next tile's MFMAs.
+  int sr1[kX], sr2[kX];
   f32x4_t xr[kX], br[kB];
-  auto fetch_x = [&](int p0, int n) {
+  auto fetch_sr = [&](int tile, int* sr) {
 #pragma unroll
-    for (int i = 0; i < kX; ++i) {
-      const int idx = tid + 1024 * i, e = idx / QD, c4 = idx - e * QD;
-      xr[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      if (e < n) xr[i] = ldv4(p.h + (int64_t)p.srcrow[p0 + e] * D + 4 * c4);
-    }
+    for (int i = 0; i < kX; ++i) sr[i] = p.srcrow[tile * TE + (tid + 1024 * i) / QD];
+  };
+  auto fetch_x = [&](const int* sr) {
+#pragma unroll
+    for (int i = 0; i < kX; ++i) xr[i] = ldv4(p.h + (int64_t)sr[i] * D + 4 * ((tid + 1024 * i) % QD));
   };
   auto park_x = [&](float* X) {
 #pragma unroll
@@ -433,26 +453,39 @@ __global__ __launch_bounds__(1024) void wide_message_kernel(MsgParams p) {
       stv4(Bm + r * LD + 4 * c4, br[i]);
     }
   };
-  int tile = t0;
-  while (p.tilebase[ty + 1] <= tile) ++ty;
-  int p0 = p.tstart[ty] + (tile - p.tilebase[ty]) * TE;
-  int n = min(TE, p.tstart[ty + 1] - p0);
-  fetch_x(p0, n);
+  int ty;
+  {  // type of the first tile: largest t with tilebase[t] <= t0 (empty types share a base with their successor)
+    int lo = 0, hi = p.nT - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (tb_s[mid] <= t0) lo = mid; else hi = mid - 1;
+    }
+    ty = lo;
+  }
+  int run_end = tb_s[ty + 1];  // first tile of the next type
+  fetch_sr(t0, sr1);
   fetch_b(ty);
+  fetch_x(sr1);
+  fetch_sr(min(t0 + 1, t1 - 1), sr1);
   park_x(Xb);
   park_b();
   __syncthreads();
+  WIDE_STAMP(p.stamps, 1);
   int cur = 0;
-  for (;;) {
-    const bool more = tile + 1 < t1;
-    int ty2 = ty, p02 = 0, n2 = 0;
-    if (more) {
-      while (p.tilebase[ty2 + 1] <= tile + 1) ++ty2;
-      p02 = p.tstart[ty2] + (tile + 1 - p.tilebase[ty2]) * TE;
-      n2 = min(TE, p.tstart[ty2 + 1] - p02);
-      fetch_x(p02, n2);
-      if (ty2 != ty) fetch_b(ty2);
+  for (int tile = t0; tile < t1; ++tile) {
+    // the next tile (the last tile is simply requested again: no branch around the requests)
+    const int nxt = min(tile + 1, t1 - 1);
+    int ty2 = ty, run_end2 = run_end;
+    if (nxt >= run_end) {  // (workgroup-uniform) a new type: step over empty ones
+      do {
+        ++ty2;
+        run_end2 = tb_s[ty2 + 1];
+      } while (run_end2 <= nxt);
+      fetch_b(ty2);
     }
+    fetch_x(sr1);
+    fetch_sr(min(tile + 2, t1 - 1), sr2);
+    __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler sinks the requests below the MFMAs, next to their use)
     {
       const float* X = Xb + cur * TE * LD;
       f32x4_t acc[NLW];
@@ -460,37 +493,50 @@ __global__ __launch_bounds__(1024) void wide_message_kernel(MsgParams p) {
       for (int TL = 0; TL < NLW; ++TL) acc[TL] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       const float* xrow = X + (16 * et + a) * LD + 4 * q;
       const float* arow = Bm + (16 * (fg * NLW) + a) * LD + 4 * q;
-#pragma unroll 2
+#pragma unroll
       for (int u = 0; u < NT; ++u) {
+#ifdef IMPNN_DIAG_WIDE_NOLDS
+        const f32x4_t xv = {1.f + u, 2.f, 3.f, 4.f};
+        f32x4_t av[NLW];
+#pragma unroll
+        for (int TL = 0; TL < NLW; ++TL) av[TL] = f32x4_t{0.5f, 0.25f + TL, 0.125f, 2.f};
+#else
         const f32x4_t xv = ldv4(xrow + 16 * u);
         f32x4_t av[NLW];
 #pragma unroll
         for (int TL = 0; TL < NLW; ++TL) av[TL] = ldv4(arow + 16 * TL * LD + 16 * u);
+#endif
+#ifdef IMPNN_DIAG_WIDE_NOMMA
+        acc[0] += xv + av[0] + av[NLW - 1];
+#else
 #pragma unroll
         for (int TL = 0; TL < NLW; ++TL)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[TL] = mfma_f32(av[TL][r], xv[r], acc[TL]);
+#endif
       }
-      const int e = 16 * et + a;
-      if (e < n) {
-        float* dst = p.m + (int64_t)(p0 + e) * D + 16 * (fg * NLW) + 4 * q;
+      float* dst = p.m + ((int64_t)tile * TE + 16 * et + a) * D + 16 * (fg * NLW) + 4 * q;
 #pragma unroll
-        for (int TL = 0; TL < NLW; ++TL) stv4(dst + 16 * TL, acc[TL]);
-      }
+      for (int TL = 0; TL < NLW; ++TL) stv4(dst + 16 * TL, acc[TL]);
     }
-    if (!more) break;
+    __builtin_amdgcn_sched_barrier(0);
     park_x(Xb + (cur ^ 1) * TE * LD);
-    if (ty2 != ty) {      // (workgroup-uniform)
-      __syncthreads();    // every wave is done with the old matrix
+    if (ty2 != ty) {     // (workgroup-uniform)
+      __syncthreads();   // every wave is done with the old matrix
       park_b();
     }
     __syncthreads();
     cur ^= 1;
-    ++tile;
     ty = ty2;
-    p0 = p02;
-    n = n2;
+    run_end = run_end2;
+#pragma unroll
+    for (int i = 0; i < kX; ++i) sr1[i] = sr2[i];
   }
+  WIDE_STAMP(p.stamps, 4);
+  WIDE_STAMP_REAL(p.stamps, 6);
+#ifdef IMPNN_DIAG_WIDE_STAMPS
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)(t1 - t0);
+#endif
 }
 
 // a5 on the compact rows: D/4 lanes per row, the in-edge messages added in edge-slot order with 4 rows in flight.
@@ -519,12 +565,14 @@ __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restric
   stv4(agg + row * D + 4 * c4, acc);
 }
 
-// a7 on 128-row tiles of the compact row space, h updated in place.
-//   phase 1   [z|r] pre-activations = [h|agg] (128 x 2D) x [Wz|Wr] (2D x 2D): 2 NT slices of 16 k; a slice of the rows
-//             (8 KB, MFMA operand order [k quad][row][4]) and of the kernels (16 KB at D = 128, the image's own order)
+// a7 on kRT-row tiles of the compact row space, h updated in place.  8 waves per tile, TWO workgroups resident per CU
+// (77 KB of LDS and 128 VGPRs each): exact-f32 MFMA and the vector ALU share one issue port, so a tile's barrier
+// bubbles, its prologue and its LayerNorm epilogue are only ever hidden by ANOTHER tile's MFMAs.
+//   phase 1   [z|r] pre-activations = [h|agg] (R x 2D) x [Wz|Wr] (2D x 2D): 2 NT slices of 16 k; a slice of the rows
+//             (4 KB, MFMA operand order [k quad][row][4]) and of the kernels (16 KB at D = 128, the image's own order)
 //             goes global -> registers (two slices ahead) -> one of two LDS stages; one barrier per slice, 32 MFMAs
-//             per wave between barriers (wave = 32 rows x 2 NL feature tiles).
-//   phase 2   candidate = [r*h|agg] x Wh: NT steps of 32 k; r*h comes from LDS (written once after phase 1), agg and
+//             per wave between barriers (wave = 32 rows x NL feature tiles of z and of r).
+//   phase 2   candidate = [r*h|agg] x Wh, 2 NT slices again: r*h comes from LDS (written once after phase 1), agg and
 //             Wh through the stages.
 //   epilogue  blend, LayerNorm (row sums across the four feature groups through LDS), residual.
 // h of the accumulator positions is read once into registers (for r*h, the blend and the residual).
@@ -536,47 +584,67 @@ struct GuParams {
   const int32_t* meta;
   float eps;
   int n_ions;
+  unsigned long long* stamps;  // diagnostics builds only (IMPNN_DIAG_WIDE_STAMPS)
 };
 
+constexpr int kGuThreads = 512;
+constexpr size_t gu_lds_floats(int D) {
+  // two stages of (row slice + [Wz|Wr] slice) | r*h | LayerNorm partials
+  return 2 * (size_t)(4 * kRT * 4 + 4 * 2 * D * 4) + (size_t)kRT * (D + 4) + 8 * kRT;
+}
+
 template <int NT>
-__global__ __launch_bounds__(1024) void wide_update_kernel(GuParams p) {
-  constexpr int D = 16 * NT, R = kRT, NL = NT / 4, LDR = D + 4;
+__global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) {
+  constexpr int D = 16 * NT, R = kRT, LDR = D + 4;
+  constexpr int RG = R / 32, FG = (kGuThreads / 64) / RG, NL = NT / FG;
   constexpr int A1 = 4 * R * 4;       // floats of a 16-k slice of the rows
   constexpr int B1 = 4 * 2 * D * 4;   // ... of [Wz|Wr]
   constexpr int B2 = 4 * D * 4;       // ... of Wh
-  constexpr int ST = (A1 + B1) > (2 * A1 + 2 * B2) ? (A1 + B1) : (2 * A1 + 2 * B2);  // stage floats
-  static_assert(B1 / 4 <= 1024 && 2 * B2 / 4 <= 1024, "one 16-byte piece per thread");
+  constexpr int ST = A1 + B1;         // stage floats
+  constexpr int kQ1 = (B1 / 4 + kGuThreads - 1) / kGuThreads, kQ2 = (B2 / 4 + kGuThreads - 1) / kGuThreads;
+  constexpr int kAT = R * 4;          // threads that move a piece of a row slice
+  static_assert(NL >= 1 && NT % FG == 0 && kAT <= kGuThreads, "tile shape");
   extern __shared__ __align__(16) float smem[];
   float* stage = smem;                 // 2 x ST
   float* rhs = stage + 2 * ST;         // R x LDR : r * h
-  float* part = rhs + R * LDR;         // 2 x 4 x R LayerNorm partials
+  float* part = rhs + R * LDR;         // 2 x FG x R LayerNorm partials
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, a = lane & 15, q = lane >> 4;
-  const int rg = wv & 3, fg = wv >> 2;  // row group (32 rows), feature group (NL tiles of z, r and the candidate)
+  const int rg = wv % RG, fg = wv / RG;  // row group (32 rows), feature group (NL tiles of z, r and the candidate)
   const int64_t row0 = (int64_t)blockIdx.x * R;
   const int end = p.meta[kMetaEnd];
   if (row0 >= end) return;
   const int g = (p.n_ions > 1 && row0 >= p.meta[kMetaBase + 1]) ? 1 : 0;
   const int64_t row_end = p.meta[kMetaBase + g] + p.meta[kMetaRows + g];  // rows of this tile beyond it are padding
   if (row0 >= row_end) return;
+  WIDE_STAMP(p.stamps, 0);
+  WIDE_STAMP_REAL(p.stamps, 5);
   const float* img = p.img[g] + p.gu_off;
   const float* P1 = img;
   const float* P2 = img + 4 * D * D;
   const float* bias = img + 6 * D * D;  // bz br bh gamma beta
   // (padding rows of the last tile of an ion lie inside the workspace; whatever they hold stays in their own rows)
-  const int a_row = (tid & 511) >> 2, a_c4 = tid & 3, a_sub = tid >> 9;
+  const int a_row = (tid % kAT) >> 2, a_c4 = tid & 3;
   const float* hsrc = p.h + (row0 + a_row) * D + 4 * a_c4;
   const float* gsrc = p.agg + (row0 + a_row) * D + 4 * a_c4;
   struct Pre {
-    f32x4_t av, bv;
+    f32x4_t av, bv[kQ1];
   };
   Pre preA, preB;
   auto fetch1 = [&](int u, Pre& pre) {
-    if (tid < B1 / 4) pre.bv = ldv4(P1 + (size_t)u * B1 + tid * 4);
-    if (tid < 512) pre.av = ldv4((u < NT ? hsrc : gsrc - D) + 16 * u);
+#pragma unroll
+    for (int i = 0; i < kQ1; ++i)
+      if (tid + kGuThreads * i < B1 / 4) pre.bv[i] = ldv4(P1 + (size_t)u * B1 + (tid + kGuThreads * i) * 4);
+#ifdef IMPNN_DIAG_WIDE_NOFETCH
+    if (tid < kAT) pre.av = f32x4_t{0.25f, 0.5f, -0.25f, 0.125f};
+#else
+    if (tid < kAT) pre.av = ldv4((u < NT ? hsrc : gsrc - D) + 16 * u);
+#endif
   };
   auto park1 = [&](float* st, const Pre& pre) {
-    if (tid < B1 / 4) stv4(st + A1 + tid * 4, pre.bv);
-    if (tid < 512) stv4(st + (a_c4 * R + a_row) * 4, pre.av);
+#pragma unroll
+    for (int i = 0; i < kQ1; ++i)
+      if (tid + kGuThreads * i < B1 / 4) stv4(st + A1 + (tid + kGuThreads * i) * 4, pre.bv[i]);
+    if (tid < kAT) stv4(st + (a_c4 * R + a_row) * 4, pre.av);
   };
   f32x4_t z[2][NL], rr[2][NL];
 #pragma unroll
@@ -616,6 +684,7 @@ __global__ __launch_bounds__(1024) void wide_update_kernel(GuParams p) {
   fetch1(1, preB);
   park1(stage, preA);
   __syncthreads();
+  WIDE_STAMP(p.stamps, 1);
   // h at this lane's accumulator positions (rows 4q + g of both row tiles, feature a of its NL tiles): requested under
   // the last two slices of phase 1 - held from the start they cost 16 registers the phase does not have
   float hreg[2][NL][4];
@@ -650,18 +719,31 @@ __global__ __launch_bounds__(1024) void wide_update_kernel(GuParams p) {
   for (int u = 0; u < 2 * NT - 2; u += 2) pair1(u);
   load_hreg();
   pair1(2 * NT - 2);
+  WIDE_STAMP(p.stamps, 2);
   // ---- phase 2
-  auto fetch2 = [&](int v, Pre& pre) {
-    if (tid < 2 * B2 / 4) pre.bv = ldv4(P2 + (size_t)v * 2 * B2 + tid * 4);
-    if (2 * v >= NT) pre.av = ldv4(gsrc + (32 * v - D) + 16 * a_sub);
+  struct Pre2 {
+    f32x4_t av, bv[kQ2];
   };
-  auto park2 = [&](int v, float* st, const Pre& pre) {
-    if (tid < 2 * B2 / 4) stv4(st + 2 * A1 + tid * 4, pre.bv);
-    if (2 * v >= NT) stv4(st + a_sub * A1 + (a_c4 * R + a_row) * 4, pre.av);
+  Pre2 qA, qB;
+  auto fetch2 = [&](int u, Pre2& pre) {
+#pragma unroll
+    for (int i = 0; i < kQ2; ++i)
+      if (tid + kGuThreads * i < B2 / 4) pre.bv[i] = ldv4(P2 + (size_t)u * B2 + (tid + kGuThreads * i) * 4);
+#ifdef IMPNN_DIAG_WIDE_NOFETCH
+    if (u >= NT && tid < kAT) pre.av = f32x4_t{0.25f, 0.5f, -0.25f, 0.125f};
+#else
+    if (u >= NT && tid < kAT) pre.av = ldv4(gsrc + 16 * (u - NT));
+#endif
   };
-  fetch2(0, preA);
-  if (NT > 1) fetch2(1, preB);
-  // gates; r * h into LDS (phase 2 reads the rows of this wave's row group written by all four feature groups)
+  auto park2 = [&](int u, float* st, const Pre2& pre) {
+#pragma unroll
+    for (int i = 0; i < kQ2; ++i)
+      if (tid + kGuThreads * i < B2 / 4) stv4(st + A1 + (tid + kGuThreads * i) * 4, pre.bv[i]);
+    if (u >= NT && tid < kAT) stv4(st + (a_c4 * R + a_row) * 4, pre.av);
+  };
+  fetch2(0, qA);
+  fetch2(1, qB);
+  // gates; r * h into LDS (phase 2 reads the rows of this wave's row group written by all feature groups)
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -678,18 +760,18 @@ __global__ __launch_bounds__(1024) void wide_update_kernel(GuParams p) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) tt[rt][TL] = f32x4_t{b2, b2, b2, b2};
   }
-  park2(0, stage, preA);
+  park2(0, stage, qA);
   __syncthreads();
   struct Ops2 {
     f32x4_t av[2], bv[NL];
   };
-  auto read2 = [&](int v, int sub, const float* st, Ops2& o) {
+  auto read2 = [&](int u, const float* st, Ops2& o) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
-      o.av[rt] = 2 * v < NT ? ldv4(rhs + (32 * rg + 16 * rt + a) * LDR + 16 * (2 * v + sub) + 4 * q)
-                            : ldv4(st + sub * A1 + (q * R + 32 * rg + 16 * rt + a) * 4);
+      o.av[rt] = u < NT ? ldv4(rhs + (32 * rg + 16 * rt + a) * LDR + 16 * u + 4 * q)
+                        : ldv4(st + (q * R + 32 * rg + 16 * rt + a) * 4);
 #pragma unroll
-    for (int TL = 0; TL < NL; ++TL) o.bv[TL] = ldv4(st + 2 * A1 + sub * B2 + (q * D + 16 * (fg * NL + TL) + a) * 4);
+    for (int TL = 0; TL < NL; ++TL) o.bv[TL] = ldv4(st + A1 + (q * D + 16 * (fg * NL + TL) + a) * 4);
   };
   auto mma2 = [&](const Ops2& o) {
 #pragma unroll
@@ -699,43 +781,39 @@ __global__ __launch_bounds__(1024) void wide_update_kernel(GuParams p) {
 #pragma unroll
         for (int TL = 0; TL < NL; ++TL) tt[rt][TL] = mfma_f32(o.av[rt][r], o.bv[TL][r], tt[rt][TL]);
   };
-  for (int v = 0; v < NT; v += 2) {
-    Ops2 o0, o1;
-    if (v + 2 < NT) fetch2(v + 2, preA);
-    read2(v, 0, stage, o0);
+  for (int u = 0; u < 2 * NT; u += 2) {
+    Ops2 o;
+    if (u + 2 < 2 * NT) fetch2(u + 2, qA);
+    read2(u, stage, o);
     __builtin_amdgcn_sched_barrier(0);
-    if (v + 1 < NT) park2(v + 1, stage + ST, preB);
-    read2(v, 1, stage, o1);
+    park2(u + 1, stage + ST, qB);
     __builtin_amdgcn_sched_barrier(0);
-    mma2(o0);
-    mma2(o1);
+    mma2(o);
     __syncthreads();
-    if (v + 1 >= NT) break;
-    if (v + 3 < NT) fetch2(v + 3, preB);
-    read2(v + 1, 0, stage + ST, o0);
+    if (u + 3 < 2 * NT) fetch2(u + 3, qB);
+    read2(u + 1, stage + ST, o);
     __builtin_amdgcn_sched_barrier(0);
-    if (v + 2 < NT) park2(v + 2, stage, preA);
-    read2(v + 1, 1, stage + ST, o1);
+    if (u + 2 < 2 * NT) park2(u + 2, stage, qA);
     __builtin_amdgcn_sched_barrier(0);
-    mma2(o0);
-    mma2(o1);
+    mma2(o);
     __syncthreads();
   }
+  WIDE_STAMP(p.stamps, 3);
   // ---- blend, LayerNorm over the D features of a row, residual (models/layers.py:150-156)
   float sum[2][4];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-      float s = 0.f;
+      float sacc = 0.f;
 #pragma unroll
       for (int TL = 0; TL < NL; ++TL) {
         const float hv = hreg[rt][TL][gq];
         const float nv = (1.0f - z[rt][TL][gq]) * hv + z[rt][TL][gq] * ftanh(tt[rt][TL][gq]);
         tt[rt][TL][gq] = nv;
-        s += nv;
+        sacc += nv;
       }
-      sum[rt][gq] = row16_sum_f(s);
+      sum[rt][gq] = row16_sum_f(sacc);
       if (a == 0) part[fg * R + 32 * rg + 16 * rt + 4 * q + gq] = sum[rt][gq];
     }
   __syncthreads();
@@ -745,23 +823,29 @@ __global__ __launch_bounds__(1024) void wide_update_kernel(GuParams p) {
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const int rl = 32 * rg + 16 * rt + 4 * q + gq;
-      mean[rt][gq] = ((part[rl] + part[R + rl]) + (part[2 * R + rl] + part[3 * R + rl])) * (1.0f / D);
+      float ms = 0.f;
+#pragma unroll
+      for (int f2 = 0; f2 < FG; ++f2) ms += part[f2 * R + rl];
+      mean[rt][gq] = ms * (1.0f / D);
       float vs = 0.f;
 #pragma unroll
       for (int TL = 0; TL < NL; ++TL) {
-        const float d = tt[rt][TL][gq] - mean[rt][gq];
-        vs = fmaf(d, d, vs);
+        const float dv = tt[rt][TL][gq] - mean[rt][gq];
+        vs = fmaf(dv, dv, vs);
       }
       vs = row16_sum_f(vs);
-      if (a == 0) part[4 * R + fg * R + rl] = vs;
+      if (a == 0) part[FG * R + fg * R + rl] = vs;
     }
   __syncthreads();
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
-      const int rl = 4 * R + 32 * rg + 16 * rt + 4 * q + gq;
-      inv[rt][gq] = 1.0f / sqrtf(((part[rl] + part[R + rl]) + (part[2 * R + rl] + part[3 * R + rl])) * (1.0f / D) + p.eps);
+      const int rl = FG * R + 32 * rg + 16 * rt + 4 * q + gq;
+      float vs = 0.f;
+#pragma unroll
+      for (int f2 = 0; f2 < FG; ++f2) vs += part[f2 * R + rl];
+      inv[rt][gq] = 1.0f / sqrtf(vs * (1.0f / D) + p.eps);
     }
 #pragma unroll
   for (int TL = 0; TL < NL; ++TL) {
@@ -776,6 +860,8 @@ __global__ __launch_bounds__(1024) void wide_update_kernel(GuParams p) {
           p.h[row * D + f] = (tt[rt][TL][gq] - mean[rt][gq]) * inv[rt][gq] * gm + bt + hreg[rt][TL][gq];
       }
   }
+  WIDE_STAMP(p.stamps, 4);
+  WIDE_STAMP_REAL(p.stamps, 6);
 }
 
 // a8: one thread per 16-byte piece of a pooled row, 4 rows in flight, ascending n.
@@ -903,7 +989,7 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     wide_zero_kernel<<<(nz + 255) / 256, 256, 0, s>>>(I(w.meta), nz);
     wide_count_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.cnt));
     wide_scan_kernel<<<1, 1024, 0, s>>>(I(w.kept), I(w.rowbase), I(w.cnt), I(w.tstart), I(w.cursor), I(w.tilebase),
-                                        I(w.meta), a.n_ions, a.B, w.nT, te);
+                                        I(w.srcrow), I(w.meta), a.n_ions, a.B, w.nT, te);
     wide_place_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.rowbase), I(w.cursor), I(w.srcrow),
                                               reinterpret_cast<int2*>(base + w.rowinfo), I(w.csr));
     if (int rc = check_launch("encoder_wide plan")) return rc;
@@ -925,12 +1011,10 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   profile_record_start(s);
   wide_embed_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.rowbase), a.atom_table, F(w.h), a.D);
   const int cus = 256;
-  const size_t msg_lds = ((size_t)a.D * (a.D + 4) + 2 * (size_t)te * (a.D + 4)) * 4;
+  const size_t msg_lds = ((size_t)a.D * (a.D + 4) + 2 * (size_t)te * (a.D + 4)) * 4 + (size_t)(w.nT + 1) * 4;
   const int nt = a.D / 16;
   constexpr int R = kRT;
-  const size_t a1 = 4 * R * 4, b1 = 4 * 2 * (size_t)a.D * 4, b2 = 4 * (size_t)a.D * 4;
-  const size_t st = (a1 + b1) > (2 * a1 + 2 * b2) ? (a1 + b1) : (2 * a1 + 2 * b2);
-  const size_t gu_lds = (2 * st + (size_t)R * (a.D + 4) + 8 * R) * 4;
+  const size_t gu_lds = gu_lds_floats(a.D) * 4;
   if (a.D == 128) {
     if (int rc = raise_lds(wide_message_kernel<8, 64>, msg_lds)) return rc;
     if (int rc = raise_lds(wide_update_kernel<8>, gu_lds)) return rc;
@@ -940,14 +1024,21 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   }
   const int64_t red_threads = w.rmax * (a.D / 4);
   const int gu_grid = (int)(w.rmax / R);
+  unsigned long long* stamps = nullptr;  // [gu_grid x 8 | cus x 8] words, the last step's launches win
+  {
+    size_t sb = 0;
+    void* sp = debug_stamp_buffer(&sb);
+    if (sp && sb >= ((size_t)gu_grid + cus) * 8 * sizeof(unsigned long long)) stamps = static_cast<unsigned long long*>(sp);
+  }
   for (int stp = 0; stp < a.S; ++stp) {
     const size_t step_off = (size_t)stp * step_floats(a.D, a.Vb);
     MsgParams mp{};
     mp.h = F(w.h); mp.m = F(w.m);
     mp.img[0] = img[0]; mp.img[1] = img[1];
     mp.mat_off = step_off;
-    mp.srcrow = I(w.srcrow); mp.tstart = I(w.tstart); mp.tilebase = I(w.tilebase); mp.meta = I(w.meta);
+    mp.srcrow = I(w.srcrow); mp.tilebase = I(w.tilebase); mp.meta = I(w.meta);
     mp.nT = w.nT; mp.Vb = a.Vb;
+    mp.stamps = stamps ? stamps + (size_t)gu_grid * 8 : nullptr;
     if (a.E > 0) {
       if (nt == 8) wide_message_kernel<8, 64><<<cus, 1024, msg_lds, s>>>(mp);
       else wide_message_kernel<4, 128><<<cus, 1024, msg_lds, s>>>(mp);
@@ -959,8 +1050,9 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     gp.img[0] = img[0]; gp.img[1] = img[1];
     gp.gu_off = step_off + (size_t)a.Vb * a.D * a.D;
     gp.meta = I(w.meta); gp.eps = a.ln_eps; gp.n_ions = a.n_ions;
-    if (nt == 8) wide_update_kernel<8><<<gu_grid, 1024, gu_lds, s>>>(gp);
-    else wide_update_kernel<4><<<gu_grid, 1024, gu_lds, s>>>(gp);
+    gp.stamps = stamps;
+    if (nt == 8) wide_update_kernel<8><<<gu_grid, kGuThreads, gu_lds, s>>>(gp);
+    else wide_update_kernel<4><<<gu_grid, kGuThreads, gu_lds, s>>>(gp);
   }
   const int64_t pool_threads = (int64_t)mols * (a.D / 4);
   wide_pool_kernel<<<(unsigned)((pool_threads + 255) / 256), 256, 0, s>>>(in, I(w.kept), I(w.rowbase), F(w.h),
