@@ -131,6 +131,59 @@ def cpu_baseline(inputs, w, gpu_pooled=None, budget_s=24.0):
     return out
 
 
+def time_other_configs(dev, Va, Vb):
+    """Labelled extras of the bench line (never `value`): whole-model forward of BASELINE.json configs[2]
+    (melting point, K = D^2 = 1024, S = 4, batch 8192: train_melting_point.py:146-198) and of configs[4]'s forward
+    shape (atom_dim 128, 6 steps, batch 4096: the validation / predict path of train_viscosity.py with atom_dim=128),
+    one stream, synthetic graphs of the bench's generator, with the executed exact-f32 flops beside the time."""
+    import numpy as np
+    import torch
+    from ionic_mpnn_amd import model, synthetic, weights
+    out = {}
+
+    def timed(fn, iters):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+
+    def executed_flops(inp, D, S):
+        rows = edges = 0
+        for pfx in ("cat", "an"):
+            ids, conn = inp[f"{pfx}_atom"], inp[f"{pfx}_connectivity"]
+            ok = (conn[:, :, 0] > 0) & (conn[:, :, 1] > 0)
+            last_id = np.where(ids > 0, np.arange(ids.shape[1])[None, :] + 1, 0).max(axis=1)
+            last_e = np.where(ok, conn.max(axis=2) + 1, 0).max(axis=1)
+            rows += int(np.maximum(last_id, last_e).sum())
+            edges += int(ok.sum())
+        return S * (12 * D * D * rows + 2 * D * D * edges)
+
+    for name, B, D, K, S, kind in (("config3_melting_point_D32_K1024_S4_B8192", 8192, 32, 1024, 4, "melting_point"),
+                                   ("config5_forward_D128_K8_S6_B4096", 4096, 128, 8, 6, "viscosity")):
+        inp = synthetic.make_batch(B, seed=0, with_temperature=(kind == "viscosity"))
+        if kind == "melting_point":
+            m = model.build_melting_point_model(Va, Vb, atom_dim=D, num_steps=S, device=dev)
+        else:
+            m = model.build_model(Va, Vb, atom_dim=D, bond_dim=K, num_steps=S, device=dev)
+        m.load_weights(weights.init_weights(kind, Va, Vb, atom_dim=D, bond_dim=K, num_steps=S, seed=1))
+        d = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+        ms = timed(lambda: m(d), 10)
+        fl = executed_flops(inp, D, S)
+        out[name] = {"ms_per_forward": ms, "graph_pairs_per_s": B / (ms * 1e-3),
+                     "encoder": m.resolve_encoder_mode(inp["cat_atom"].shape[1], inp["cat_bond"].shape[1]),
+                     "executed_f32_tflops": fl / (ms * 1e-3) / 1e12,
+                     "frac_of_f32_mfma_peak": fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                     "note": "whole model forward incl. plan kernels and the head, one stream; executed flops = exact-f32 "
+                             "products on kept rows / valid edges (12 D^2 per row, 2 D^2 per edge and step)"}
+        del m, d
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +192,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="graph pairs per GPU")
     ap.add_argument("--mp-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the labelled extras for BASELINE.json configs[2] and configs[4]'s forward shape")
     ap.add_argument("--schedule", choices=["fused", "layered"], default="fused")
     ap.add_argument("--pipeline", action="store_true",
                     help="enqueue the plan kernels of step i+1 on a side stream before the encoder of step i "
@@ -282,7 +337,7 @@ def main():
     # the dominant kernel ALONE on the chip (one stream, one workgroup per CU): what roofline.achieved is computed from.
     # With several streams the event-bracketed duration of a launch includes the time it shares the chip with the
     # neighbouring batches' kernels, so that figure is reported as `overlapped` only.
-    exclusive_ms, single_ms, full_ms, extras = None, None, None, {}
+    exclusive_ms, single_ms, full_ms, extras, other_configs = None, None, None, {}, None
     if fused and rank == 0:
         m.encoder_workgroups = 0
         for _ in range(5):
@@ -358,6 +413,8 @@ def main():
                                  "max_rel_diff_vs_timed_mode": float(max((oc - ref_c).abs().max(),
                                                                          (oa - ref_a).abs().max())) / scale}
             m.encoder_mode = args.mode
+            if not args.no_other_configs:
+                other_configs = time_other_configs(dev, synthetic.DEFAULT_VA, synthetic.DEFAULT_VB)
     m.encoder_workgroups = enc_wgs
 
     if rank != 0:
@@ -427,6 +484,8 @@ def main():
                                                        "not `value`"}
     if extras:
         out["config"]["other_modes"] = extras
+    if other_configs:
+        out["config"]["other_configs"] = other_configs
     if rehearsal:
         out["config"]["rehearsal"] = f"{world} ranks share {ndev} GPU(s) over gloo - not a scaling number"
     k_ms = exclusive_ms or overlapped_ms

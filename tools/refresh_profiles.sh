@@ -12,6 +12,11 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/$R/prof -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $ROOT/gpurun_out/$R/prof.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/$R/prof_s1 -- python3 $ROOT/bench.py --steps 20 --warmup 5 --streams 1 --no-cpu-baseline > $ROOT/gpurun_out/$R/prof_s1.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/$R/prof_layered -- python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --schedule layered > $ROOT/gpurun_out/$R/prof_layered.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/$R/prof_wide -- python3 $ROOT/tools/wide_probe.py > $ROOT/gpurun_out/$R/prof_wide.log 2>&1
 cd $ROOT
+python tools/wide_probe.py > gpurun_out/$R/wide_probe.json 2>> gpurun_out/$R/bench.err
+if [ -f ionic_mpnn_amd/csrc/ab/lib_STAMPS.so ]; then
+  IMPNN_LIB=$ROOT/ionic_mpnn_amd/csrc/ab/lib_STAMPS.so python tools/wide_stamps.py > gpurun_out/$R/wide_stamps.txt 2>&1
+fi
 bash tools/pmc_profile.sh gpurun_out/$R/pmc > /dev/null 2>&1
 cat gpurun_out/$R/bench.json
