@@ -13,7 +13,9 @@ for f in glob.glob(f"{out}/*/**/*counter_collection.csv", recursive=True):
             k = row["Kernel_Name"]
             short = ("encoder_typed_x3" if "encoder_typed" in k and ", true>" in k else
                      "encoder_typed" if "encoder_typed" in k else "encoder_fused" if "encoder_fused" in k else
-                     "plan_stats" if "plan_stats" in k else "plan_chunks" if "plan_chunks" in k else None)
+                     "plan_stats" if "plan_stats" in k else "plan_chunks" if "plan_chunks" in k else
+                     "wide_update" if "wide_update" in k else "wide_message" if "wide_message" in k else
+                     "wide_reduce" if "wide_reduce" in k else None)
             if short:
                 acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for kern, cs in acc.items():
