@@ -4,6 +4,8 @@
 // in layer_kernels.hip with the same masks (models/layers.py:114-115, :70 tgt > 0) and the same
 // "out-of-range index == padding" rule.  Written for any D (VALU, f32); the parameter-gradient sums run
 // over per-workgroup partial buffers that a second kernel adds in a fixed order, except where noted.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace impnn {
@@ -312,6 +314,248 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_kernel(
       atomicAdd(&dA[(int64_t)ty * DD + q], v);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// The same adjoint on the matrix cores for wide states (D = 64, 128; exact f32 products).  Per 64-edge segment two
+// GEMMs: dh rows = G A_t (features on M from the TRANSPOSED type matrix in LDS, edges on N) and dA_t += G^T X (both
+// operands straight from the row-major edge tiles: one 4-byte LDS read per operand and k step, a 2x2 block of output
+// tiles per wave), G = dm rows (or dagg rows at the edges' targets), X = h rows at their sources.  A workgroup walks a
+// contiguous range of segments: the type's transposed matrix stays in LDS and its dA accumulators (16 registers per
+// thread) in registers until the type changes, when they are added to dA with float atomics (dh likewise, as in the
+// VALU kernel above: several edges share a source row).  Edge indices run three segments ahead of the MFMAs (sorted
+// position -> edge slot -> its rows -> the two 512-byte rows), one stage per iteration, so that no request waits on a
+// load issued in the same iteration; segments past the workgroup's range are clamped to its last one.
+// The VALU kernel took 1.7 ms per call at 4096 molecules x D = 128 (1.3 % of the f32 MFMA peak for 10.7 GFLOP).
+// ---------------------------------------------------------------------------------------
+constexpr int kBwdMfmaMaxTypes = 1024;
+
+template <int NT>
+__global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
+    const float* __restrict__ h, const int32_t* __restrict__ conn, const float* __restrict__ A,
+    const float* __restrict__ dm, float* __restrict__ dh, float* __restrict__ dA, const int32_t* __restrict__ start,
+    const int32_t* __restrict__ segbase, const int32_t* __restrict__ order, int N, int E, int Vb, int from_agg) {
+  constexpr int D = 16 * NT, LD = D + 4, QD = D / 4, NLW = NT / 4, TI = NT / 4;
+  constexpr int kX = kSeg * QD / 1024;  // 16-byte pieces of an edge tile per thread
+  constexpr int kB = D * QD / 1024;     // ... of the matrix
+  static_assert(kX >= 1 && kB >= 1 && NLW >= 1, "tile shape");
+  extern __shared__ __align__(16) float smem[];
+  float* AmT = smem;                // D x LD : AmT[j][i] = A_t[i][j]
+  float* G = AmT + D * LD;          // kSeg x LD
+  float* X = G + kSeg * LD;         // kSeg x LD
+  int32_t* hrow_s = reinterpret_cast<int32_t*>(X + kSeg * LD);  // kSeg source rows (b * N + src)
+  int32_t* sb_s = hrow_s + kSeg;    // segbase[0 .. Vb]
+  int32_t* st_s = sb_s + Vb + 1;    // start[0 .. Vb]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = lane & 15, q = lane >> 4;
+  const int nseg = segbase[Vb];
+  const int per = (nseg + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int s0 = blockIdx.x * per, s1 = s0 + per < nseg ? s0 + per : nseg;
+  if (s0 >= s1) return;
+  for (int t = tid; t <= Vb; t += 1024) {
+    sb_s[t] = segbase[t];
+    st_s[t] = start[t];
+  }
+  __syncthreads();
+  struct Seg {
+    int ty, p0, n;
+  };
+  auto seg_of = [&](int seg, int ty) {  // ty: a type at or before the segment's
+    while (sb_s[ty + 1] <= seg) ++ty;
+    Seg d;
+    d.ty = ty;
+    d.p0 = st_s[ty] + (seg - sb_s[ty]) * kSeg;
+    d.n = min(kSeg, st_s[ty + 1] - d.p0);
+    return d;
+  };
+  int ty0;
+  {
+    int lo = 0, hi = Vb - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (sb_s[mid] <= s0) lo = mid; else hi = mid - 1;
+    }
+    ty0 = lo;
+  }
+  // pipeline stages, per thread and piece i < kX (edge e_i = (tid + 1024 i) / QD of the segment):
+  //   stage C (3 ahead): be  = order[p0 + min(e, n - 1)]
+  //   stage B (2 ahead): src, tgt = conn[be]                      -> rows
+  //   stage A (1 ahead): the two 16-byte pieces of dm / h          -> registers -> LDS after the MFMAs
+  int be_c[kX], be_b[kX], ok_b[kX];
+  int hrow_a[kX], grow_a[kX], ok_a[kX];
+  int64_t hrow_x[kX];
+  f32x4_t gr[kX], xr[kX];
+  int hrow_n[kX], ok_n[kX];  // of the pieces held in gr / xr
+  auto stage_c = [&](const Seg& d, int* be, int* ok) {
+#pragma unroll
+    for (int i = 0; i < kX; ++i) {
+      const int e = (tid + 1024 * i) / QD;
+      ok[i] = e < d.n;
+      be[i] = order[d.p0 + min(e, d.n - 1)];
+    }
+  };
+  auto stage_b = [&](const int* be, int* hrow, int* grow) {
+#pragma unroll
+    for (int i = 0; i < kX; ++i) {
+      const int b = be[i] / E;
+      const int2 st = *reinterpret_cast<const int2*>(conn + (int64_t)be[i] * 2);
+      hrow[i] = b * N + st.x;
+      grow[i] = from_agg ? b * N + st.y : be[i];
+    }
+  };
+  auto stage_a = [&](const int* hrow, const int* grow) {
+#pragma unroll
+    for (int i = 0; i < kX; ++i) {
+      const int c4 = (tid + 1024 * i) % QD;
+      gr[i] = ldv4(dm + (int64_t)grow[i] * D + 4 * c4);
+      xr[i] = ldv4(h + (int64_t)hrow[i] * D + 4 * c4);
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < kX; ++i) {
+      const int idx = tid + 1024 * i, e = idx / QD, c4 = idx - e * QD;
+      const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+      stv4(G + e * LD + 4 * c4, ok_n[i] ? gr[i] : zero);  // rows past the segment's edges are zero: they add nothing to dA
+      stv4(X + e * LD + 4 * c4, ok_n[i] ? xr[i] : zero);
+      if (c4 == 0) hrow_s[e] = hrow_n[i];
+    }
+  };
+  auto load_matrix = [&](int ty) {  // transposing copy: lanes run along i (conflict-free LDS stores)
+    const float* At = A + (int64_t)ty * D * D;
+#pragma unroll
+    for (int i2 = 0; i2 < kB; ++i2) {
+      const int idx = tid + 1024 * i2, i = idx % D, c4 = idx / D;
+      const f32x4_t v = ldv4(At + (int64_t)i * D + 4 * c4);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) AmT[(4 * c4 + r) * LD + i] = v[r];
+    }
+  };
+  const int last = s1 - 1;
+  Seg d0 = seg_of(s0, ty0);
+  Seg d1 = seg_of(min(s0 + 1, last), d0.ty), d2 = seg_of(min(s0 + 2, last), d1.ty), d3 = seg_of(min(s0 + 3, last), d2.ty);
+  // prologue: bring segment s0 into LDS, s0 + 1 to stage A, s0 + 2 to stage B, s0 + 3 to stage C
+  {
+    int be0[kX], ok0[kX], hr0[kX], gr0[kX];
+    stage_c(d0, be0, ok0);
+    stage_b(be0, hr0, gr0);
+    stage_a(hr0, gr0);
+#pragma unroll
+    for (int i = 0; i < kX; ++i) {
+      hrow_n[i] = hr0[i];
+      ok_n[i] = ok0[i];
+    }
+    load_matrix(d0.ty);
+    park();
+    stage_c(d1, be0, ok0);
+    stage_b(be0, hrow_a, grow_a);
+#pragma unroll
+    for (int i = 0; i < kX; ++i) ok_a[i] = ok0[i];
+    stage_c(d2, be_b, ok_b);
+    stage_c(d3, be_c, ok_n);  // (ok of stage C travels with it below)
+  }
+  int ok_c[kX];
+#pragma unroll
+  for (int i = 0; i < kX; ++i) ok_c[i] = ok_n[i];
+#pragma unroll
+  for (int i = 0; i < kX; ++i) ok_n[i] = 1;  // placeholder until the first stage-A request below
+  __syncthreads();
+  const int et = wave & 3, fg = wave >> 2;          // GEMM 1: edge tile, feature group
+  const int wi = wave & 3, wj = wave >> 2;          // GEMM 2: block of i tiles, block of j tiles
+  f32x4_t acc2[TI][TI];
+#pragma unroll
+  for (int x = 0; x < TI; ++x)
+#pragma unroll
+    for (int y = 0; y < TI; ++y) acc2[x][y] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  auto flush_dA = [&](int ty) {
+    float* dst = dA + (int64_t)ty * D * D;
+#pragma unroll
+    for (int x = 0; x < TI; ++x)
+#pragma unroll
+      for (int y = 0; y < TI; ++y) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          atomicAdd(dst + (16 * (wi * TI + x) + 4 * q + g) * D + 16 * (wj * TI + y) + a, acc2[x][y][g]);
+        acc2[x][y] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+  };
+  for (int seg = s0; seg < s1; ++seg) {
+    // requests for the segments ahead (each consumes what the previous iteration requested)
+    int hrow_t[kX], ok_t[kX];
+#pragma unroll
+    for (int i = 0; i < kX; ++i) {
+      hrow_t[i] = hrow_a[i];
+      ok_t[i] = ok_a[i];
+    }
+    stage_a(hrow_a, grow_a);                 // rows of seg + 1
+    stage_b(be_b, hrow_a, grow_a);           // row indices of seg + 2
+#pragma unroll
+    for (int i = 0; i < kX; ++i) {
+      ok_a[i] = ok_b[i];
+      be_b[i] = be_c[i];
+      ok_b[i] = ok_c[i];
+    }
+    const Seg d4 = seg_of(min(seg + 4, last), d3.ty);
+    stage_c(d4, be_c, ok_c);                 // edge slots of seg + 4
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- GEMM 1: dh rows of this segment's edges
+    {
+      f32x4_t acc1[NLW];
+#pragma unroll
+      for (int TL = 0; TL < NLW; ++TL) acc1[TL] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      const float* grow_p = G + (16 * et + a) * LD + 4 * q;
+      const float* arow_p = AmT + (16 * (fg * NLW) + a) * LD + 4 * q;
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const f32x4_t gv = ldv4(grow_p + 16 * u);
+        f32x4_t av[NLW];
+#pragma unroll
+        for (int TL = 0; TL < NLW; ++TL) av[TL] = ldv4(arow_p + 16 * TL * LD + 16 * u);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int TL = 0; TL < NLW; ++TL) acc1[TL] = mfma_f32(av[TL][r], gv[r], acc1[TL]);
+      }
+      // (unconditional: rows past the segment's edges are zero in G, so their sums are exact zeros added to the row
+      //  of the segment's last edge - a conditional atomic would keep the compiler from counting outstanding
+      //  memory operations, and the LDS stores below would wait for every atomic of the tile)
+      float* dst = dh + (int64_t)hrow_s[16 * et + a] * D + 16 * (fg * NLW) + 4 * q;
+#pragma unroll
+      for (int TL = 0; TL < NLW; ++TL)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) atomicAdd(dst + 16 * TL + g, acc1[TL][g]);
+    }
+    // ---- GEMM 2: dA_t += G^T X over the segment's edges (k = edge)
+#pragma unroll 4
+    for (int sx = 0; sx < kSeg / 4; ++sx) {
+      float gi[TI], xj[TI];
+#pragma unroll
+      for (int x = 0; x < TI; ++x) gi[x] = G[(4 * sx + q) * LD + 16 * (wi * TI + x) + a];
+#pragma unroll
+      for (int y = 0; y < TI; ++y) xj[y] = X[(4 * sx + q) * LD + 16 * (wj * TI + y) + a];
+#pragma unroll
+      for (int x = 0; x < TI; ++x)
+#pragma unroll
+        for (int y = 0; y < TI; ++y) acc2[x][y] = mfma_f32(gi[x], xj[y], acc2[x][y]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (seg + 1 >= s1) break;
+    const bool new_type = d1.ty != d0.ty;  // (workgroup-uniform)
+    if (new_type) flush_dA(d0.ty);
+    __syncthreads();                       // every wave is done with G, X, hrow_s (and AmT)
+#pragma unroll
+    for (int i = 0; i < kX; ++i) {
+      hrow_n[i] = hrow_t[i];
+      ok_n[i] = ok_t[i];
+    }
+    park();
+    if (new_type) load_matrix(d1.ty);
+    __syncthreads();
+    d0 = d1;
+    d1 = d2;
+    d2 = d3;
+    d3 = d4;
+  }
+  flush_dA(d0.ty);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2175,6 +2419,20 @@ int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const 
   if (!sorted_ready)  // the sort depends on (conn, bond_ids) only: forward and backward of the S layers of an ion share it
     if (int rc = launch_edge_type_sort(bond_ids, conn, workspace, B, N, E, Vb, s)) return rc;
   const int64_t max_segs = (BE + kSeg - 1) / kSeg + Vb;
+  const bool al16 = ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(dm)) & 15u) == 0 &&
+                    (reinterpret_cast<uintptr_t>(conn) & 7u) == 0;
+  if ((D == 64 || D == 128) && Vb <= kBwdMfmaMaxTypes && al16 && !getenv("IMPNN_MESSAGE_BWD_VALU")) {
+    const size_t lm = sizeof(float) * ((size_t)D * (D + 4) + 2 * (size_t)kSeg * (D + 4)) + sizeof(int32_t) * (kSeg + 2 * (size_t)(Vb + 1));
+    const int grid = (int)(max_segs < 256 ? max_segs : 256);
+    if (D == 128) {
+      (void)hipFuncSetAttribute((const void*)bmm_message_typed_bwd_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
+      bmm_message_typed_bwd_mfma_kernel<8><<<grid, 1024, lm, s>>>(h, conn, A, dm, dh, dA, start, segbase, order, N, E, Vb, from_agg);
+    } else {
+      (void)hipFuncSetAttribute((const void*)bmm_message_typed_bwd_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
+      bmm_message_typed_bwd_mfma_kernel<4><<<grid, 1024, lm, s>>>(h, conn, A, dm, dh, dA, start, segbase, order, N, E, Vb, from_agg);
+    }
+    return check_launch("bmm_message_typed_bwd (mfma)");
+  }
   const size_t lds = sizeof(float) * ((size_t)D * D + 2 * (size_t)kSeg * D);
   // wide states need > 64 KB of LDS (one workgroup per CU): 16 waves instead of 4 keep every SIMD busy
   const int threads = D >= 64 ? 1024 : kBlock;

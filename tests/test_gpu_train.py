@@ -29,10 +29,10 @@ def rand_graph(B, N, E, Vb, rng):
     return conn, bond, ids
 
 
-@pytest.mark.parametrize("D,K", [(8, 4), (32, 8), (64, 3)])
-def test_message_reduce_backward(D, K):
+@pytest.mark.parametrize("D,K,B,E", [(8, 4, 5, 14), (32, 8, 5, 14), (64, 3, 5, 14), (128, 8, 40, 30), (64, 8, 90, 30)])
+def test_message_reduce_backward(D, K, B, E):
     rng = np.random.default_rng(D)
-    B, N, E, Vb = 5, 9, 14, 7
+    N, Vb = 9, 7
     conn, bond, _ = rand_graph(B, N, E, Vb, rng)
     h = rng.normal(size=(B, N, D)); tb = rng.normal(size=(Vb, K)); W = rng.normal(size=(K, D, D)) / np.sqrt(D)
     go = rng.normal(size=(B, N, D))
@@ -62,6 +62,44 @@ def test_message_reduce_backward(D, K):
     close(hf.grad, ho.grad, what="dh (one node)")
     close(Wf.grad, Wo.grad, what="dW (one node)")
     close(tbf.grad, tbo.grad, what="dbond_table (one node)")
+
+
+@pytest.mark.parametrize("D,Vb,from_agg", [(128, 12, True), (64, 72, True), (128, 3, False)])
+def test_message_backward_on_the_matrix_cores_equals_the_valu_kernel(D, Vb, from_agg):
+    """Wide states take bmm_message_typed_bwd_mfma_kernel (csrc/train_kernels.hip): same gradients as the VALU kernel
+    (IMPNN_MESSAGE_BWD_VALU=1) on a batch whose type runs span several segments and several workgroup ranges - types
+    change inside a workgroup's range, last segments of a type are partial.  (Both kernels add into dh / dA with
+    float atomics: equal up to the order of f32 additions.)"""
+    import os
+    from ionic_mpnn_amd import _lib
+    rng = np.random.default_rng(D + Vb)
+    B, N, E = 700, 40, 80
+    conn, bond, _ = rand_graph(B, N, E, Vb, rng)
+    h = torch.tensor(rng.normal(size=(B, N, D)), dtype=torch.float32, device=DEV)
+    mats = torch.tensor(rng.normal(size=(Vb, D, D)) / np.sqrt(D), dtype=torch.float32, device=DEV)
+    dm = torch.tensor(rng.normal(size=(B, N, D) if from_agg else (B, E, D)), dtype=torch.float32, device=DEV)
+    cg, bg = torch.tensor(conn, device=DEV), torch.tensor(bond, device=DEV)
+    lib = _lib.load()
+
+    def run():
+        dh = torch.zeros(B, N, D, device=DEV)
+        dA = torch.zeros_like(mats)
+        nb = int(lib.impnn_bmm_message_typed_bwd_workspace_bytes(B, E, Vb))
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        fn = lib.impnn_message_reduce_typed_bwd if from_agg else lib.impnn_bmm_message_typed_bwd
+        _lib.check(fn(ops.ptr(h), ops.ptr(bg), ops.ptr(cg), ops.ptr(mats), ops.ptr(dm), ops.ptr(dh), ops.ptr(dA),
+                      ops.ptr(ws), ws.numel(), B, N, E, D, Vb, 0, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        return dh, dA
+
+    dh1, dA1 = run()
+    os.environ["IMPNN_MESSAGE_BWD_VALU"] = "1"
+    try:
+        dh0, dA0 = run()
+    finally:
+        del os.environ["IMPNN_MESSAGE_BWD_VALU"]
+    close(dh1, dh0.double().cpu(), 2e-6, "dh mfma vs valu")
+    close(dA1, dA0.double().cpu(), 2e-6, "dA mfma vs valu")
 
 
 @pytest.mark.parametrize("D,K,n,sinks", [(32, 8, 6, True), (8, 4, 3, False), (16, 5, 18, True)])
