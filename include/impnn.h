@@ -376,6 +376,17 @@ int impnn_gated_update_bwd(const float* h, const float* agg, const float* Wz, co
                            const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
                            int64_t workspace_floats, int64_t rows, int32_t D, int32_t accumulate,
                            impnn_stream_t stream);
+/* a7 backward on a row list (the adjoint of impnn_gated_update_rows; atom_dim 64 / 128): gradients of the rows
+ * row_index[0 .. *n_rows) only - dh / dagg rows outside the list are left untouched (a caller that reads them zeroes
+ * them first), the parameter gradients are sums over the listed rows.  Padding atoms of an encode() loop carry no
+ * gradient (nothing they compute reaches a message or the pool), so this is exact for impnn_kept_rows' list.
+ * The launch is sized for max_rows; *n_rows lives on the device (no host round trip, capturable). */
+int64_t impnn_gated_update_rows_bwd_workspace_floats(int64_t max_rows, int32_t D);
+int impnn_gated_update_rows_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
+                                const float* br, const float* Wh, const float* bh, const float* gamma, float ln_eps,
+                                const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
+                                int64_t workspace_floats, const int32_t* row_index, const int32_t* n_rows,
+                                int64_t max_rows, int32_t D, int32_t accumulate, impnn_stream_t stream);
 
 /*  Optimizer step, one launch for all variables (train_viscosity.py:227-230):
  *      g <- g * clipnorm / max(||g||_2, clipnorm)      per variable (tf.clip_by_norm); clipnorm <= 0: off

@@ -258,17 +258,32 @@ class GatedUpdate(torch.autograd.Function):
         return _gated_update_backward(ctx.saved_tensors, ctx.eps, dout)
 
 
-def _gated_update_backward(saved, eps, dout):
-    """(dh, dagg, 8 parameter gradients or None where the kernel added into the sink, None for eps)"""
+def _gated_update_backward(saved, eps, dout, row_list=None):
+    """(dh, dagg, 8 parameter gradients or None where the kernel added into the sink, None for eps).
+    row_list = (row_index, n_rows) of ops.kept_row_index: gradients of those rows only (impnn_gated_update_rows_bwd);
+    dh is zero elsewhere (padding atoms carry no gradient), dagg is undefined there and never read."""
     h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta = saved
     D = h.shape[-1]
     rows = h.numel() // D
     lib = _lib.load()
     dout = f32c(dout)
-    dh, dagg = torch.empty_like(h), torch.empty_like(agg)
+    dh = torch.zeros_like(h) if row_list is not None else torch.empty_like(h)
+    dagg = torch.empty_like(agg)
     P = int(lib.impnn_gated_update_param_floats(D))
-    wsn = int(lib.impnn_gated_update_bwd_workspace_floats(rows, D))
+    if row_list is not None:
+        wsn = int(lib.impnn_gated_update_rows_bwd_workspace_floats(rows, D))
+    else:
+        wsn = int(lib.impnn_gated_update_bwd_workspace_floats(rows, D))
     ws = torch.empty(max(wsn, 1), dtype=torch.float32, device=h.device)
+
+    def call(dparams, accumulate):
+        common = (ptr(h), ptr(agg), ptr(Wz), ptr(bz), ptr(Wr), ptr(br), ptr(Wh), ptr(bh), ptr(gamma), eps, ptr(dout),
+                  ptr(dh), ptr(dagg), ptr(dparams), ptr(ws), wsn)
+        if row_list is not None:
+            _lib_call(h.device, lib.impnn_gated_update_rows_bwd, *common, ptr(row_list[0]), ptr(row_list[1]), rows, D,
+                      accumulate)
+        else:
+            _lib_call(h.device, lib.impnn_gated_update_bwd, *common, rows, D, accumulate)
     # the eight parameter gradients leave the kernel as one block in the canonical order; when the existing
     # .grad buffers form exactly that block (train.Adam's flat buffer does), the kernel adds into it directly
     params = (Wz, bz, Wr, br, Wh, bh, gamma, beta)
@@ -280,13 +295,10 @@ def _gated_update_backward(saved, eps, dout):
             direct = direct and g.data_ptr() == base + 4 * off and g.numel() == t.numel()
             off += t.numel()
     if direct:
-        _lib_call(h.device, lib.impnn_gated_update_bwd, ptr(h), ptr(agg), ptr(Wz), ptr(bz), ptr(Wr), ptr(br),
-                  ptr(Wh), ptr(bh), ptr(gamma), eps, ptr(dout), ptr(dh), ptr(dagg), ptr(sinks[0]), ptr(ws), wsn,
-                  rows, D, 1)
+        call(sinks[0], 1)
         return (dh, dagg, *([None] * 8), None)
     dparams = torch.empty(P, dtype=torch.float32, device=h.device)
-    _lib_call(h.device, lib.impnn_gated_update_bwd, ptr(h), ptr(agg), ptr(Wz), ptr(bz), ptr(Wr), ptr(br), ptr(Wh),
-              ptr(bh), ptr(gamma), eps, ptr(dout), ptr(dh), ptr(dagg), ptr(dparams), ptr(ws), wsn, rows, D, 0)
+    call(dparams, 0)
     n_w, o = 2 * D * D, 0
     grads = []
     for _ in range(3):
@@ -305,13 +317,18 @@ class MessagePassingStep(torch.autograd.Function):
     goes into a buffer BondTypeMatricesAll zeroed for all layers at once (``type_mats._impnn_dmats``) when there is one."""
 
     @staticmethod
-    def forward(ctx, h, bond_ids, conn, type_mats, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps):
+    def forward(ctx, h, bond_ids, conn, type_mats, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, row_index=None,
+                n_rows=None):
+        """row_index / n_rows (ops.kept_row_index; atom_dim 64 / 128): GatedUpdate forward and backward on the kept rows
+        only - padding atoms reach neither a message nor the pool, so their rows of the output are left undefined
+        and their gradient is zero (include/impnn.h, impnn_gated_update_rows[_bwd])."""
         h, type_mats, bond_ids, conn = f32c(h), f32c(type_mats), i32c(bond_ids), i32c(conn)
         gu = [f32c(t) for t in (Wz, bz, Wr, br, Wh, bh, gamma)]
         m = ops.bmm_message_typed(h, bond_ids, conn, type_mats)
         agg = ops.reduce_scatter_add(m, conn[:, :, 1], h.shape[1])
         del m
-        out = ops.gated_update(h, agg, *gu, beta, eps)
+        ctx.row_list = (row_index, n_rows) if row_index is not None else None
+        out = ops.gated_update(h, agg, *gu, beta, eps, rows=ctx.row_list)
         ctx.save_for_backward(h, agg, *gu, beta, bond_ids, conn, type_mats)
         ctx.eps = float(eps)
         ctx.graph_key = (conn, bond_ids, _pass["id"])
@@ -322,7 +339,7 @@ class MessagePassingStep(torch.autograd.Function):
     def backward(ctx, dout):
         saved = ctx.saved_tensors
         h, bond_ids, conn, mats = saved[0], saved[10], saved[11], saved[12]
-        dh, dagg, *dparams = _gated_update_backward(saved[:10], ctx.eps, dout)
+        dh, dagg, *dparams = _gated_update_backward(saved[:10], ctx.eps, dout, ctx.row_list)
         B, N, D = h.shape
         E, Vb = conn.shape[1], mats.shape[0]
         dmats = ctx.dmats_buf if ctx.dmats_buf is not None else torch.zeros_like(mats)
@@ -335,7 +352,7 @@ class MessagePassingStep(torch.autograd.Function):
             _pass["id"] = prev
         _lib_call(h.device, _lib.load().impnn_message_reduce_typed_bwd, ptr(h), ptr(bond_ids), ptr(conn), ptr(mats),
                   ptr(dagg), ptr(dh), ptr(dmats), ptr(ws), ws.numel(), B, N, E, D, Vb, 1 if ready else 0)
-        return (dh, None, None, dmats, *dparams)
+        return (dh, None, None, dmats, *dparams, None, None)
 
 
 class GlobalSumPool(torch.autograd.Function):

@@ -88,11 +88,12 @@ int launch_bond_type_matrices_bwd(const float* tb, const float* W, const float* 
                                   int K, int D, int accumulate, hipStream_t s);
 int gated_update_bwd_blocks(int64_t rows, int D);
 int64_t gated_update_param_floats(int D);
-int64_t gated_update_bwd_workspace(int64_t rows, int D);
+int64_t gated_update_bwd_workspace(int64_t rows, int D, bool row_list = false);
 int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
                             const float* br, const float* Wh, const float* bh, const float* gamma, float eps,
                             const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
-                            int64_t rows, int D, int accumulate, hipStream_t s);
+                            int64_t rows, int D, int accumulate, hipStream_t s, const int32_t* ridx = nullptr,
+                            const int32_t* nrows_dev = nullptr);
 int launch_adam_clipnorm(const void* table, const void* sizes, int n_vars, int64_t step, int64_t* step_dev, float lr,
                          float b1, float b2, float eps, float clipnorm, hipStream_t s);
 

@@ -1301,7 +1301,12 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
     const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma, float eps,
     const float* __restrict__ dout, float* __restrict__ dh, float* __restrict__ dagg, float* __restrict__ dpre,
-    float* __restrict__ rh_out, float* __restrict__ small, int64_t rows) {
+    float* __restrict__ rh_out, float* __restrict__ small, int64_t rows, const int32_t* __restrict__ ridx,
+    const int32_t* __restrict__ nrows_dev, float* __restrict__ hc, float* __restrict__ aggc) {
+  // ridx / nrows_dev (optional): the kernel works on the rows ridx[0 .. *nrows_dev) of h / agg / dout / dh / dagg
+  // (impnn_gated_update_rows_bwd: the kept rows of an encode() loop); dpre, r*h and the copies hc / aggc of the rows'
+  // inputs are written compactly (list position), which is what the weight-gradient GEMMs behind this kernel read.
+  if (nrows_dev) rows = *nrows_dev;
   constexpr int D = 16 * NT, LDC = 2 * D + 4, LDR = D + 4, LDW = 2 * D, NL = NT / 4;
   extern __shared__ __align__(16) float smem[];
   float* cs = smem;                   // 64 x LDC
@@ -1309,6 +1314,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
   float* ws = rhs + 64 * LDR;         // 2 x 16 x LDW, element (k = 4*qq + r, column c) at ((qq * LDW + c) * 4 + r)
   float* part = ws + 2 * 16 * LDW;    // 4 x (4 x 64): LayerNorm row partials (sum, sq. deviation, m1, m2)
   float* red = part + 4 * 256;        // 4 row tiles x 5 x D column sums
+  int32_t* grow_s = reinterpret_cast<int32_t*>(red + 4 * 5 * D);  // 64 global rows of the tile
   const int tid = threadIdx.x;
   int a = tid & 15, q = (tid >> 4) & 3, rt = (tid >> 6) & 3, fg = tid >> 8;  // lane = 16 q + a, wave = 4 fg + rt
   constexpr int kPre = 16 * 2 * D / 1024;
@@ -1353,17 +1359,22 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     const int64_t row0 = tile * 64;
     const int nrt = (int)((rows - row0) < 64 ? (rows - row0) : 64);  // rows of this tile
     // per-tile base pointers (scalar) + 32-bit offsets: keeps the per-element addresses out of the register file
-    const float* dout_t = dout + row0 * D;
-    float* dh_t = dh + row0 * D;
-    float* dagg_t = dagg + row0 * D;
     float* rh_t = rh_out + row0 * D;
     float* dpre_t = dpre + row0 * 3 * D;
+    __syncthreads();
+    if (tid < 64) grow_s[tid] = tid < nrt ? (ridx ? ridx[row0 + tid] : (int32_t)(row0 + tid)) : 0;
     __syncthreads();
     for (int t = tid; t < 64 * D; t += 1024) {
       const int r = t / D, c = t - r * D;
       const bool in = r < nrt;
-      cs[r * LDC + c] = in ? h[row0 * D + t] : 0.f;
-      cs[r * LDC + D + c] = in ? agg[row0 * D + t] : 0.f;
+      const int64_t src = (int64_t)grow_s[r] * D + c;
+      const float hv = in ? h[src] : 0.f, av = in ? agg[src] : 0.f;
+      cs[r * LDC + c] = hv;
+      cs[r * LDC + D + c] = av;
+      if (hc && in) {
+        hc[row0 * D + t] = hv;
+        aggc[row0 * D + t] = av;
+      }
     }
     const float* crow = cs + (16 * rt + a) * LDC + 4 * q;
     const float* rrow = rhs + (16 * rt + a) * LDR + 4 * q;
@@ -1513,7 +1524,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int rl = 16 * rt + 4 * q + g;
-        dy[TL][g] = rl < nrt ? dout_t[rl * D + 16 * (fg * NL + TL) + a] : 0.f;
+        dy[TL][g] = rl < nrt ? dout[(int64_t)grow_s[rl] * D + 16 * (fg * NL + TL) + a] : 0.f;
         xh[TL][g] *= inv[g];
         dxh[TL][g] = dy[TL][g] * gm;
         m1[g] += dxh[TL][g];
@@ -1659,8 +1670,9 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       for (int g = 0; g < 4; ++g) {
         const int rl = 16 * rt + 4 * q + g, f = 16 * (fg * NL + TL) + a;
         if (rl < nrt) {
-          dh_t[rl * D + f] = dhA[TL][g] + lo[TL][g];
-          dagg_t[rl * D + f] = daA[TL][g] + hi[TL][g];
+          const int64_t dst = (int64_t)grow_s[rl] * D + f;
+          dh[dst] = dhA[TL][g] + lo[TL][g];
+          dagg[dst] = daA[TL][g] + hi[TL][g];
         }
       }
   }
@@ -1713,7 +1725,9 @@ constexpr int kGM = 64, kGN = 32, kGR = 32;  // output tile, rows staged per ite
 __global__ __launch_bounds__(kBlock) void strided_gemm_splitk_kernel(GemmProblems ga, float* __restrict__ out,
                                                                      int64_t rows, int M, int Mh, int N,
                                                                      int64_t a_rs, int64_t a_cs, int64_t b_rs,
-                                                                     int64_t b_cs, int nchunk, int tilesN) {
+                                                                     int64_t b_cs, int nchunk, int tilesN,
+                                                                     const int32_t* __restrict__ rows_dev) {
+  if (rows_dev) rows = *rows_dev;  // (the contraction length lives on the device: kept rows of a batch)
   // LDS tiles of kGR contraction rows; row strides chosen so that the four k-rows of one MFMA step fall into
   // disjoint bank groups (80 = 64 + 16, 48 = 32 + 16 floats)
   constexpr int kLA = kGM + 16, kLB = kGN + 16;
@@ -2421,7 +2435,12 @@ int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const 
   const int64_t max_segs = (BE + kSeg - 1) / kSeg + Vb;
   const bool al16 = ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(dm)) & 15u) == 0 &&
                     (reinterpret_cast<uintptr_t>(conn) & 7u) == 0;
-  if ((D == 64 || D == 128) && Vb <= kBwdMfmaMaxTypes && al16 && !getenv("IMPNN_MESSAGE_BWD_VALU")) {
+  // (from 64 K edge slots: below that every workgroup gets a single segment and the persistent kernel's prologue -
+  //  index chain, transposing matrix copy - costs more than its MFMAs save: 2.66 vs 2.17 ms per step at batch 32,
+  //  3.46 vs 3.26 ms at batch 256, 20.9 vs 27 ms at batch 4096, D = 128)
+  const char* force = getenv("IMPNN_MESSAGE_BWD");  // diagnostics: "valu" / "mfma"
+  const bool want_mfma = force ? force[0] == 'm' : BE >= 65536;
+  if ((D == 64 || D == 128) && Vb <= kBwdMfmaMaxTypes && al16 && want_mfma) {
     const size_t lm = sizeof(float) * ((size_t)D * (D + 4) + 2 * (size_t)kSeg * (D + 4)) + sizeof(int32_t) * (kSeg + 2 * (size_t)(Vb + 1));
     const int grid = (int)(max_segs < 256 ? max_segs : 256);
     if (D == 128) {
@@ -2460,7 +2479,7 @@ int launch_strided_gemm(const float* A, const float* B, float* out, int64_t rows
   ga.A1[0] = A; ga.A2[0] = A; ga.B[0] = B;
   const int tiles_n = (N + kGN - 1) / kGN, tiles_m = (M + kGM - 1) / kGM;
   strided_gemm_splitk_kernel<<<dim3(1, tiles_m * tiles_n, 1), kBlock, 0, s>>>(ga, out, rows, M, M, N, a_rs, a_cs, b_rs,
-                                                                              b_cs, 1, tiles_n);
+                                                                              b_cs, 1, tiles_n, nullptr);
   return check_launch("strided_gemm");
 }
 
@@ -2503,17 +2522,21 @@ int gated_update_bwd_blocks(int64_t rows, int D) { return gu_main_blocks(rows, D
 int64_t gated_update_param_floats(int D) { return 3 * ((int64_t)2 * D * D + D) + 2 * D; }
 
 // workspace (floats): dpre rows*3D | r*h rows*D | small nblk*5D | GEMM partials 3*nchunk*2D*D | W^T 3*2D*D
-int64_t gated_update_bwd_workspace(int64_t rows, int D) {
+// (row-list form: + compact copies of the rows' h and agg, rows*2D)
+int64_t gated_update_bwd_workspace(int64_t rows, int D, bool row_list) {
   return rows * 4 * D + (int64_t)gu_main_blocks(rows, D) * 5 * D + (int64_t)3 * gu_chunks(rows, D) * 2 * D * D +
-         (int64_t)3 * 2 * D * D;
+         (int64_t)3 * 2 * D * D + (row_list ? rows * 2 * D : 0);
 }
 
 int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
                             const float* br, const float* Wh, const float* bh, const float* gamma, float eps,
                             const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
-                            int64_t rows, int D, int accumulate, hipStream_t s) {
+                            int64_t rows, int D, int accumulate, hipStream_t s, const int32_t* ridx,
+                            const int32_t* nrows_dev) {
   if (D > kBlock || kBlock % D != 0)
     return fail(IMPNN_E_UNSUPPORTED, "gated_update_bwd: atom_dim %d must divide %d", D, kBlock);
+  if (ridx && D != 64 && D != 128)
+    return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_bwd: atom_dim %d (the row-list form covers 64 and 128)", D);
   const int R = kBlock / D;
   const int nblk = gu_main_blocks(rows, D), nchunk = gu_chunks(rows, D);
   float* dpre = workspace;
@@ -2521,14 +2544,17 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   float* small = rh + rows * D;
   float* gpart = small + (int64_t)nblk * 5 * D;
   float* wt = gpart + (int64_t)3 * nchunk * 2 * D * D;
+  float* hc = ridx ? wt + (int64_t)3 * 2 * D * D : nullptr;  // compact copies of the listed rows (row-list form)
+  float* aggc = ridx ? hc + rows * D : nullptr;
   size_t lds = sizeof(float) * ((size_t)10 * R * D + 4 * R);
   if (lds < sizeof(float) * 5 * kBlock) lds = sizeof(float) * 5 * kBlock;
   const size_t wlds = sizeof(float) * (size_t)3 * 2 * D * (D + 1);
   const bool al16 = ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(agg) | reinterpret_cast<uintptr_t>(dout) |
                       reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(dagg) |
                       reinterpret_cast<uintptr_t>(workspace)) & 15u) == 0;
+  if (ridx && !al16) return fail(IMPNN_E_BADARG, "gated_update_rows_bwd: tensors must be 16B aligned");
   if ((D == 64 || D == 128) && al16) {
-    const size_t lw = sizeof(float) * ((size_t)64 * (2 * D + 4) + 64 * (D + 4) + 2 * 16 * 2 * D + 4 * 256 + 4 * 5 * D);
+    const size_t lw = sizeof(float) * ((size_t)64 * (2 * D + 4) + 64 * (D + 4) + 2 * 16 * 2 * D + 4 * 256 + 4 * 5 * D) + 64 * sizeof(int32_t);
     const int64_t tiles64 = (rows + 63) / 64;
     const int nb = (int)(tiles64 < nblk ? tiles64 : nblk);  // `small` has nblk slices: unused ones must be zero
     // (zeroing is a kernel, not hipMemsetAsync: the call may sit inside a captured graph)
@@ -2538,12 +2564,12 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
       (void)hipFuncSetAttribute((const void*)gated_update_bwd_wide16_kernel<4>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
       gated_update_bwd_wide16_kernel<4><<<nb, 1024, lw, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, dagg,
-                                                            dpre, rh, small, rows);
+                                                            dpre, rh, small, rows, ridx, nrows_dev, hc, aggc);
     } else {
       (void)hipFuncSetAttribute((const void*)gated_update_bwd_wide16_kernel<8>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
       gated_update_bwd_wide16_kernel<8><<<nb, 1024, lw, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, dagg,
-                                                            dpre, rh, small, rows);
+                                                            dpre, rh, small, rows, ridx, nrows_dev, hc, aggc);
     }
   } else if (D == 32 && al16) {
     const size_t l32 = sizeof(float) * ((size_t)3 * 32 * kBwT + 3 * 64 * kBwN + 4 * 32 + 4 * 5 * 32);
@@ -2576,11 +2602,13 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   int tiles_n = 1;
   const int tiles = gu_tiles(D, &tiles_n);
   GemmProblems ga;
-  ga.A1[0] = h;  ga.A2[0] = agg; ga.B[0] = dpre;
-  ga.A1[1] = h;  ga.A2[1] = agg; ga.B[1] = dpre + D;
-  ga.A1[2] = rh; ga.A2[2] = agg; ga.B[2] = dpre + 2 * D;
+  const float* gh = ridx ? hc : h;      // the GEMMs contract over the listed rows: their compact copies
+  const float* ga_ = ridx ? aggc : agg;
+  ga.A1[0] = gh; ga.A2[0] = ga_; ga.B[0] = dpre;
+  ga.A1[1] = gh; ga.A2[1] = ga_; ga.B[1] = dpre + D;
+  ga.A1[2] = rh; ga.A2[2] = ga_; ga.B[2] = dpre + 2 * D;
   strided_gemm_splitk_kernel<<<dim3(nchunk, tiles, 3), kBlock, 0, s>>>(ga, gpart, rows, 2 * D, D, D, D, 1, 3 * D, 1,
-                                                                       nchunk, tiles_n);
+                                                                       nchunk, tiles_n, ridx ? nrows_dev : nullptr);
   if (int rc = check_launch("strided_gemm_splitk")) return rc;
   const int P = (int)gated_update_param_floats(D);
   gated_update_reduce_kernel<<<(P * 64 + kBlock - 1) / kBlock, kBlock, 0, s>>>(small, gpart, dparams, nblk, nchunk, D,

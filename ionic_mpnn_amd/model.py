@@ -30,6 +30,7 @@ INPUT_NAMES = ["cat_atom", "cat_bond", "cat_connectivity", "an_atom", "an_bond",
 # 4096; layered inference 7.7 -> 8.5 M pairs/s at 4096 and D=128 forward 9.8 -> 9.4 ms, but 1.12 -> 1.18 ms at batch
 # 8192 (config 3), where every kernel already fills the chip.  IMPNN_TWO_STREAM_MAX_BATCH=0 switches it off.
 TWO_STREAM_MAX_BATCH = 4096
+TRAIN_ROW_LIST_MIN_ROWS = int(os.environ.get("IMPNN_TRAIN_ROW_LIST_MIN_ROWS", 4096))
 
 
 class MPNNModel:
@@ -310,8 +311,11 @@ class MPNNModel:
         rows = None
         # (atom_dim 32 has the entry too, but there the three small launches that build the list cost what the skipped
         #  rows save: measured 8.1 vs 8.5 M pairs/s at batch 4096)
-        if (typed and trace is None and not self._builds_graph() and self.atom_dim in (64, 128)
-                and self.num_steps > 0):
+        if typed and trace is None and self.atom_dim in (64, 128) and self.num_steps > 0 and (
+                not self._builds_graph() or atom_ids.numel() >= TRAIN_ROW_LIST_MIN_ROWS):
+            # (training too, from TRAIN_ROW_LIST_MIN_ROWS atom rows per ion: the one-node step runs GatedUpdate forward
+            #  AND backward on the list, impnn_gated_update_rows_bwd - padding atoms carry no gradient; below that a
+            #  step is bound by its launch count and the list's own launches cost more than the skipped rows save)
             rows = ops.kept_row_index(atom_ids, bond_ids, conn, self.bond_vocab_size)
         for i in range(self.num_steps):
             if one_node:
@@ -320,7 +324,8 @@ class MPNNModel:
                 u, w = br["update"][i], br["update"][i]._weights
                 h = autograd.MessagePassingStep.apply(
                     h, bond.ids, conn, mats, w["dense_z/kernel"], w["dense_z/bias"], w["dense_r/kernel"],
-                    w["dense_r/bias"], w["dense_h/kernel"], w["dense_h/bias"], u.gamma, u.beta, u.epsilon)
+                    w["dense_r/bias"], w["dense_h/kernel"], w["dense_h/bias"], u.gamma, u.beta, u.epsilon,
+                    *(rows if rows is not None else (None, None)))
                 continue
             m = br["bmm"][i]([h, bond, conn])
             agg = br["reduce"][i]([m, conn[:, :, 1], h])

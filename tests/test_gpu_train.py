@@ -30,7 +30,9 @@ def rand_graph(B, N, E, Vb, rng):
 
 
 @pytest.mark.parametrize("D,K,B,E", [(8, 4, 5, 14), (32, 8, 5, 14), (64, 3, 5, 14), (128, 8, 40, 30), (64, 8, 90, 30)])
-def test_message_reduce_backward(D, K, B, E):
+def test_message_reduce_backward(D, K, B, E, monkeypatch):
+    if D >= 64 and B > 5:  # the matrix-core kernel (taken from 64 K edge slots on its own) against the fp64 oracle
+        monkeypatch.setenv("IMPNN_MESSAGE_BWD", "mfma")
     rng = np.random.default_rng(D)
     N, Vb = 9, 7
     conn, bond, _ = rand_graph(B, N, E, Vb, rng)
@@ -67,7 +69,7 @@ def test_message_reduce_backward(D, K, B, E):
 @pytest.mark.parametrize("D,Vb,from_agg", [(128, 12, True), (64, 72, True), (128, 3, False)])
 def test_message_backward_on_the_matrix_cores_equals_the_valu_kernel(D, Vb, from_agg):
     """Wide states take bmm_message_typed_bwd_mfma_kernel (csrc/train_kernels.hip): same gradients as the VALU kernel
-    (IMPNN_MESSAGE_BWD_VALU=1) on a batch whose type runs span several segments and several workgroup ranges - types
+    (IMPNN_MESSAGE_BWD=valu) on a batch whose type runs span several segments and several workgroup ranges - types
     change inside a workgroup's range, last segments of a type are partial.  (Both kernels add into dh / dA with
     float atomics: equal up to the order of f32 additions.)"""
     import os
@@ -92,12 +94,13 @@ def test_message_backward_on_the_matrix_cores_equals_the_valu_kernel(D, Vb, from
         torch.cuda.synchronize()
         return dh, dA
 
-    dh1, dA1 = run()
-    os.environ["IMPNN_MESSAGE_BWD_VALU"] = "1"
+    os.environ["IMPNN_MESSAGE_BWD"] = "mfma"
     try:
+        dh1, dA1 = run()
+        os.environ["IMPNN_MESSAGE_BWD"] = "valu"
         dh0, dA0 = run()
     finally:
-        del os.environ["IMPNN_MESSAGE_BWD_VALU"]
+        del os.environ["IMPNN_MESSAGE_BWD"]
     close(dh1, dh0.double().cpu(), 2e-6, "dh mfma vs valu")
     close(dA1, dA0.double().cpu(), 2e-6, "dA mfma vs valu")
 
@@ -163,6 +166,45 @@ def test_gated_update_backward(D, rows):
     og = ops.gated_update(hg, ag, *[pg[k] for k in names])
     (og * torch.tensor(go, dtype=torch.float32, device=DEV)).sum().backward()
     assert torch.equal(pg["Wz"].grad, g1)
+
+
+@pytest.mark.parametrize("D,rows,keep", [(128, 1000, 0.6), (64, 5000, 0.3), (128, 70, 1.0), (64, 64, 0.0)])
+def test_gated_update_backward_on_a_row_list(D, rows, keep):
+    """impnn_gated_update_rows_bwd (the adjoint of GatedUpdate on the kept rows of an encode() loop) against the fp64
+    oracle restricted to the listed rows: dh / dagg of the listed rows, parameter gradients = sums over them; rows
+    outside the list are left untouched (dh) and the count lives on the device."""
+    from ionic_mpnn_amd import autograd
+    rng = np.random.default_rng(D + rows)
+    names = ["Wz", "bz", "Wr", "br", "Wh", "bh", "gamma", "beta"]
+    vals = {"Wz": rng.normal(size=(2 * D, D)) / np.sqrt(2 * D), "Wr": rng.normal(size=(2 * D, D)) / np.sqrt(2 * D),
+            "Wh": rng.normal(size=(2 * D, D)) / np.sqrt(2 * D), "bz": rng.normal(size=D) * 0.1,
+            "br": rng.normal(size=D) * 0.1, "bh": rng.normal(size=D) * 0.1, "gamma": 1 + 0.1 * rng.normal(size=D),
+            "beta": 0.1 * rng.normal(size=D)}
+    h, agg, go = rng.normal(size=(rows, D)), rng.normal(size=(rows, D)), rng.normal(size=(rows, D))
+    sel = np.flatnonzero(rng.random(rows) < keep).astype(np.int32)
+    n = len(sel)
+    po = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in vals.items()}
+    ho, ao = (torch.tensor(a[sel], dtype=torch.float64, requires_grad=True) for a in (h, agg))
+    if n:
+        (TR.gated_update(ho, ao, po) * torch.tensor(go[sel])).sum().backward()
+    idx = torch.zeros(rows, dtype=torch.int32, device=DEV)
+    idx[:n] = torch.tensor(sel, device=DEV)
+    idx[n:] = -7                                  # entries past the count are never read
+    cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
+    f32 = lambda a: torch.tensor(a, dtype=torch.float32, device=DEV)
+    saved = (f32(h), f32(agg), *[f32(vals[k]) for k in names])
+    dh, dagg, *dp = autograd._gated_update_backward(saved, 1e-3, f32(go), (idx, cnt))[:10]
+    torch.cuda.synchronize()
+    if n:
+        close(dh[sel], ho.grad, what="dh of the listed rows")
+        close(dagg[sel], ao.grad, what="dagg of the listed rows")
+        for k, g in zip(names, dp):
+            close(g, po[k].grad, what=f"d{k}")
+    else:
+        for g in dp:
+            assert float(g.abs().max()) == 0.0
+    rest = np.setdiff1d(np.arange(rows), sel)
+    assert float(dh[rest].abs().max()) == 0.0 if len(rest) else True
 
 
 def test_embedding_and_pool_backward():
