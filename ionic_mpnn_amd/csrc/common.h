@@ -138,6 +138,7 @@ size_t encoder_prepared_bytes(int mode, int D, int S, int Vb);
 int launch_encoder_prepare(const float* weights, const float* bond_table, int D, int K, int S, int Vb, int mode,
                            void* prepared, hipStream_t s);
 int ensure_lds_limit(const void* kern, int slot);
+int device_compute_units();  // CUs of the current device (cached per device index)
 // ---- wide states (encoder_wide.hip: atom_dim 64 / 128 behind the same entries, mode 2)
 bool encoder_wide_supported(int N, int E, int D, int K, int S, int Vb);
 size_t encoder_wide_workspace_bytes(int n_ions, int B, int N, int E, int D, int S, int Vb);

@@ -537,7 +537,7 @@ bool encoder_fused_supported(int mode, int N, int E, int D, int K, int S, int Vb
 }
 
 // Compute units of the CURRENT device (cached per device index; the value never changes).
-static int compute_units() {
+int device_compute_units() {
   static std::atomic<int> cache[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -568,7 +568,7 @@ int ensure_lds_limit(const void* kern, int slot) {
 // multiple of that, so that a share never holds more molecules than plan_chunks resolves in LDS (the extra
 // workgroups simply run in rounds).  A pure function of its arguments and the environment: no library state.
 int encoder_workgroups(int n_ions, int B, int requested) {
-  int cus = compute_units();
+  int cus = device_compute_units();
   int want = requested;
   if (want <= 0) {
     const char* e = getenv("IMPNN_ENCODER_WORKGROUPS");

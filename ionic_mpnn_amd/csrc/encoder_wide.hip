@@ -26,6 +26,8 @@
 //
 // Every product is an exact f32 product on v_mfma_f32_16x16x4_f32; every sum has a fixed order that does not depend
 // on where a molecule sits in the batch, so results are bitwise reproducible and independent of sharding.
+#include <atomic>
+
 #include "common.h"
 
 namespace impnn {
@@ -958,11 +960,18 @@ int launch_encoder_wide_prepare(const float* weights, const float* bond_table, i
 }
 
 namespace {
-template <typename K>
+// Dynamic-LDS opt-in above 64 KB, once per (kernel, device).
+template <int SLOT, typename K>
 int raise_lds(K kern, size_t bytes) {
   if (bytes <= 64 * 1024) return IMPNN_OK;
-  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  static std::atomic<uint64_t> done{0};  // one instance per SLOT = per kernel instantiation
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  const uint64_t bit = 1ull << dev;
+  if (done.load(std::memory_order_acquire) & bit) return IMPNN_OK;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (e != hipSuccess) return fail(IMPNN_E_LAUNCH, "encoder_wide: cannot raise the LDS limit: %s", hipGetErrorString(e));
+  done.fetch_or(bit, std::memory_order_release);
   return IMPNN_OK;
 }
 }  // namespace
@@ -1010,17 +1019,17 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   if (a.n_ions == 1) img[1] = img[0];
   profile_record_start(s);
   wide_embed_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.rowbase), a.atom_table, F(w.h), a.D);
-  const int cus = 256;
+  const int cus = device_compute_units();  // persistent message workgroups: one per CU
   const size_t msg_lds = ((size_t)a.D * (a.D + 4) + 2 * (size_t)te * (a.D + 4)) * 4 + (size_t)(w.nT + 1) * 4;
   const int nt = a.D / 16;
   constexpr int R = kRT;
   const size_t gu_lds = gu_lds_floats(a.D) * 4;
   if (a.D == 128) {
-    if (int rc = raise_lds(wide_message_kernel<8, 64>, msg_lds)) return rc;
-    if (int rc = raise_lds(wide_update_kernel<8>, gu_lds)) return rc;
+    if (int rc = raise_lds<0>(wide_message_kernel<8, 64>, msg_lds)) return rc;
+    if (int rc = raise_lds<1>(wide_update_kernel<8>, gu_lds)) return rc;
   } else {
-    if (int rc = raise_lds(wide_message_kernel<4, 128>, msg_lds)) return rc;
-    if (int rc = raise_lds(wide_update_kernel<4>, gu_lds)) return rc;
+    if (int rc = raise_lds<2>(wide_message_kernel<4, 128>, msg_lds)) return rc;
+    if (int rc = raise_lds<3>(wide_update_kernel<4>, gu_lds)) return rc;
   }
   const int64_t red_threads = w.rmax * (a.D / 4);
   const int gu_grid = (int)(w.rmax / R);
