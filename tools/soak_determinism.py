@@ -14,14 +14,18 @@ from ionic_mpnn_amd import model, synthetic, weights  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=3000)
+ap.add_argument("--wide", action="store_true", help="the wide encoder (atom_dim 128 / 64) instead of the D = 32 ones")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 bad = 0
-for (B, S, mode, seed) in ((4096, 3, "f32t", 0), (4096, 3, "f32", 1), (1000, 4, "f32t", 2), (8192, 2, "f32t", 3),
-                           (4096, 3, "f16x2", 4)):
-    m = model.build_model(synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, num_steps=S, device=dev)
-    m.load_weights(weights.init_weights("viscosity", synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, num_steps=S, seed=seed,
-                                        perturb=True))
+cases = ((4096, 3, "f32t", 0, 32), (4096, 3, "f32", 1, 32), (1000, 4, "f32t", 2, 32), (8192, 2, "f32t", 3, 32),
+         (4096, 3, "f16x2", 4, 32))
+if a.wide:
+    cases = ((4096, 6, "f32t", 5, 128), (777, 3, "f32t", 6, 128), (2048, 2, "f32t", 7, 64))
+for (B, S, mode, seed, D) in cases:
+    m = model.build_model(synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, atom_dim=D, num_steps=S, device=dev)
+    m.load_weights(weights.init_weights("viscosity", synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, atom_dim=D, num_steps=S,
+                                        seed=seed, perturb=True))
     m.encoder_mode = mode
     d = {k: torch.from_numpy(v).to(dev) for k, v in synthetic.make_batch(B, seed=seed).items()}
     pc0, pa0 = [t.clone() for t in m.encode_pooled(d, fused=True)]
@@ -31,5 +35,5 @@ for (B, S, mode, seed) in ((4096, 3, "f32t", 0), (4096, 3, "f32", 1), (1000, 4, 
         mism += (pc != pc0).any().long() + (pa != pa0).any().long()
     n = int(mism.item())
     bad += n
-    print(f"B={B} S={S} mode={mode}: {a.iters} launches, {n} differing results, finite={bool(torch.isfinite(pc0).all())}")
+    print(f"B={B} S={S} D={D} mode={mode}: {a.iters} launches, {n} differing results, finite={bool(torch.isfinite(pc0).all())}")
 sys.exit(1 if bad else 0)
