@@ -732,10 +732,13 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
     const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
     const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float* __restrict__ out, int64_t rows,
-    const int32_t* __restrict__ ridx, const int32_t* __restrict__ nrows_dev) {
+    const int32_t* __restrict__ ridx, const int32_t* __restrict__ nrows_dev, int tile_rows) {
   // ridx / nrows_dev (optional): the kernel works on the rows ridx[0 .. *nrows_dev) of h / agg / out instead of on
   // rows [0, rows) - the model's layered path skips padding atoms this way (impnn_kept_row_index); the grid is
   // sized for `rows`, workgroups beyond the list leave at once.
+  // tile_rows = 64, or 16 when the launch has too few rows to fill the chip with 64-row tiles (the reference trains
+  // with 32 pairs per step: 1 280 rows = 20 tiles on 256 CUs): only the four waves of row tile 0 - one per SIMD -
+  // multiply then, the others just help moving the weight slices, and a tile's MFMA time drops 4x.
   if (nrows_dev) rows = *nrows_dev;
   constexpr int D = 16 * NT, LDC = 2 * D + 4, LDR = D + 4;
   constexpr int LDW = 2 * D;  // slice layout: element (input row 4*qq + r, column c) at ((qq * LDW + c) * 4 + r)
@@ -745,9 +748,10 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
   float* ws = rhs + 64 * LDR;       // 3 x 16 x LDW : slices of 16 input rows of the gate kernels, a ring of three
   constexpr int NL = NT / 4;  // feature tiles of this wave
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, a = lane & 15, q = lane >> 4;
-  const int wave = wv & 3, fg = wv >> 2;  // row tile, feature group
+  const int wave = wv >> 2, fg = wv & 3;  // row tile, feature group (the four waves of a row tile sit on four SIMDs)
+  const bool act = 16 * wave < tile_rows;  // (wave-uniform) does this wave own rows of the tile?
   float* part = ws + 3 * 16 * LDW;  // 2 x 4 x 64 row partials (sum, squared deviation) of LayerNorm
-  const int64_t row0 = (int64_t)blockIdx.x * 64;
+  const int64_t row0 = (int64_t)blockIdx.x * tile_rows;
   if (row0 >= rows) return;
   {  // the tile of [h | agg]: 16-byte loads, all of a thread's requests in flight before the first LDS store
     constexpr int kQ = 64 * (D / 4) / 1024;  // quads of h (and of agg) per thread
@@ -755,7 +759,7 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
 #pragma unroll
     for (int i = 0; i < kQ; ++i) {
       const int t = tid + 1024 * i, r = t / (D / 4), c4 = t - r * (D / 4);
-      const bool in = row0 + r < rows;
+      const bool in = row0 + r < rows && r < tile_rows;
       const int64_t src = in ? (ridx ? (int64_t)ridx[row0 + r] : row0 + r) : 0;
       hv[i] = in ? ldv4(h + src * D + 4 * c4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
       av[i] = in ? ldv4(agg + src * D + 4 * c4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -811,6 +815,7 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
     }
   };
   auto mma1 = [&](const Ops1& o) {
+    if (!act) return;
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL)
 #pragma unroll
@@ -848,14 +853,16 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
     __syncthreads();
   }
   // z, r -> sigmoid; r * h into LDS (every wave only touches its own 16 rows)
+  if (act) {
 #pragma unroll
-  for (int TL = 0; TL < NL; ++TL)
+    for (int TL = 0; TL < NL; ++TL)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int rl = 16 * wave + 4 * q + g, f = 16 * (fg * NL + TL) + a;
-      z[TL][g] = fsig(z[TL][g]);
-      rhs[rl * LDR + f] = fsig(rg[TL][g]) * cs[rl * LDC + f];
-    }
+      for (int g = 0; g < 4; ++g) {
+        const int rl = 16 * wave + 4 * q + g, f = 16 * (fg * NL + TL) + a;
+        z[TL][g] = fsig(z[TL][g]);
+        rhs[rl * LDR + f] = fsig(rg[TL][g]) * cs[rl * LDC + f];
+      }
+  }
   f32x4_t tt[NL];
 #pragma unroll
   for (int TL = 0; TL < NL; ++TL) {
@@ -884,6 +891,7 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
     for (int TL = 0; TL < NL; ++TL) o.bv[TL] = ldv4(cur + ((q * LDW + 16 * (fg * NL + TL) + a) << 2));
   };
   auto mma2 = [&](const Ops2& o) {
+    if (!act) return;
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL)
 #pragma unroll
@@ -916,41 +924,46 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
   }
   // blend, LayerNorm over the D features of each row (partials of the 4 feature groups meet in LDS), residual
   float sum[4] = {0.f, 0.f, 0.f, 0.f};
+  if (act) {
 #pragma unroll
-  for (int TL = 0; TL < NL; ++TL)
+    for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float hv = cs[(16 * wave + 4 * q + g) * LDC + 16 * (fg * NL + TL) + a];
+        const float n = (1.0f - z[TL][g]) * hv + z[TL][g] * ftanh(tt[TL][g]);
+        tt[TL][g] = n;
+        sum[g] += n;
+      }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float hv = cs[(16 * wave + 4 * q + g) * LDC + 16 * (fg * NL + TL) + a];
-      const float n = (1.0f - z[TL][g]) * hv + z[TL][g] * ftanh(tt[TL][g]);
-      tt[TL][g] = n;
-      sum[g] += n;
+      const float v = row16_sum_f(sum[g]);
+      if (a == 0) part[fg * 64 + 16 * wave + 4 * q + g] = v;
     }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float v = row16_sum_f(sum[g]);
-    if (a == 0) part[fg * 64 + 16 * wave + 4 * q + g] = v;
   }
   __syncthreads();
   float mean[4], inv[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int rl = 16 * wave + 4 * q + g;
-    mean[g] = ((part[rl] + part[64 + rl]) + (part[128 + rl] + part[192 + rl])) * (1.0f / D);
-  }
-  float var[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int TL = 0; TL < NL; ++TL)
+  if (act) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float d = tt[TL][g] - mean[g];
-      var[g] = fmaf(d, d, var[g]);
+      const int rl = 16 * wave + 4 * q + g;
+      mean[g] = ((part[rl] + part[64 + rl]) + (part[128 + rl] + part[192 + rl])) * (1.0f / D);
     }
+    float var[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float v = row16_sum_f(var[g]);
-    if (a == 0) part[256 + fg * 64 + 16 * wave + 4 * q + g] = v;
+    for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float d = tt[TL][g] - mean[g];
+        var[g] = fmaf(d, d, var[g]);
+      }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float v = row16_sum_f(var[g]);
+      if (a == 0) part[256 + fg * 64 + 16 * wave + 4 * q + g] = v;
+    }
   }
   __syncthreads();
+  if (!act) return;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const int rl = 256 + 16 * wave + 4 * q + g;
@@ -1343,6 +1356,9 @@ int launch_gated_update(const float* h, const float* agg, const float* Wz, const
   if (D % 16 == 0 && D >= 48 && D <= 128) {  // matrix cores; the kernels stream through LDS in 16-row slices
     const size_t lw = sizeof(float) * ((size_t)64 * (2 * D + 4) + 64 * (D + 4) + 2 * 16 * (2 * D));
     const unsigned blocks = (unsigned)((rows + 63) / 64);
+    // 16 waves / 64-row tiles fill the chip from ~8 K rows; below that 16-row tiles (four multiplying waves)
+    const int tile_rows = rows < 8192 ? 16 : 64;
+    const unsigned blocks16 = (unsigned)((rows + tile_rows - 1) / tile_rows);
 #define WIDE(NT_)                                                                                                  \
     do {                                                                                                            \
       if (lw > 48 * 1024)                                                                                           \
@@ -1357,8 +1373,8 @@ int launch_gated_update(const float* h, const float* agg, const float* Wz, const
       do {                                                                                                          \
         (void)hipFuncSetAttribute((const void*)gated_update_wide16_kernel<NT_>,                                     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)l16);                            \
-        gated_update_wide16_kernel<NT_><<<blocks, 1024, l16, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, out, \
-                                                                 rows, ridx, nrows_dev);                            \
+        gated_update_wide16_kernel<NT_><<<blocks16, 1024, l16, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, out, \
+                                                                   rows, ridx, nrows_dev, tile_rows);               \
         return check_launch("gated_update_wide16");                                                                 \
       } while (0)
       if (D == 64) WIDE16(4);

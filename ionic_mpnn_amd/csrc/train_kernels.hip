@@ -1302,7 +1302,9 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma, float eps,
     const float* __restrict__ dout, float* __restrict__ dh, float* __restrict__ dagg, float* __restrict__ dpre,
     float* __restrict__ rh_out, float* __restrict__ small, int64_t rows, const int32_t* __restrict__ ridx,
-    const int32_t* __restrict__ nrows_dev, float* __restrict__ hc, float* __restrict__ aggc) {
+    const int32_t* __restrict__ nrows_dev, float* __restrict__ hc, float* __restrict__ aggc, int tile_rows) {
+  // tile_rows = 64, or 16 for launches with too few rows to fill the chip with 64-row tiles (the reference trains with
+  // 32 pairs per step): then only the four waves of row tile 0 - one per SIMD - run the four GEMM passes.
   // ridx / nrows_dev (optional): the kernel works on the rows ridx[0 .. *nrows_dev) of h / agg / dout / dh / dagg
   // (impnn_gated_update_rows_bwd: the kept rows of an encode() loop); dpre, r*h and the copies hc / aggc of the rows'
   // inputs are written compactly (list position), which is what the weight-gradient GEMMs behind this kernel read.
@@ -1316,7 +1318,8 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
   float* red = part + 4 * 256;        // 4 row tiles x 5 x D column sums
   int32_t* grow_s = reinterpret_cast<int32_t*>(red + 4 * 5 * D);  // 64 global rows of the tile
   const int tid = threadIdx.x;
-  int a = tid & 15, q = (tid >> 4) & 3, rt = (tid >> 6) & 3, fg = tid >> 8;  // lane = 16 q + a, wave = 4 fg + rt
+  int a = tid & 15, q = (tid >> 4) & 3, fg = (tid >> 6) & 3, rt = tid >> 8;  // lane = 16 q + a, wave = 4 rt + fg: a row tile's four waves sit on four SIMDs
+  const bool act = 16 * (tid >> 8) < tile_rows;  // (wave-uniform) does this wave's row tile hold rows of the tile?
   constexpr int kPre = 16 * 2 * D / 1024;
   float pre[kPre];
   // (`opaque(tid)`: the slice addresses are recomputed where they are used - a few integer ops - instead of being
@@ -1332,7 +1335,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
   };
   auto relane = [&]() {  // same values, re-derived: every phase's element addresses start from here
     const int t_ = opaque0(threadIdx.x);
-    a = t_ & 15; q = (t_ >> 4) & 3; rt = (t_ >> 6) & 3; fg = t_ >> 8;
+    a = t_ & 15; q = (t_ >> 4) & 3; fg = (t_ >> 6) & 3; rt = t_ >> 8;
   };
   auto park = [&](float* dst, int ncols) {  // slice element t -> (k = t / ncols, column t % ncols)
     const int tid = opaque(threadIdx.x);
@@ -1354,10 +1357,10 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     }
   };
   float s_bz[NL] = {}, s_br[NL] = {}, s_bh[NL] = {}, s_dg[NL] = {}, s_db[NL] = {};
-  const int64_t ntile = (rows + 63) / 64;
+  const int64_t ntile = (rows + tile_rows - 1) / tile_rows;
   for (int64_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
-    const int64_t row0 = tile * 64;
-    const int nrt = (int)((rows - row0) < 64 ? (rows - row0) : 64);  // rows of this tile
+    const int64_t row0 = tile * tile_rows;
+    const int nrt = (int)((rows - row0) < tile_rows ? (rows - row0) : tile_rows);  // rows of this tile
     // per-tile base pointers (scalar) + 32-bit offsets: keeps the per-element addresses out of the register file
     float* rh_t = rh_out + row0 * D;
     float* dpre_t = dpre + row0 * 3 * D;
@@ -1402,6 +1405,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       float* cur = ws + (u & 1) * 16 * LDW;
       float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
       if (u + 1 < 2 * NT) fetch1(u + 1);
+      if (act) {
       const f32x4_t av = ldv4(crow + 16 * u);
 #pragma unroll
       for (int TL = 0; TL < NL; ++TL) {
@@ -1412,6 +1416,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
           z[TL] = mfma_f32(av[r], b0[r], z[TL]);
           rr[TL] = mfma_f32(av[r], b1[r], rr[TL]);
         }
+      }
       }
       if (u + 1 < 2 * NT) park(nxt, 2 * D);
       __syncthreads();
@@ -1458,12 +1463,14 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       float* cur = ws + (u & 1) * 16 * LDW;
       float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
       if (u + 1 < 2 * NT) fetch2(u + 1);
+      if (act) {
       const f32x4_t av = u < NT ? ldv4(rrow + 16 * u) : ldv4(crow + 16 * u);
 #pragma unroll
       for (int TL = 0; TL < NL; ++TL) {
         const f32x4_t bv = ldv4(cur + ((q * LDW + 16 * (fg * NL + TL) + a) << 2));
 #pragma unroll
         for (int r = 0; r < 4; ++r) tt[TL] = mfma_f32(av[r], bv[r], tt[TL]);
+      }
       }
       if (u + 1 < 2 * NT) park(nxt, D);
       __syncthreads();
@@ -1589,6 +1596,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       float* cur = ws + (u & 1) * 16 * LDW;
       float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
       if (u + 1 < NT) fetch3(u + 1);
+      if (act) {
       const f32x4_t av = ldv4(rrow + 16 * u);
 #pragma unroll
       for (int TL = 0; TL < NL; ++TL) {
@@ -1599,6 +1607,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
           lo[TL] = mfma_f32(av[r], b0[r], lo[TL]);
           hi[TL] = mfma_f32(av[r], b1[r], hi[TL]);
         }
+      }
       }
       if (u + 1 < NT) park_t(nxt);
       __syncthreads();
@@ -1649,6 +1658,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       float* cur = ws + (u & 1) * 16 * LDW;
       float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
       if (u + 1 < 2 * NT) fetch4(u + 1);
+      if (act) {
       const f32x4_t av = ldv4(crow + 16 * u);
 #pragma unroll
       for (int TL = 0; TL < NL; ++TL) {
@@ -1659,6 +1669,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
           lo[TL] = mfma_f32(av[r], b0[r], lo[TL]);
           hi[TL] = mfma_f32(av[r], b1[r], hi[TL]);
         }
+      }
       }
       if (u + 1 < 2 * NT) park_t(nxt);
       __syncthreads();
@@ -2555,7 +2566,8 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   if (ridx && !al16) return fail(IMPNN_E_BADARG, "gated_update_rows_bwd: tensors must be 16B aligned");
   if ((D == 64 || D == 128) && al16) {
     const size_t lw = sizeof(float) * ((size_t)64 * (2 * D + 4) + 64 * (D + 4) + 2 * 16 * 2 * D + 4 * 256 + 4 * 5 * D) + 64 * sizeof(int32_t);
-    const int64_t tiles64 = (rows + 63) / 64;
+    const int tile_rows = rows < 8192 ? 16 : 64;  // (as the forward kernel: 16-row tiles below ~8 K rows)
+    const int64_t tiles64 = (rows + tile_rows - 1) / tile_rows;
     const int nb = (int)(tiles64 < nblk ? tiles64 : nblk);  // `small` has nblk slices: unused ones must be zero
     // (zeroing is a kernel, not hipMemsetAsync: the call may sit inside a captured graph)
     zero_floats_kernel<<<grid_for((int64_t)nblk * 5 * D), kBlock, 0, s>>>(small, (int64_t)nblk * 5 * D);
@@ -2564,12 +2576,12 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
       (void)hipFuncSetAttribute((const void*)gated_update_bwd_wide16_kernel<4>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
       gated_update_bwd_wide16_kernel<4><<<nb, 1024, lw, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, dagg,
-                                                            dpre, rh, small, rows, ridx, nrows_dev, hc, aggc);
+                                                            dpre, rh, small, rows, ridx, nrows_dev, hc, aggc, tile_rows);
     } else {
       (void)hipFuncSetAttribute((const void*)gated_update_bwd_wide16_kernel<8>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
       gated_update_bwd_wide16_kernel<8><<<nb, 1024, lw, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, dagg,
-                                                            dpre, rh, small, rows, ridx, nrows_dev, hc, aggc);
+                                                            dpre, rh, small, rows, ridx, nrows_dev, hc, aggc, tile_rows);
     }
   } else if (D == 32 && al16) {
     const size_t l32 = sizeof(float) * ((size_t)3 * 32 * kBwT + 3 * 64 * kBwN + 4 * 32 + 4 * 5 * 32);

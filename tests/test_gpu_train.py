@@ -137,7 +137,7 @@ def test_type_matrices_of_all_layers_in_one_node(D, K, n, sinks):
         close(a.grad, b.grad, 1e-6, "dW")
 
 
-@pytest.mark.parametrize("D,rows", [(8, 37), (32, 301), (32, 70001), (64, 1500), (128, 19)])
+@pytest.mark.parametrize("D,rows", [(8, 37), (32, 301), (32, 70001), (64, 1500), (128, 19), (128, 1280), (128, 9000), (64, 8300)])
 def test_gated_update_backward(D, rows):
     rng = np.random.default_rng(D + 1)
     names = ["Wz", "bz", "Wr", "br", "Wh", "bh", "gamma", "beta"]
@@ -168,7 +168,7 @@ def test_gated_update_backward(D, rows):
     assert torch.equal(pg["Wz"].grad, g1)
 
 
-@pytest.mark.parametrize("D,rows,keep", [(128, 1000, 0.6), (64, 5000, 0.3), (128, 70, 1.0), (64, 64, 0.0)])
+@pytest.mark.parametrize("D,rows,keep", [(128, 1000, 0.6), (64, 5000, 0.3), (128, 70, 1.0), (64, 64, 0.0), (128, 12000, 0.7)])
 def test_gated_update_backward_on_a_row_list(D, rows, keep):
     """impnn_gated_update_rows_bwd (the adjoint of GatedUpdate on the kept rows of an encode() loop) against the fp64
     oracle restricted to the listed rows: dh / dagg of the listed rows, parameter gradients = sums over them; rows
