@@ -1861,45 +1861,60 @@ __global__ __launch_bounds__(kBlock) void strided_gemm_splitk_kernel(GemmProblem
 // dparams = fixed-order sums of the partials (canonical layout, see above).  One wave per output: lane l adds
 // partials l, l+64, ... in order, then a fixed butterfly - the same association on every run.
 __global__ void gated_update_reduce_kernel(const float* __restrict__ small, const float* __restrict__ gpart,
-                                           float* __restrict__ dparams, int nblk, int nchunk, int D, int accumulate) {
+                                           float* __restrict__ dparams, int nblk, int nchunk, int D, int accumulate,
+                                           int wblocks) {
   const int DD2 = 2 * D * D;
-  const int P = 3 * (DD2 + D) + 2 * D;
-  const int q = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (q >= P) return;
-  const float* src;
-  int64_t stride;
-  int n;
-  if (q < 3 * (DD2 + D)) {
-    const int gate = q / (DD2 + D), off = q - gate * (DD2 + D);
-    if (off < DD2) {
-      src = gpart + (int64_t)gate * nchunk * DD2 + off;
-      stride = DD2;
-      n = nchunk;
-    } else {
-      src = small + gate * D + (off - DD2);  // bias of the gate: column sums of dpre_gate
-      stride = 5 * D;
-      n = nblk;
+  if ((int)blockIdx.x < wblocks) {
+    // the three kernel gradients.  Few chunk partials (wide states: <= 22): one THREAD per element, the partials added
+    // in chunk order, consecutive threads on consecutive addresses (one wave per element read its 20 partials 128 KB
+    // apart: 27 us per call for 8 MB).  Many partials (atom_dim 32 at large batches: 342): one wave per element.
+    if (nchunk <= 32) {
+      const int t = blockIdx.x * blockDim.x + threadIdx.x;
+      if (t >= 3 * DD2) return;
+      const int gate = t / DD2, off = t - gate * DD2;
+      const float* src = gpart + (int64_t)gate * nchunk * DD2 + off;
+      float acc = 0.f;
+      for (int c = 0; c < nchunk; ++c) acc += src[(int64_t)c * DD2];
+      const int q = gate * (DD2 + D) + off;
+      dparams[q] = accumulate ? dparams[q] + acc : acc;
+      return;
     }
-  } else {
-    src = small + 3 * D + (q - 3 * (DD2 + D));  // gamma (0..D), beta (D..2D)
-    stride = 5 * D;
-    n = nblk;
+    const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (t >= 3 * DD2) return;
+    const int gate = t / DD2, off = t - gate * DD2;
+    const float* src = gpart + (int64_t)gate * nchunk * DD2 + off;
+    float acc = 0.f;
+    for (int c = lane; c < nchunk; c += 64) acc += src[(int64_t)c * DD2];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    const int q = gate * (DD2 + D) + off;
+    if (lane == 0) dparams[q] = accumulate ? dparams[q] + acc : acc;
+    return;
   }
+  // the five vectors (bz, br, bh, gamma, beta): one wave per element over the nblk per-workgroup column sums
+  const int e = (((int)blockIdx.x - wblocks) * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (e >= 5 * D) return;
+  const int q = e < 3 * D ? (e / D) * (DD2 + D) + DD2 + (e % D) : 3 * (DD2 + D) + (e - 3 * D);
+  const float* src = small + e;
   float acc = 0.f;
-  for (int c = lane; c < n; c += 64) acc += src[(int64_t)c * stride];
+  for (int c = lane; c < nblk; c += 64) acc += src[(int64_t)c * 5 * D];
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if (lane == 0) dparams[q] = accumulate ? dparams[q] + acc : acc;
 }
 
 // ---------------------------------------------------------------------------------------
 // Optimizer step: keras.optimizers.Adam(lr, clipnorm) as the trainers configure it
-// (train_viscosity.py:227-230).  One workgroup per variable:
+// (train_viscosity.py:227-230).  kAdamSplit workgroups per variable: each forms the variable's gradient norm itself
+// (the same thread-strided sum in the same order in every workgroup, so all of them scale by the identical factor - no
+// partials buffer, no second launch) and updates its own 1/kAdamSplit of the elements; with one workgroup per variable
+// the step took as long as one workgroup needs for the largest variable (172 us at atom_dim 128: bond_transform, 131 K
+// floats through one workgroup's 20 GB/s):
 //   g <- g * clipnorm / max(||g||_2, clipnorm)          (tf.clip_by_norm, per variable; clipnorm <= 0: off)
 //   m <- b1 m + (1-b1) g;  v <- b2 v + (1-b2) g^2
 //   w <- w - lr * sqrt(1-b2^t)/(1-b1^t) * m / (sqrt(v) + eps)
 // The variable table holds device pointers: 4 per variable (w, g, m, v) and the element count.
 // ---------------------------------------------------------------------------------------
 __global__ void incr_step_kernel(long long* step) { *step += 1; }
+constexpr int kAdamSplit = 16;
 
 __global__ __launch_bounds__(1024) void adam_clipnorm_kernel(const unsigned long long* __restrict__ table,
                                                              const long long* __restrict__ sizes, float lr,
@@ -1919,6 +1934,7 @@ __global__ __launch_bounds__(1024) void adam_clipnorm_kernel(const unsigned long
   float* m = reinterpret_cast<float*>(table[4 * var + 2]);
   float* v = reinterpret_cast<float*>(table[4 * var + 3]);
   const long long n = sizes[var];
+  if ((long long)blockIdx.y * 4096 >= n && blockIdx.y > 0) return;  // no elements for this workgroup
   float ss = 0.f;
   for (long long t = threadIdx.x; t < n; t += blockDim.x) ss = fmaf(g[t], g[t], ss);
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o);
@@ -1933,7 +1949,10 @@ __global__ __launch_bounds__(1024) void adam_clipnorm_kernel(const unsigned long
   __syncthreads();
   const float sc = scale_s;
   const float alpha = lr * sqrtf(corr2) / corr1;  // corr1 = 1 - b1^t, corr2 = 1 - b2^t
-  for (long long t = threadIdx.x; t < n; t += blockDim.x) {
+  long long per = (n + gridDim.y - 1) / gridDim.y;
+  if (per < 4096) per = 4096;  // small variables stay with their first workgroup(s)
+  const long long lo = (long long)blockIdx.y * per, hi = lo + per < n ? lo + per : n;
+  for (long long t = lo + threadIdx.x; t < hi; t += blockDim.x) {
     const float gg = g[t] * sc;
     const float mm = b1 * m[t] + (1.0f - b1) * gg;
     const float vv = b2 * v[t] + (1.0f - b2) * gg * gg;
@@ -2511,7 +2530,8 @@ int launch_bond_type_matrices_bwd(const float* tb, const float* W, const float* 
 }
 
 static int gu_main_blocks(int64_t rows, int D) {
-  const int R = kBlock / D;
+  // tiles of the main kernel: kBlock / D rows (generic kernels), 16 or 64 rows (the wide matrix-core kernel)
+  const int R = (D == 64 || D == 128) ? (rows < 8192 ? 16 : 64) : kBlock / D;
   const int64_t ntile = (rows + R - 1) / R;
   return (int)(ntile < 1024 ? (ntile < 1 ? 1 : ntile) : 1024);
 }
@@ -2523,7 +2543,7 @@ static int gu_tiles(int D, int* tiles_n) {
 static int gu_chunks(int64_t rows, int D) {
   const int tiles = gu_tiles(D, nullptr);
   int64_t want = (1024 + 3 * tiles - 1) / (3 * tiles);
-  const int64_t cap = (rows + 63) / 64;
+  const int64_t cap = (rows + 255) / 256;  // at least 256 contraction rows per chunk: fewer partials to write and add
   if (want > cap) want = cap;
   return (int)(want < 1 ? 1 : want);
 }
@@ -2622,9 +2642,10 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   strided_gemm_splitk_kernel<<<dim3(nchunk, tiles, 3), kBlock, 0, s>>>(ga, gpart, rows, 2 * D, D, D, D, 1, 3 * D, 1,
                                                                        nchunk, tiles_n, ridx ? nrows_dev : nullptr);
   if (int rc = check_launch("strided_gemm_splitk")) return rc;
-  const int P = (int)gated_update_param_floats(D);
-  gated_update_reduce_kernel<<<(P * 64 + kBlock - 1) / kBlock, kBlock, 0, s>>>(small, gpart, dparams, nblk, nchunk, D,
-                                                                            accumulate);
+  const int64_t welems = (int64_t)3 * 2 * D * D * (nchunk <= 32 ? 1 : 64);  // a thread or a wave per kernel element
+  const int wblocks = (int)((welems + kBlock - 1) / kBlock), vblocks = (5 * D * 64 + kBlock - 1) / kBlock;
+  gated_update_reduce_kernel<<<wblocks + vblocks, kBlock, 0, s>>>(small, gpart, dparams, nblk, nchunk, D, accumulate,
+                                                                 wblocks);
   return check_launch("gated_update_reduce");
 }
 
@@ -2638,7 +2659,7 @@ int launch_adam_clipnorm(const void* table, const void* sizes, int n_vars, int64
     corr1 = 1.0f - powf(b1, (float)step);
     corr2 = 1.0f - powf(b2, (float)step);
   }
-  adam_clipnorm_kernel<<<n_vars, 1024, 0, s>>>(static_cast<const unsigned long long*>(table),
+  adam_clipnorm_kernel<<<dim3(n_vars, kAdamSplit), 1024, 0, s>>>(static_cast<const unsigned long long*>(table),
                                                static_cast<const long long*>(sizes), lr, b1, b2, eps, clipnorm,
                                                corr1, corr2, reinterpret_cast<const long long*>(step_dev));
   return check_launch("adam_clipnorm");
