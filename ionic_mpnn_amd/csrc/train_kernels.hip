@@ -334,7 +334,11 @@ template <int NT>
 __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
     const float* __restrict__ h, const int32_t* __restrict__ conn, const float* __restrict__ A,
     const float* __restrict__ dm, float* __restrict__ dh, float* __restrict__ dA, const int32_t* __restrict__ start,
-    const int32_t* __restrict__ segbase, const int32_t* __restrict__ order, int N, int E, int Vb, int from_agg) {
+    const int32_t* __restrict__ segbase, const int32_t* __restrict__ order, int N, int E, int Vb, int from_agg,
+    int owner_mode) {
+  // owner_mode (small batches): workgroup t takes ALL segments of bond type t and is the only one that touches dA_t,
+  // which it updates with plain loads / adds / stores - flushing 64 KB of accumulators with float atomics after a
+  // single segment costs ~50 us per workgroup (one 256-byte atomic wave-instruction per ~50 ns and CU).
   constexpr int D = 16 * NT, LD = D + 4, QD = D / 4, NLW = NT / 4, TI = NT / 4;
   constexpr int kX = kSeg * QD / 1024;  // 16-byte pieces of an edge tile per thread
   constexpr int kB = D * QD / 1024;     // ... of the matrix
@@ -349,7 +353,12 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = lane & 15, q = lane >> 4;
   const int nseg = segbase[Vb];
   const int per = (nseg + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int s0 = blockIdx.x * per, s1 = s0 + per < nseg ? s0 + per : nseg;
+  int s0 = blockIdx.x * per, s1 = s0 + per < nseg ? s0 + per : nseg;
+  if (owner_mode) {
+    if ((int)blockIdx.x >= Vb) return;
+    s0 = segbase[blockIdx.x];
+    s1 = segbase[blockIdx.x + 1];
+  }
   if (s0 >= s1) return;
   for (int t = tid; t <= Vb; t += 1024) {
     sb_s[t] = segbase[t];
@@ -390,7 +399,10 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
     for (int i = 0; i < kX; ++i) {
       const int e = (tid + 1024 * i) / QD;
       ok[i] = e < d.n;
-      be[i] = order[d.p0 + min(e, d.n - 1)];
+      // (slots past the segment's edges borrow the rows of its real edges in turn: their zero sums are then spread
+      //  over the segment's source rows - all of them on the LAST edge's row made 46 of 64 slots contend for one
+      //  row at the reference's batch of 32: 99 vs 15 us per call)
+      be[i] = order[d.p0 + (e < d.n ? e : e % d.n)];
     }
   };
   auto stage_b = [&](const int* be, int* hrow, int* grow) {
@@ -421,6 +433,9 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
     }
   };
   auto load_matrix = [&](int ty) {  // transposing copy: lanes run along i (conflict-free LDS stores)
+#ifdef IMPNN_DIAG_BWD_NOMATRIX
+    return;
+#endif
     const float* At = A + (int64_t)ty * D * D;
 #pragma unroll
     for (int i2 = 0; i2 < kB; ++i2) {
@@ -467,14 +482,20 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
 #pragma unroll
     for (int y = 0; y < TI; ++y) acc2[x][y] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   auto flush_dA = [&](int ty) {
+#ifdef IMPNN_DIAG_BWD_NOFLUSH
+    return;
+#endif
     float* dst = dA + (int64_t)ty * D * D;
 #pragma unroll
     for (int x = 0; x < TI; ++x)
 #pragma unroll
       for (int y = 0; y < TI; ++y) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          atomicAdd(dst + (16 * (wi * TI + x) + 4 * q + g) * D + 16 * (wj * TI + y) + a, acc2[x][y][g]);
+        for (int g = 0; g < 4; ++g) {
+          float* pd = dst + (16 * (wi * TI + x) + 4 * q + g) * D + 16 * (wj * TI + y) + a;
+          if (owner_mode) *pd += acc2[x][y][g];
+          else atomicAdd(pd, acc2[x][y][g]);
+        }
         acc2[x][y] = f32x4_t{0.f, 0.f, 0.f, 0.f};
       }
   };
@@ -515,14 +536,16 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
 #pragma unroll
           for (int TL = 0; TL < NLW; ++TL) acc1[TL] = mfma_f32(av[TL][r], gv[r], acc1[TL]);
       }
-      // (unconditional: rows past the segment's edges are zero in G, so their sums are exact zeros added to the row
-      //  of the segment's last edge - a conditional atomic would keep the compiler from counting outstanding
+      // (unconditional: rows past the segment's edges are zero in G, so their sums are exact zeros added to rows of
+      //  the segment's real edges - a conditional atomic would keep the compiler from counting outstanding
       //  memory operations, and the LDS stores below would wait for every atomic of the tile)
       float* dst = dh + (int64_t)hrow_s[16 * et + a] * D + 16 * (fg * NLW) + 4 * q;
+#ifndef IMPNN_DIAG_BWD_NODH
 #pragma unroll
       for (int TL = 0; TL < NLW; ++TL)
 #pragma unroll
         for (int g = 0; g < 4; ++g) atomicAdd(dst + 16 * TL + g, acc1[TL][g]);
+#endif
     }
     // ---- GEMM 2: dA_t += G^T X over the segment's edges (k = edge)
 #pragma unroll 4
@@ -1936,7 +1959,19 @@ __global__ __launch_bounds__(1024) void adam_clipnorm_kernel(const unsigned long
   const long long n = sizes[var];
   if ((long long)blockIdx.y * 4096 >= n && blockIdx.y > 0) return;  // no elements for this workgroup
   float ss = 0.f;
-  for (long long t = threadIdx.x; t < n; t += blockDim.x) ss = fmaf(g[t], g[t], ss);
+  if ((reinterpret_cast<uintptr_t>(g) & 15u) == 0) {  // 16-byte loads (every workgroup of the variable takes this path or none)
+    const long long n4 = n >> 2;
+    for (long long t = threadIdx.x; t < n4; t += blockDim.x) {
+      const f32x4_t x = ldv4(g + 4 * t);
+      ss = fmaf(x[0], x[0], ss);
+      ss = fmaf(x[1], x[1], ss);
+      ss = fmaf(x[2], x[2], ss);
+      ss = fmaf(x[3], x[3], ss);
+    }
+    for (long long t = 4 * n4 + threadIdx.x; t < n; t += blockDim.x) ss = fmaf(g[t], g[t], ss);
+  } else {
+    for (long long t = threadIdx.x; t < n; t += blockDim.x) ss = fmaf(g[t], g[t], ss);
+  }
   for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
   __syncthreads();
@@ -2465,20 +2500,20 @@ int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const 
   const int64_t max_segs = (BE + kSeg - 1) / kSeg + Vb;
   const bool al16 = ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(dm)) & 15u) == 0 &&
                     (reinterpret_cast<uintptr_t>(conn) & 7u) == 0;
-  // (from 64 K edge slots: below that every workgroup gets a single segment and the persistent kernel's prologue -
-  //  index chain, transposing matrix copy - costs more than its MFMAs save: 2.66 vs 2.17 ms per step at batch 32,
-  //  3.46 vs 3.26 ms at batch 256, 20.9 vs 27 ms at batch 4096, D = 128)
   const char* force = getenv("IMPNN_MESSAGE_BWD");  // diagnostics: "valu" / "mfma"
-  const bool want_mfma = force ? force[0] == 'm' : BE >= 65536;
+  const bool want_mfma = force ? force[0] == 'm' : true;
   if ((D == 64 || D == 128) && Vb <= kBwdMfmaMaxTypes && al16 && want_mfma) {
     const size_t lm = sizeof(float) * ((size_t)D * (D + 4) + 2 * (size_t)kSeg * (D + 4)) + sizeof(int32_t) * (kSeg + 2 * (size_t)(Vb + 1));
-    const int grid = (int)(max_segs < 256 ? max_segs : 256);
+    // one workgroup per type without atomics on dA ("mo", diagnostics) was never faster than balanced segment ranges:
+    // 26.8 vs 26.1 us per call at batch 32, 423 vs 331 us at batch 4096 (VALU kernel: 41.7 / 887 us)
+    const int owner = force && force[1] == 'o' ? 1 : 0;
+    const int grid = owner ? Vb : (int)(max_segs < 256 ? max_segs : 256);
     if (D == 128) {
       (void)hipFuncSetAttribute((const void*)bmm_message_typed_bwd_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
-      bmm_message_typed_bwd_mfma_kernel<8><<<grid, 1024, lm, s>>>(h, conn, A, dm, dh, dA, start, segbase, order, N, E, Vb, from_agg);
+      bmm_message_typed_bwd_mfma_kernel<8><<<grid, 1024, lm, s>>>(h, conn, A, dm, dh, dA, start, segbase, order, N, E, Vb, from_agg, owner);
     } else {
       (void)hipFuncSetAttribute((const void*)bmm_message_typed_bwd_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
-      bmm_message_typed_bwd_mfma_kernel<4><<<grid, 1024, lm, s>>>(h, conn, A, dm, dh, dA, start, segbase, order, N, E, Vb, from_agg);
+      bmm_message_typed_bwd_mfma_kernel<4><<<grid, 1024, lm, s>>>(h, conn, A, dm, dh, dA, start, segbase, order, N, E, Vb, from_agg, owner);
     }
     return check_launch("bmm_message_typed_bwd (mfma)");
   }

@@ -30,9 +30,7 @@ def rand_graph(B, N, E, Vb, rng):
 
 
 @pytest.mark.parametrize("D,K,B,E", [(8, 4, 5, 14), (32, 8, 5, 14), (64, 3, 5, 14), (128, 8, 40, 30), (64, 8, 90, 30)])
-def test_message_reduce_backward(D, K, B, E, monkeypatch):
-    if D >= 64 and B > 5:  # the matrix-core kernel (taken from 64 K edge slots on its own) against the fp64 oracle
-        monkeypatch.setenv("IMPNN_MESSAGE_BWD", "mfma")
+def test_message_reduce_backward(D, K, B, E):
     rng = np.random.default_rng(D)
     N, Vb = 9, 7
     conn, bond, _ = rand_graph(B, N, E, Vb, rng)
@@ -66,8 +64,8 @@ def test_message_reduce_backward(D, K, B, E, monkeypatch):
     close(tbf.grad, tbo.grad, what="dbond_table (one node)")
 
 
-@pytest.mark.parametrize("D,Vb,from_agg", [(128, 12, True), (64, 72, True), (128, 3, False)])
-def test_message_backward_on_the_matrix_cores_equals_the_valu_kernel(D, Vb, from_agg):
+@pytest.mark.parametrize("D,Vb,from_agg,B", [(128, 12, True, 700), (64, 72, True, 700), (128, 3, False, 700), (128, 72, True, 32), (64, 9, True, 200)])
+def test_message_backward_on_the_matrix_cores_equals_the_valu_kernel(D, Vb, from_agg, B):
     """Wide states take bmm_message_typed_bwd_mfma_kernel (csrc/train_kernels.hip): same gradients as the VALU kernel
     (IMPNN_MESSAGE_BWD=valu) on a batch whose type runs span several segments and several workgroup ranges - types
     change inside a workgroup's range, last segments of a type are partial.  (Both kernels add into dh / dA with
@@ -75,7 +73,7 @@ def test_message_backward_on_the_matrix_cores_equals_the_valu_kernel(D, Vb, from
     import os
     from ionic_mpnn_amd import _lib
     rng = np.random.default_rng(D + Vb)
-    B, N, E = 700, 40, 80
+    N, E = 40, 80
     conn, bond, _ = rand_graph(B, N, E, Vb, rng)
     h = torch.tensor(rng.normal(size=(B, N, D)), dtype=torch.float32, device=DEV)
     mats = torch.tensor(rng.normal(size=(Vb, D, D)) / np.sqrt(D), dtype=torch.float32, device=DEV)
@@ -101,8 +99,8 @@ def test_message_backward_on_the_matrix_cores_equals_the_valu_kernel(D, Vb, from
         dh0, dA0 = run()
     finally:
         del os.environ["IMPNN_MESSAGE_BWD"]
-    close(dh1, dh0.double().cpu(), 2e-6, "dh mfma vs valu")
-    close(dA1, dA0.double().cpu(), 2e-6, "dA mfma vs valu")
+    close(dh1, dh0.double().cpu(), 5e-6, "dh mfma vs valu")
+    close(dA1, dA0.double().cpu(), 5e-6, "dA mfma vs valu")
 
 
 @pytest.mark.parametrize("D,K,n,sinks", [(32, 8, 6, True), (8, 4, 3, False), (16, 5, 18, True)])
