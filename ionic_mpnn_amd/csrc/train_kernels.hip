@@ -1897,7 +1897,15 @@ __global__ void gated_update_reduce_kernel(const float* __restrict__ small, cons
       const int gate = t / DD2, off = t - gate * DD2;
       const float* src = gpart + (int64_t)gate * nchunk * DD2 + off;
       float acc = 0.f;
-      for (int c = 0; c < nchunk; ++c) acc += src[(int64_t)c * DD2];
+      int c = 0;
+      for (; c + 8 <= nchunk; c += 8) {  // 8 partials in flight, added in chunk order
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = src[(int64_t)(c + u) * DD2];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += x[u];
+      }
+      for (; c < nchunk; ++c) acc += src[(int64_t)c * DD2];
       const int q = gate * (DD2 + D) + off;
       dparams[q] = accumulate ? dparams[q] + acc : acc;
       return;
