@@ -103,7 +103,8 @@ def test_message_backward_on_the_matrix_cores_equals_the_valu_kernel(D, Vb, from
     close(dA1, dA0.double().cpu(), 5e-6, "dA mfma vs valu")
 
 
-@pytest.mark.parametrize("D,K,n,sinks", [(32, 8, 6, True), (8, 4, 3, False), (16, 5, 18, True)])
+@pytest.mark.parametrize("D,K,n,sinks", [(32, 8, 6, True), (8, 4, 3, False), (16, 5, 18, True), (64, 8, 3, True),
+                                         (128, 8, 12, False), (32, 12, 4, True)])
 def test_type_matrices_of_all_layers_in_one_node(D, K, n, sinks):
     """impnn_bond_type_matrices_multi[_bwd] against the per-layer entries: bitwise equal A_p, gradients equal to the
     per-layer sums (more than 16 layers take a second launch)."""
