@@ -56,3 +56,9 @@ inp = synthetic.make_batch(5, max_atoms=10, max_edges=20, atom_vocab_size=15, bo
 w = weights.init_weights("melting_point", 15, 7, atom_dim=8, bond_dim=64, fp_size=8, mixing_size=6, num_steps=2,
                          seed=22, perturb=True)
 save_case("tiny_melting_point", "melting_point", inp, w)
+
+# wide atom states (train_viscosity.py with a larger atom_dim; the config-5 family): atom_dim 64, 2 steps, small graphs
+inp = synthetic.make_batch(5, max_atoms=14, max_edges=28, atom_vocab_size=17, bond_vocab_size=6, min_atoms=3, seed=31)
+w = weights.init_weights("viscosity", 17, 6, atom_dim=64, bond_dim=8, fp_size=16, mixing_size=10, num_steps=2, seed=32,
+                         perturb=True)
+save_case("wide_d64_b5", "viscosity", inp, w)

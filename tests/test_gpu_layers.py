@@ -22,7 +22,7 @@ def f32(a):
     return np.asarray(a, dtype=np.float32)
 
 
-CASES = ["tiny_viscosity", "config2_b8", "config2_perturbed_b6", "tiny_melting_point"]
+CASES = ["tiny_viscosity", "config2_b8", "config2_perturbed_b6", "tiny_melting_point", "wide_d64_b5"]
 
 
 @pytest.mark.parametrize("name", CASES)

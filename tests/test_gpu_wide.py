@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_close
+from conftest import assert_close, load_case
 from ionic_mpnn_amd import model as MM
 from ionic_mpnn_amd import ops, synthetic, weights
 from oracle import mpnn_oracle as O
@@ -177,3 +177,21 @@ def test_wide_pipelined_plan_run_matches_single_call(wide_full):
     plan = m.plan_batch(d)
     c, a = m.encode_pooled(d, plan=plan)
     assert torch.equal(c, pc) and torch.equal(a, pa)
+
+
+def test_wide_encoder_vs_golden():
+    """tests/golden/wide_d64_b5.npz (atom_dim 64, 2 steps; frozen oracle vectors): the wide encoder's pooled states and
+    log_eta, and the layer-at-a-time kernels' per-layer tensors of the same model."""
+    _, inp, w, outs = load_case("wide_d64_b5")
+    m = MM.build_model(17, 6, atom_dim=64, bond_dim=8, fp_size=16, mixing_size=10, num_steps=2, device=DEV)
+    m.load_weights(w)
+    assert m.resolve_encoder_mode(14, 28) == "f32t"
+    pc, pa = m.encode_pooled(to_dev(inp), fused=True)
+    assert_close(pc.cpu().numpy(), outs["cat/pooled"], what="cat pooled")
+    assert_close(pa.cpu().numpy(), outs["an/pooled"], what="an pooled")
+    assert_close(m(inp, fused=True).cpu().numpy(), outs["final"], what="log_eta")
+    tr = {}
+    yl = m(inp, fused=False, trace=tr).cpu().numpy()
+    assert_close(yl, outs["final"], what="log_eta layered")
+    for k in ("cat/m0", "cat/agg1", "an/h2", "an/pooled", "cat/fp", "mixed"):
+        assert_close(tr[k].cpu().numpy(), outs[k], what=k)

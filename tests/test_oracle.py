@@ -9,7 +9,7 @@ from ionic_mpnn_amd import synthetic, weights
 from oracle import mpnn_oracle as O
 from oracle import torch_ref as TR
 
-CASES = ["tiny_viscosity", "config2_b8", "config2_perturbed_b6", "tiny_melting_point"]
+CASES = ["tiny_viscosity", "config2_b8", "config2_perturbed_b6", "tiny_melting_point", "wide_d64_b5"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -34,7 +34,7 @@ def test_oracle_fp32_within_tolerance_of_fp64(name):
         assert_close(trace[k], outs[k], rel=1e-5, what=k)
 
 
-@pytest.mark.parametrize("name", ["tiny_viscosity", "config2_b8", "config2_perturbed_b6"])
+@pytest.mark.parametrize("name", ["tiny_viscosity", "config2_b8", "config2_perturbed_b6", "wide_d64_b5"])
 def test_torch_restatement_agrees_with_numpy_oracle(name):
     kind, inputs, w, outs = load_case(name)
     y = TR.viscosity_forward(w, inputs, torch.float64).numpy()
