@@ -505,6 +505,9 @@ def main():
         out["roofline"] = {"bound": "mfma", "kernel": kname, "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                            "frac": ach / peak, "traffic": pmc_field("hbm_bytes_per_launch", kname),
                            "kernel_ms": k_ms,
+                           "traffic_source": "profiles/pmc_r*.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch from separate "
+                                             "rocprofv3 --pmc passes of this command (tools/pmc_profile.sh) on an earlier box "
+                                             "run of the same kernels - PMC collection cannot share a run with the timing",
                            "timing": (f"two HIP events around {args.steps} back-to-back launches of the kernel alone on the chip "
                                       "(one plan, impnn_encoder_run K times, one stream, one workgroup per CU; untimed "
                                       "extra launches of this run), divided by K") if exclusive_ms else
