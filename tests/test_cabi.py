@@ -146,3 +146,16 @@ def test_cpu_tensors_fail_loudly():
         ops.embed_gather(torch.zeros(2, 3, dtype=torch.int32), torch.zeros(5, 4))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.global_sum_pool(torch.zeros(1, 2, 4), torch.ones(1, 2, dtype=torch.int32))
+
+
+def test_row_list_backward_reports_its_coverage():
+    """impnn_gated_update_rows_bwd covers atom_dim 64 / 128 (the wide matrix-core kernel); other widths are refused
+    before anything is launched, and the workspace query answers 0 for them."""
+    lib = _lib.load()
+    null = None
+    assert lib.impnn_gated_update_rows_bwd_workspace_floats(1000, 128) > lib.impnn_gated_update_bwd_workspace_floats(1000, 128) > 0
+    assert lib.impnn_gated_update_rows_bwd_workspace_floats(1000, 32) == 0
+    rc = lib.impnn_gated_update_rows_bwd(*([null] * 9), 1e-3, *([null] * 5), 0, null, null, 1000, 32, 0, null)
+    assert rc == -2 and b"row-list" in lib.impnn_last_error_string()
+    rc = lib.impnn_gated_update_rows_bwd(*([null] * 9), 1e-3, *([null] * 5), 0, null, null, 1000, 128, 0, null)
+    assert rc == -1  # null pointers
