@@ -586,6 +586,7 @@ struct GuParams {
   const int32_t* meta;
   float eps;
   int n_ions;
+  int tile_rows;  // rows a workgroup updates: kRT, or 16 for launches too small to fill the chip with kRT-row tiles
   unsigned long long* stamps;  // diagnostics builds only (IMPNN_DIAG_WIDE_STAMPS)
 };
 
@@ -612,12 +613,17 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
   float* part = rhs + R * LDR;         // 2 x FG x R LayerNorm partials
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, a = lane & 15, q = lane >> 4;
   const int rg = wv % RG, fg = wv / RG;  // row group (32 rows), feature group (NL tiles of z, r and the candidate)
-  const int64_t row0 = (int64_t)blockIdx.x * R;
+  // A workgroup's LDS tile always spans R rows; with tile_rows < R only its first tile_rows rows are the workgroup's
+  // own (the rest is read like any padding and never stored), and the 16-row tiles past them are not multiplied:
+  // 768 64-row tiles on 512 slots are two rounds, the second half empty - 1 536 32-row tiles are three short ones.
+  const int64_t row0 = (int64_t)blockIdx.x * p.tile_rows;
   const int end = p.meta[kMetaEnd];
   if (row0 >= end) return;
   const int g = (p.n_ions > 1 && row0 >= p.meta[kMetaBase + 1]) ? 1 : 0;
-  const int64_t row_end = p.meta[kMetaBase + g] + p.meta[kMetaRows + g];  // rows of this tile beyond it are padding
+  const int64_t ion_end = p.meta[kMetaBase + g] + p.meta[kMetaRows + g];
+  const int64_t row_end = row0 + p.tile_rows < ion_end ? row0 + p.tile_rows : ion_end;  // rows beyond it are not this tile's
   if (row0 >= row_end) return;
+  const bool lv[2] = {32 * rg < p.tile_rows, 32 * rg + 16 < p.tile_rows};  // (wave-uniform) this wave's two row tiles
   WIDE_STAMP(p.stamps, 0);
   WIDE_STAMP_REAL(p.stamps, 5);
   const float* img = p.img[g] + p.gu_off;
@@ -673,14 +679,16 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
   };
   auto mma1 = [&](const Ops1& o) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int rt = 0; rt < 2; ++rt)
+      if (lv[rt]) {
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int TL = 0; TL < NL; ++TL) {
-          z[rt][TL] = mfma_f32(o.av[rt][r], o.bz[TL][r], z[rt][TL]);
-          rr[rt][TL] = mfma_f32(o.av[rt][r], o.br[TL][r], rr[rt][TL]);
-        }
+          for (int TL = 0; TL < NL; ++TL) {
+            z[rt][TL] = mfma_f32(o.av[rt][r], o.bz[TL][r], z[rt][TL]);
+            rr[rt][TL] = mfma_f32(o.av[rt][r], o.br[TL][r], rr[rt][TL]);
+          }
+      }
   };
   fetch1(0, preA);
   fetch1(1, preB);
@@ -777,11 +785,13 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
   };
   auto mma2 = [&](const Ops2& o) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int rt = 0; rt < 2; ++rt)
+      if (lv[rt]) {
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int TL = 0; TL < NL; ++TL) tt[rt][TL] = mfma_f32(o.av[rt][r], o.bv[TL][r], tt[rt][TL]);
+          for (int TL = 0; TL < NL; ++TL) tt[rt][TL] = mfma_f32(o.av[rt][r], o.bv[TL][r], tt[rt][TL]);
+      }
   };
   for (int u = 0; u < 2 * NT; u += 2) {
     Ops2 o;
@@ -1032,7 +1042,13 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     if (int rc = raise_lds<3>(wide_update_kernel<4>, gu_lds)) return rc;
   }
   const int64_t red_threads = w.rmax * (a.D / 4);
-  const int gu_grid = (int)(w.rmax / R);
+  // update tiles: kRT rows, or 16 rows for batches of up to ~100 pairs (the kept rows are only known on the device: the
+  // choice goes by the upper bound mols * N)
+  // (only while the smaller tiles still fit one round of two workgroups per CU: a tile's cost is mostly its 48 weight
+  //  slices and barriers, not its rows - at 256 pairs 16-row tiles took 666 us per forward against 526 us)
+  const int64_t max_tiles = ((int64_t)mols * a.N + R - 1) / R;
+  const int tile_rows = 4 * max_tiles <= 2 * cus ? 16 : R;  // (32-row tiles: 574 us at 200 pairs against ~500 us)
+  const int gu_grid = (int)(w.rmax / tile_rows);
   unsigned long long* stamps = nullptr;  // [gu_grid x 8 | cus x 8] words, the last step's launches win
   {
     size_t sb = 0;
@@ -1058,7 +1074,7 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     gp.h = F(w.h); gp.agg = F(w.agg);
     gp.img[0] = img[0]; gp.img[1] = img[1];
     gp.gu_off = step_off + (size_t)a.Vb * a.D * a.D;
-    gp.meta = I(w.meta); gp.eps = a.ln_eps; gp.n_ions = a.n_ions;
+    gp.meta = I(w.meta); gp.eps = a.ln_eps; gp.n_ions = a.n_ions; gp.tile_rows = tile_rows;
     gp.stamps = stamps;
     if (nt == 8) wide_update_kernel<8><<<gu_grid, kGuThreads, gu_lds, s>>>(gp);
     else wide_update_kernel<4><<<gu_grid, kGuThreads, gu_lds, s>>>(gp);
