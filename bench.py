@@ -412,6 +412,18 @@ def main():
                                  "graph_pairs_per_s_single_stream": B / (s_ms * 1e-3),
                                  "max_rel_diff_vs_timed_mode": float(max((oc - ref_c).abs().max(),
                                                                          (oa - ref_a).abs().max())) / scale}
+                if lanes:  # the same mode in the timed configuration (streams x workgroups of `value`), still an extra
+                    m.encoder_workgroups = enc_wgs
+                    for _ in range(3 * len(lanes)):
+                        step()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(args.steps):
+                        step()
+                    torch.cuda.synchronize()
+                    l_ms = (time.perf_counter() - t1) / args.steps * 1e3
+                    extras[other][f"graph_pairs_per_s_{len(lanes)}_streams"] = B / (l_ms * 1e-3)
+                    m.encoder_workgroups = 0
             m.encoder_mode = args.mode
             if not args.no_other_configs:
                 other_configs = time_other_configs(dev, synthetic.DEFAULT_VA, synthetic.DEFAULT_VB)
