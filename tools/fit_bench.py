@@ -16,9 +16,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--samples", type=int, default=3200)
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--epochs", type=int, default=6)
+ap.add_argument("--atom-dim", type=int, default=32)
+ap.add_argument("--steps", type=int, default=3, help="message-passing steps")
 args = ap.parse_args()
 Va, Vb = 124, 72
-m = MM.build_model(Va, Vb, device="cuda")
+m = MM.build_model(Va, Vb, atom_dim=args.atom_dim, num_steps=args.steps, device="cuda")
 m.compile(train.Adam(1e-3, clipnorm=1.0))
 x = synthetic.make_batch(args.samples, max_atoms=40, max_edges=80, atom_vocab_size=Va, bond_vocab_size=Vb, seed=0)
 y = np.random.default_rng(0).normal(1.0, 0.5, size=args.samples).astype(np.float32)
