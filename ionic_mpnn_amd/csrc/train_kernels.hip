@@ -1908,6 +1908,90 @@ __global__ __launch_bounds__(kBlock) void strided_gemm_splitk_kernel(GemmProblem
   }
 }
 
+// The same product for wide states (M = 2D >= 128, N = D >= 64, both operands row-major, whole tiles): a 128 x 64
+// output tile per workgroup, a 32 x 64 block (2 x 4 accumulator tiles) per wave - 6 LDS reads feed 8 MFMAs per k step
+// instead of 3 feeding 2, and a 32-row stage holds 64 MFMAs per wave between its two barriers instead of 16 (the
+// 64 x 32 tiles above ran the D = 128 weight gradients at 27 % of the f32 MFMA peak: 433 us per call at batch 4096).
+constexpr int kBM = 128, kBN = 64;
+__global__ __launch_bounds__(kBlock) void strided_gemm_splitk_big_kernel(GemmProblems ga, float* __restrict__ out,
+                                                                         int64_t rows, int M, int Mh, int N,
+                                                                         int64_t a_rs, int64_t b_rs, int nchunk,
+                                                                         int tilesN, const int32_t* __restrict__ rows_dev) {
+  if (rows_dev) rows = *rows_dev;
+  constexpr int kLA = kBM + 16, kLB = kBN + 16;  // row strides: the four k rows of an MFMA step on disjoint bank groups
+  __shared__ __align__(16) float As[kGR * kLA];
+  __shared__ __align__(16) float Bs[kGR * kLB];
+  const int chunk = blockIdx.x, tile = blockIdx.y, prob = blockIdx.z;
+  const int tm0 = (tile / tilesN) * kBM, tn0 = (tile % tilesN) * kBN;
+  const float* A1 = ga.A1[prob];
+  const float* A2 = ga.A2[prob];
+  const float* B = ga.B[prob];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = lane & 15, q = lane >> 4;
+  const int64_t per = (rows + nchunk - 1) / nchunk;
+  const int64_t r_lo = (int64_t)chunk * per, r_hi = r_lo + per < rows ? r_lo + per : rows;
+  constexpr int kA4 = kGR * kBM / 4 / kBlock, kB4 = kGR * kBN / 4 / kBlock;  // float4 per thread: 4 and 2
+  static_assert(kA4 * kBlock * 4 == kGR * kBM && kB4 * kBlock * 4 == kGR * kBN, "tile / block mismatch");
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = zero4;
+  f32x4_t ra[kA4], rb[kB4];
+  auto fetch = [&](int64_t r0) {
+    const int nr = (int)((r_hi - r0) < kGR ? (r_hi - r0) : kGR);
+#pragma unroll
+    for (int i = 0; i < kA4; ++i) {
+      const int t = tid + kBlock * i, r = t / (kBM / 4), m = tm0 + 4 * (t % (kBM / 4));
+      const float* ap = (m < Mh ? A1 + m : A2 + (m - Mh)) + (r0 + r) * a_rs;
+      ra[i] = r < nr ? ldv4(ap) : zero4;
+    }
+#pragma unroll
+    for (int i = 0; i < kB4; ++i) {
+      const int t = tid + kBlock * i, r = t / (kBN / 4), n = tn0 + 4 * (t % (kBN / 4));
+      rb[i] = r < nr ? ldv4(B + n + (r0 + r) * b_rs) : zero4;
+    }
+  };
+  if (r_lo < r_hi) fetch(r_lo);
+  for (int64_t r0 = r_lo; r0 < r_hi; r0 += kGR) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kA4; ++i) {
+      const int t = tid + kBlock * i;
+      stv4(As + (t / (kBM / 4)) * kLA + 4 * (t % (kBM / 4)), ra[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < kB4; ++i) {
+      const int t = tid + kBlock * i;
+      stv4(Bs + (t / (kBN / 4)) * kLB + 4 * (t % (kBN / 4)), rb[i]);
+    }
+    __syncthreads();
+    if (r0 + kGR < r_hi) fetch(r0 + kGR);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < kGR / 4; ++st) {
+      float av[2], bv[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i] = As[(4 * st + q) * kLA + 32 * wave + 16 * i + a];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[j] = Bs[(4 * st + q) * kLB + 16 * j + a];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma_f32(av[i], bv[j], acc[i][j]);
+    }
+  }
+  float* o = out + ((int64_t)prob * nchunk + chunk) * M * N;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {  // accumulator (i, j): row 32w + 16i + 4q + g, column 16j + a
+      const int m = tm0 + 32 * wave + 16 * i + 4 * q + g;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[(int64_t)m * N + tn0 + 16 * j + a] = acc[i][j][g];
+    }
+}
+
 // dparams = fixed-order sums of the partials (canonical layout, see above).  One wave per output: lane l adds
 // partials l, l+64, ... in order, then a fixed butterfly - the same association on every run.
 __global__ void gated_update_reduce_kernel(const float* __restrict__ small, const float* __restrict__ gpart,
@@ -1915,10 +1999,10 @@ __global__ void gated_update_reduce_kernel(const float* __restrict__ small, cons
                                            int wblocks) {
   const int DD2 = 2 * D * D;
   if ((int)blockIdx.x < wblocks) {
-    // the three kernel gradients.  Few chunk partials (wide states: <= 22): one THREAD per element, the partials added
+    // the three kernel gradients.  Few chunk partials (wide states: <= 64): one THREAD per element, the partials added
     // in chunk order, consecutive threads on consecutive addresses (one wave per element read its 20 partials 128 KB
     // apart: 27 us per call for 8 MB).  Many partials (atom_dim 32 at large batches: 342): one wave per element.
-    if (nchunk <= 32) {
+    if (nchunk <= 64) {
       const int t = blockIdx.x * blockDim.x + threadIdx.x;
       if (t >= 3 * DD2) return;
       const int gate = t / DD2, off = t - gate * DD2;
@@ -2605,14 +2689,19 @@ static int gu_main_blocks(int64_t rows, int D) {
   const int64_t ntile = (rows + R - 1) / R;
   return (int)(ntile < 1024 ? (ntile < 1 ? 1 : ntile) : 1024);
 }
-static int gu_tiles(int D, int* tiles_n) {
-  const int tn = (D + kGN - 1) / kGN, tm = (2 * D + kGM - 1) / kGM;
+// 128 x 64 output tiles: atom_dim 64 / 128 from 8 K rows (below that the 64 x 32 tiles give 4x the workgroups: 1.445
+// vs 1.478 ms per step at batch 32)
+static bool gu_big_tiles(int D, int64_t rows) { return D % kBN == 0 && (2 * D) % kBM == 0 && rows >= 8192; }
+static int gu_tiles(int D, int64_t rows, int* tiles_n) {
+  const int gn = gu_big_tiles(D, rows) ? kBN : kGN, gm = gu_big_tiles(D, rows) ? kBM : kGM;
+  const int tn = (D + gn - 1) / gn, tm = (2 * D + gm - 1) / gm;
   if (tiles_n) *tiles_n = tn;
   return tm * tn;
 }
 static int gu_chunks(int64_t rows, int D) {
-  const int tiles = gu_tiles(D, nullptr);
-  int64_t want = (1024 + 3 * tiles - 1) / (3 * tiles);
+  const int tiles = gu_tiles(D, rows, nullptr);
+  // ~1024 workgroups of the 64 x 32 tiles, ~768 (three resident per CU) of the 128 x 64 ones
+  int64_t want = gu_big_tiles(D, rows) ? (768 + 3 * tiles - 1) / (3 * tiles) : (1024 + 3 * tiles - 1) / (3 * tiles);
   const int64_t cap = (rows + 255) / 256;  // at least 256 contraction rows per chunk: fewer partials to write and add
   if (want > cap) want = cap;
   return (int)(want < 1 ? 1 : want);
@@ -2702,17 +2791,25 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   }
   if (int rc = check_launch("gated_update_bwd")) return rc;
   int tiles_n = 1;
-  const int tiles = gu_tiles(D, &tiles_n);
+  const int tiles = gu_tiles(D, rows, &tiles_n);
   GemmProblems ga;
   const float* gh = ridx ? hc : h;      // the GEMMs contract over the listed rows: their compact copies
   const float* ga_ = ridx ? aggc : agg;
   ga.A1[0] = gh; ga.A2[0] = ga_; ga.B[0] = dpre;
   ga.A1[1] = gh; ga.A2[1] = ga_; ga.B[1] = dpre + D;
   ga.A1[2] = rh; ga.A2[2] = ga_; ga.B[2] = dpre + 2 * D;
-  strided_gemm_splitk_kernel<<<dim3(nchunk, tiles, 3), kBlock, 0, s>>>(ga, gpart, rows, 2 * D, D, D, D, 1, 3 * D, 1,
-                                                                       nchunk, tiles_n, ridx ? nrows_dev : nullptr);
+  const bool al16g = ((reinterpret_cast<uintptr_t>(gh) | reinterpret_cast<uintptr_t>(ga_) | reinterpret_cast<uintptr_t>(rh) |
+                       reinterpret_cast<uintptr_t>(dpre)) & 15u) == 0;
+  if (gu_big_tiles(D, rows) && al16g)
+    strided_gemm_splitk_big_kernel<<<dim3(nchunk, tiles, 3), kBlock, 0, s>>>(ga, gpart, rows, 2 * D, D, D, D, 3 * D, nchunk,
+                                                                             tiles_n, ridx ? nrows_dev : nullptr);
+  else if (gu_big_tiles(D, rows))
+    return fail(IMPNN_E_BADARG, "gated_update_bwd: tensors must be 16B aligned at atom_dim %d", D);
+  else
+    strided_gemm_splitk_kernel<<<dim3(nchunk, tiles, 3), kBlock, 0, s>>>(ga, gpart, rows, 2 * D, D, D, D, 1, 3 * D, 1,
+                                                                         nchunk, tiles_n, ridx ? nrows_dev : nullptr);
   if (int rc = check_launch("strided_gemm_splitk")) return rc;
-  const int64_t welems = (int64_t)3 * 2 * D * D * (nchunk <= 32 ? 1 : 64);  // a thread or a wave per kernel element
+  const int64_t welems = (int64_t)3 * 2 * D * D * (nchunk <= 64 ? 1 : 64);  // a thread or a wave per kernel element
   const int wblocks = (int)((welems + kBlock - 1) / kBlock), vblocks = (5 * D * 64 + kBlock - 1) / kBlock;
   gated_update_reduce_kernel<<<wblocks + vblocks, kBlock, 0, s>>>(small, gpart, dparams, nblk, nchunk, D, accumulate,
                                                                  wblocks);
