@@ -139,6 +139,9 @@ int launch_encoder_prepare(const float* weights, const float* bond_table, int D,
                            void* prepared, hipStream_t s);
 int ensure_lds_limit(const void* kern, int slot);
 int device_compute_units();  // CUs of the current device (cached per device index)
+// Rows per workgroup of the wide (atom_dim 64 / 128) GatedUpdate forward / backward kernels: 64, or 16 below 8 K rows,
+// where 64-row tiles cannot fill the chip (one definition: the launchers and the workspace sizing must agree).
+inline int gu_wide_tile_rows(int64_t rows) { return rows < 8192 ? 16 : 64; }
 // ---- wide states (encoder_wide.hip: atom_dim 64 / 128 behind the same entries, mode 2)
 bool encoder_wide_supported(int N, int E, int D, int K, int S, int Vb);
 size_t encoder_wide_workspace_bytes(int n_ions, int B, int N, int E, int D, int S, int Vb);

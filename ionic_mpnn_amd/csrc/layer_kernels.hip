@@ -1357,7 +1357,7 @@ int launch_gated_update(const float* h, const float* agg, const float* Wz, const
     const size_t lw = sizeof(float) * ((size_t)64 * (2 * D + 4) + 64 * (D + 4) + 2 * 16 * (2 * D));
     const unsigned blocks = (unsigned)((rows + 63) / 64);
     // 16 waves / 64-row tiles fill the chip from ~8 K rows; below that 16-row tiles (four multiplying waves)
-    const int tile_rows = rows < 8192 ? 16 : 64;
+    const int tile_rows = gu_wide_tile_rows(rows);
     const unsigned blocks16 = (unsigned)((rows + tile_rows - 1) / tile_rows);
 #define WIDE(NT_)                                                                                                  \
     do {                                                                                                            \

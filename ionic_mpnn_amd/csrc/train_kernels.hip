@@ -2685,7 +2685,7 @@ int launch_bond_type_matrices_bwd(const float* tb, const float* W, const float* 
 
 static int gu_main_blocks(int64_t rows, int D) {
   // tiles of the main kernel: kBlock / D rows (generic kernels), 16 or 64 rows (the wide matrix-core kernel)
-  const int R = (D == 64 || D == 128) ? (rows < 8192 ? 16 : 64) : kBlock / D;
+  const int R = (D == 64 || D == 128) ? gu_wide_tile_rows(rows) : kBlock / D;
   const int64_t ntile = (rows + R - 1) / R;
   return (int)(ntile < 1024 ? (ntile < 1 ? 1 : ntile) : 1024);
 }
@@ -2745,7 +2745,7 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   if (ridx && !al16) return fail(IMPNN_E_BADARG, "gated_update_rows_bwd: tensors must be 16B aligned");
   if ((D == 64 || D == 128) && al16) {
     const size_t lw = sizeof(float) * ((size_t)64 * (2 * D + 4) + 64 * (D + 4) + 2 * 16 * 2 * D + 4 * 256 + 4 * 5 * D) + 64 * sizeof(int32_t);
-    const int tile_rows = rows < 8192 ? 16 : 64;  // (as the forward kernel: 16-row tiles below ~8 K rows)
+    const int tile_rows = gu_wide_tile_rows(rows);  // (as the forward kernel: 16-row tiles below ~8 K rows)
     const int64_t tiles64 = (rows + tile_rows - 1) / tile_rows;
     const int nb = (int)(tiles64 < nblk ? tiles64 : nblk);  // `small` has nblk slices: unused ones must be zero
     // (zeroing is a kernel, not hipMemsetAsync: the call may sit inside a captured graph)
