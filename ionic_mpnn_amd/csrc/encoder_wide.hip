@@ -27,6 +27,7 @@
 // Every product is an exact f32 product on v_mfma_f32_16x16x4_f32; every sum has a fixed order that does not depend
 // on where a molecule sits in the batch, so results are bitwise reproducible and independent of sharding.
 #include <atomic>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -1047,7 +1048,8 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   // (only while the smaller tiles still fit one round of two workgroups per CU: a tile's cost is mostly its 48 weight
   //  slices and barriers, not its rows - at 256 pairs 16-row tiles took 666 us per forward against 526 us)
   const int64_t max_tiles = ((int64_t)mols * a.N + R - 1) / R;
-  const int tile_rows = 4 * max_tiles <= 2 * cus ? 16 : R;  // (32-row tiles: 574 us at 200 pairs against ~500 us)
+  int tile_rows = 4 * max_tiles <= 2 * cus ? 16 : R;  // (32-row tiles: 574 us at 200 pairs against ~500 us)
+  if (const char* e = getenv("IMPNN_WIDE_TILE_ROWS")) tile_rows = atoi(e) == 16 ? 16 : (atoi(e) == 32 ? 32 : R);  // diagnostics
   const int gu_grid = (int)(w.rmax / tile_rows);
   unsigned long long* stamps = nullptr;  // [gu_grid x 8 | cus x 8] words, the last step's launches win
   {

@@ -1039,7 +1039,8 @@ __global__ void validate_indices_kernel(const int32_t* conn, const int32_t* atom
 //           Cc = clip(softplus(vp2), 0.1, 50); out = A + Bc / (T/100 + Cc + 1e-6)
 //   kind 1: out = relu(mixed @ Wh + bh) @ Wo + bo   (Mx -> F -> 1)
 // ---------------------------------------------------------------------------------------
-constexpr int kHeadMaxDim = 64;
+constexpr int kHeadMaxDim = 64;   // fp_size, mixing_size
+constexpr int kHeadMaxX = 128;    // pooled width (atom_dim 128: train_viscosity.py with a wider encoder)
 
 __device__ __forceinline__ float softplus_exact(float x) { return x > 20.f ? x + log1pf(expf(-x)) : log1pf(expf(x)); }
 
@@ -1053,8 +1054,8 @@ __global__ __launch_bounds__(256) void model_head_kernel(int kind, const float* 
                                                          int F, int Mx, int wfloats) {
   extern __shared__ __align__(16) float hsm[];
   float* ws = hsm;                                   // all head weights
-  float* xs = ws + ((wfloats + 3) & ~3);             // [kHeadSPB][2][kHeadMaxDim] pooled rows
-  float* fp = xs + kHeadSPB * 2 * kHeadMaxDim;       // [kHeadSPB][2][kHeadMaxDim]
+  float* xs = ws + ((wfloats + 3) & ~3);             // [kHeadSPB][2][kHeadMaxX] pooled rows
+  float* fp = xs + kHeadSPB * 2 * kHeadMaxX;         // [kHeadSPB][2][kHeadMaxDim]
   float* mix = fp + kHeadSPB * 2 * kHeadMaxDim;      // [kHeadSPB][kHeadMaxDim]
   float* hid = mix + kHeadSPB * kHeadMaxDim;         // [kHeadSPB][kHeadMaxDim]
   const int tid = threadIdx.x, sl = tid >> 5, jj = tid & 31;
@@ -1062,7 +1063,7 @@ __global__ __launch_bounds__(256) void model_head_kernel(int kind, const float* 
   const bool live = b < B;
   for (int t = tid; t < wfloats; t += blockDim.x) ws[t] = w[t];
   for (int g = 0; g < 2; ++g)
-    for (int i = jj; i < D; i += 32) xs[(sl * 2 + g) * kHeadMaxDim + i] = live ? (g == 0 ? pc : pa)[(int64_t)b * D + i] : 0.f;
+    for (int i = jj; i < D; i += 32) xs[(sl * 2 + g) * kHeadMaxX + i] = live ? (g == 0 ? pc : pa)[(int64_t)b * D + i] : 0.f;
   __syncthreads();
   const float* Wfp[2] = {ws, ws + D * F + F};
   const float* wp = ws + 2 * (D * F + F);
@@ -1071,7 +1072,7 @@ __global__ __launch_bounds__(256) void model_head_kernel(int kind, const float* 
   for (int g = 0; g < 2; ++g)
     for (int j = jj; j < F; j += 32) {
       float acc = Wfp[g][D * F + j];
-      const float* x = xs + (sl * 2 + g) * kHeadMaxDim;
+      const float* x = xs + (sl * 2 + g) * kHeadMaxX;
       for (int i = 0; i < D; ++i) acc = fmaf(x[i], Wfp[g][i * F + j], acc);
       fp[(sl * 2 + g) * kHeadMaxDim + j] = fmaxf(acc, 0.f);
     }
@@ -1422,10 +1423,10 @@ int launch_global_sum_pool(const float* h, const int32_t* ids, float* out, int B
 int launch_model_head(int kind, const float* pc, const float* pa, const float* T, const float* w, float* out, int B,
                       int D, int F, int Mx, hipStream_t s) {
   if (B == 0) return IMPNN_OK;
-  if (D > kHeadMaxDim || F > kHeadMaxDim || Mx > kHeadMaxDim)
-    return fail(IMPNN_E_UNSUPPORTED, "model_head: dims D=%d F=%d Mx=%d exceed %d", D, F, Mx, kHeadMaxDim);
+  if (D > kHeadMaxX || F > kHeadMaxDim || Mx > kHeadMaxDim)
+    return fail(IMPNN_E_UNSUPPORTED, "model_head: dims D=%d (<= %d) F=%d Mx=%d (<= %d)", D, kHeadMaxX, F, Mx, kHeadMaxDim);
   const int wfloats = (int)impnn_model_head_floats(kind, D, F, Mx);
-  const size_t lds = sizeof(float) * (((size_t)wfloats + 3) / 4 * 4 + (size_t)kHeadSPB * 6 * kHeadMaxDim);
+  const size_t lds = sizeof(float) * (((size_t)wfloats + 3) / 4 * 4 + (size_t)kHeadSPB * (2 * kHeadMaxX + 4 * kHeadMaxDim));
   if (lds > 64 * 1024) return fail(IMPNN_E_UNSUPPORTED, "model_head: weights do not fit LDS");
   model_head_kernel<<<(B + kHeadSPB - 1) / kHeadSPB, 256, lds, s>>>(kind, pc, pa, T, w, out, B, D, F, Mx, wfloats);
   return check_launch("model_head");

@@ -439,7 +439,7 @@ class MPNNModel:
             self._side_stream_used = False
 
     def head(self, pooled_cat, pooled_an, temperature=None, trace=None, differentiable=False):
-        if trace is None and not differentiable and max(self.atom_dim, self.fp_size, self.mixing_size) <= 64:
+        if trace is None and not differentiable and self.atom_dim <= 128 and max(self.fp_size, self.mixing_size) <= 64:
             return ops.model_head(self.kind, pooled_cat, pooled_an, temperature, self._packed_head(), self.fp_size,
                                   self.mixing_size)  # one launch
         if trace is None and differentiable and self.atom_dim <= 128 and max(self.fp_size, self.mixing_size) <= 64 \

@@ -195,3 +195,20 @@ def test_wide_encoder_vs_golden():
     assert_close(yl, outs["final"], what="log_eta layered")
     for k in ("cat/m0", "cat/agg1", "an/h2", "an/pooled", "cat/fp", "mixed"):
         assert_close(tr[k].cpu().numpy(), outs[k], what=k)
+
+
+def test_wide_predict_in_chunks_equals_predict_at_once():
+    """model.predict(x, batch_size) at atom_dim 128: consecutive chunks on two streams, each with its own wide workspace;
+    the head runs in impnn_model_head (pooled width up to 128), so a molecule's prediction does not depend on the
+    batch it sits in - bit for bit."""
+    Va, Vb = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=128, num_steps=2, seed=5, perturb=True)
+    m = MM.build_model(Va, Vb, atom_dim=128, num_steps=2, device=DEV)
+    m.load_weights(w)
+    inp = synthetic.make_batch(203, seed=11)
+    whole = m.predict(inp)
+    assert_close(whole, O.viscosity_forward(w, inp), what="log_eta")
+    for bs in (32, 100):
+        parts = m.predict(inp, batch_size=bs)
+        assert parts.shape == whole.shape
+        np.testing.assert_array_equal(parts, whole)
