@@ -204,7 +204,8 @@ int impnn_encoder_fused_prepared(int32_t n_ions, const int32_t* const* atom_ids,
  *      head_weights (keras Dense kernels (in,out) then bias, in this order; impnn_model_head_floats):
  *        Wfp_cat D*F | bfp_cat F | Wfp_an | bfp_an | Wp_cat F*Mx | bp_cat Mx | Wp_an | bp_an |
  *        kind 0: Wv Mx*3 | bv 3        kind 1: Wh Mx*F | bh F | Wo F | bo 1
- *      pooled_* (B,D), temperature (B,1) in kelvin (kind 0 only), out (B,1).  D, F, Mx <= 64. */
+ *      pooled_* (B,D), temperature (B,1) in kelvin (kind 0 only), out (B,1).  D <= 128 (atom_dim of the encoder:
+ *      train_viscosity.py's 32, or 128 for the wider models), F, Mx <= 64 (fp_size 32, mixing_size 20 in the reference). */
 int64_t impnn_model_head_floats(int32_t kind, int32_t D, int32_t F, int32_t Mx);
 int impnn_model_head(int32_t kind, const float* pooled_cat, const float* pooled_an,
                      const float* temperature, const float* head_weights, float* out, int32_t B,
