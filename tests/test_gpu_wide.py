@@ -212,3 +212,36 @@ def test_wide_predict_in_chunks_equals_predict_at_once():
         parts = m.predict(inp, batch_size=bs)
         assert parts.shape == whole.shape
         np.testing.assert_array_equal(parts, whole)
+
+
+def _random_dense_case(rng):
+    """Arbitrary multigraphs (self loops, edges naming padding atoms, id-0 holes), random shapes inside the wide
+    encoder's limits; sizes kept where the (B,E,D,D) oracle finishes in seconds."""
+    D = int(rng.choice([64, 128]))
+    N = int(rng.integers(1, 70))
+    E = min(int(rng.integers(0, 4 * N + 1)), 160)
+    K = int(rng.integers(1, 9))
+    S = int(rng.integers(0, 4))
+    B = int(rng.integers(1, 60 if D == 128 else 120))
+    Va, Vb = int(rng.integers(2, 300)), int(rng.integers(1, 400))
+    ids = rng.integers(0, Va, size=(2, B, N)).astype(np.int32)
+    ids[rng.random(size=ids.shape) < 0.2] = 0
+    conn = rng.integers(0, N, size=(2, B, E, 2)).astype(np.int32)
+    bond = rng.integers(0, Vb, size=(2, B, E)).astype(np.int32)
+    inp = {"cat_atom": ids[0], "cat_bond": bond[0], "cat_connectivity": conn[0],
+           "an_atom": ids[1], "an_bond": bond[1], "an_connectivity": conn[1]}
+    return D, N, E, K, S, B, Va, Vb, inp
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_wide_encoder_fuzz_against_the_oracle(seed):
+    rng = np.random.default_rng(7000 + seed)
+    D, N, E, K, S, B, Va, Vb, inp = _random_dense_case(rng)
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=D, bond_dim=K, num_steps=S, seed=seed, perturb=True)
+    m = make_model(w, Va, Vb, D, K)
+    assert m.resolve_encoder_mode(N, E) == "f32t"
+    pc, pa = m.encode_pooled(to_dev(inp), fused=True)
+    rc, ra = oracle_pooled(w, inp)
+    what = f"(D={D} N={N} E={E} K={K} S={S} B={B} Va={Va} Vb={Vb})"
+    assert_close(pc.cpu().numpy(), rc, what="cat pooled " + what)
+    assert_close(pa.cpu().numpy(), ra, what="an pooled " + what)
