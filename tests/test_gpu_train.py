@@ -248,6 +248,32 @@ def test_whole_model_gradients_match_the_oracle():
         close(t.grad, wo[name].grad, 2e-4, f"grad {name}")
 
 
+@pytest.mark.parametrize("B,N", [(120, 36), (30, 36)])
+def test_wide_state_model_gradients_match_the_oracle(B, N):
+    """atom_dim 64 (the wide kernels: matrix-core message backward, 16-row GatedUpdate tiles; at B = 120 the 4 320 atom
+    rows per ion switch on the kept-row list, impnn_gated_update_rows[_bwd]) - every parameter gradient of the whole
+    viscosity model against fp64 autograd over oracle/torch_ref.py."""
+    Va, Vb, D, K, S = 13, 6, 64, 4, 2
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=D, bond_dim=K, fp_size=12, mixing_size=10, num_steps=S, seed=9,
+                             perturb=True)
+    m = MM.build_model(Va, Vb, atom_dim=D, bond_dim=K, fp_size=12, mixing_size=10, num_steps=S, device=DEV)
+    m.load_weights(w)
+    inp = synthetic.make_batch(B, max_atoms=N, max_edges=24, atom_vocab_size=Va, bond_vocab_size=Vb, min_atoms=3, seed=9)
+    y = np.random.default_rng(9).normal(1.0, 0.5, size=B).astype(np.float32)
+    assert (B * N >= MM.TRAIN_ROW_LIST_MIN_ROWS) == (B == 120)
+    m.compile(train.Adam(1e-3, clipnorm=1.0))
+    loss = m._loss(m._to_device(inp), y, training=True)
+    loss.backward()
+    wo = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w.items()}
+    pred = TR.viscosity_forward(wo, inp, torch.float64)
+    lo = torch.mean((pred.reshape(-1) - torch.tensor(y, dtype=torch.float64)) ** 2) \
+        + 1e-4 * ((wo["cat_fp/kernel"] ** 2).sum() + (wo["an_fp/kernel"] ** 2).sum())
+    lo.backward()
+    close(loss, lo, 1e-5, "loss")
+    for name, t in m.trainable_variables():
+        close(t.grad, wo[name].grad, 2e-4, f"grad {name}")
+
+
 def test_melting_point_model_gradients_match_the_oracle():
     """train_melting_point.py: bond_dim = atom_dim^2 (the per-bond-type schedule is mandatory), l2(1e-5) on the
     fingerprint and hidden Dense kernels."""
