@@ -27,6 +27,7 @@
 // Every product is an exact f32 product on v_mfma_f32_16x16x4_f32; every sum has a fixed order that does not depend
 // on where a molecule sits in the batch, so results are bitwise reproducible and independent of sharding.
 #include <atomic>
+#include <climits>
 #include <cstdlib>
 
 #include "common.h"
@@ -991,6 +992,9 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   using namespace wide;
   const Ws w = ws_layout(a.n_ions, a.B, a.N, a.E, a.D, a.S, a.Vb);
   if (!aligned16(a.workspace)) return fail(IMPNN_E_BADARG, "encoder_fused: workspace must be 16B aligned");
+  if (w.vmax >= INT_MAX || w.rmax >= INT_MAX)  // sorted positions and compact rows are 32-bit indices
+    return fail(IMPNN_E_UNSUPPORTED, "encoder_fused: batch of %d pairs x (N=%d, E=%d) exceeds 32-bit row / edge indices",
+                a.B, a.N, a.E);
   char* base = static_cast<char*>(a.workspace);
   auto I = [&](size_t off) { return reinterpret_cast<int32_t*>(base + off); };
   auto F = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
