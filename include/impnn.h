@@ -143,8 +143,15 @@ int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, i
  *                                 (models/layers.py:108-112): m_e = A[bond id of e] h[src_e] with
  *                                 A[v] = sum_k bond_table[v,k] W[k], on v_mfma_f32_4x4x1_16b_f32, exact f32 products;
  *                                 in-edge messages summed in edge-slot order.  atom_dim 32, ANY bond_dim (K = D^2 of
- *                                 train_melting_point.py:146 included), Vb <= 256, E <= 255: one persistent kernel with
- *                                 the node state in LDS.  atom_dim 64 / 128 (train_viscosity.py with atom_dim=128,
+ *                                 train_melting_point.py:146 included), Vb <= 256, ANY padded shape N, E < 65536 (the
+ *                                 explicit-hydrogen molecules of src/featurize.py:45 pad to E = 4 max_bonds,
+ *                                 train_viscosity.py:288-289): one persistent kernel with the node state in LDS.  What
+ *                                 bounds a molecule is what it HOLDS - kept rows <= 256, valid edges <= 512,
+ *                                 in-degrees <= 255 - checked per batch by the plan kernels: a batch with a molecule
+ *                                 beyond that gets NaN outputs and a nonzero int32 at byte
+ *                                 impnn_encoder_plan_overflow_offset() of the workspace (device memory; a caller whose
+ *                                 shapes allow it - N > 256 or E > 255 - reads the word back and takes the layer-at-a-
+ *                                 time entries for that batch, as ionic_mpnn_amd.model does).  atom_dim 64 / 128 (train_viscosity.py with atom_dim=128,
  *                                 num_steps=6), N <= 256, E <= 512, Vb <= 512: the same arithmetic as a short sequence
  *                                 of launches per call on compact kept rows (per type-run GEMMs for the messages,
  *                                 slot-order sums, GatedUpdate on 128-row tiles; csrc/encoder_wide.hip); `workgroups`
@@ -154,8 +161,9 @@ int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, i
  *                                 cross products are accumulated in f32 (9 x v_mfma_f32_16x16x32_bf16 per 8 f32 MFMAs):
  *                                 the products are the f32 products, only their summation order differs.  Messages
  *                                 stay on the f32 4x4x1 MFMA.  Same records, prepared buffer of its own.  Opt-in.
- *  `workgroups` - persistent workgroups of the launch: 0 = default (environment IMPNN_ENCODER_WORKGROUPS if set, else
- *  one per compute unit), n = min(max(n, 16), CUs).  It fixes the workspace layout, so the size query, the plan and
+ *  `workgroups` - persistent workgroups of the launch: 0 = default (environment IMPNN_ENCODER_WORKGROUPS if set - a
+ *  process-wide diagnostics override, read ONCE at the first call - else one per compute unit), n = min(max(n, 16), CUs);
+ *  a multiple of that for very large batches or padded shapes (the size query, plan and run agree on it by themselves).  It fixes the workspace layout, so the size query, the plan and
  *  the run of one batch must agree - impnn_encoder_plan returns what it used in its plan info and impnn_encoder_run
  *  takes it from there.  Why it is a knob: a caller that keeps several batches in flight on several streams gets more
  *  out of the chip with fewer, longer-running workgroups per launch (bench.py --streams 3: 128). */
@@ -164,6 +172,7 @@ int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, i
 #define IMPNN_ENCODER_F32_TYPED 2
 #define IMPNN_ENCODER_F32X3_TYPED 3
 int64_t impnn_encoder_step_floats(int32_t D, int32_t K);
+size_t impnn_encoder_plan_overflow_offset(void);
 int impnn_encoder_workspace_bytes(int32_t n_ions, int32_t B, int32_t N, int32_t E, int32_t D,
                                   int32_t K, int32_t S, int32_t Vb, int32_t mode, int32_t workgroups,
                                   size_t* bytes);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "impnn_row_index_fill": (C.c_int, [vp, vp, vp, vp, i32, i32, vp]),
     "impnn_global_sum_pool": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
     "impnn_encoder_step_floats": (i64, [i32, i32]),
+    "impnn_encoder_plan_overflow_offset": (sz, []),
     "impnn_encoder_workspace_bytes": (C.c_int, [i32] * 10 + [C.POINTER(sz)]),
     "impnn_encoder_fused": (C.c_int, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, i32, vp, i32,
                                       C.POINTER(vp), i32, C.POINTER(vp), i32, i32, i32, i32, i32, i32, f32, i32, vp,

@@ -2,7 +2,10 @@
 #include <cstring>
 #include <vector>
 
+#include <cstddef>
+
 #include "common.h"
+#include "encoder_layout.h"
 
 namespace impnn {
 
@@ -165,6 +168,8 @@ int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, i
   return launch_global_sum_pool(h, atom_ids, out, B, N, D, as_stream(stream));
 }
 
+size_t impnn_encoder_plan_overflow_offset(void) { return offsetof(enc::PlanHeader, overflow); }
+
 int64_t impnn_encoder_step_floats(int32_t D, int32_t K) {
   if (D <= 0 || K <= 0) return -1;
   const int64_t d = D, k = K;
@@ -187,7 +192,7 @@ int impnn_encoder_workspace_bytes(int32_t n_ions, int32_t B, int32_t N, int32_t 
   if (!encoder_fused_supported(mode, N, E, D, K, S, Vb))
     return fail(IMPNN_E_UNSUPPORTED, "encoder_fused: mode=%d shape N=%d E=%d D=%d K=%d S=%d Vb=%d not covered", mode,
                 N, E, D, K, S, Vb);
-  *bytes = encoder_fused_workspace_bytes(mode, n_ions, B, N, E, D, S, Vb, encoder_workgroups(n_ions, B, workgroups));
+  *bytes = encoder_fused_workspace_bytes(mode, n_ions, B, N, E, D, S, Vb, encoder_workgroups(n_ions, B, workgroups, N, E, mode));
   return IMPNN_OK;
 }
 
@@ -212,7 +217,7 @@ static int encoder_common(const char* fn, int32_t n_ions, const int32_t* const* 
   if (!encoder_fused_supported(mode, N, E, D, K, S, Vb))
     return fail(IMPNN_E_UNSUPPORTED, "encoder_fused: mode=%d shape N=%d E=%d D=%d K=%d S=%d Vb=%d not covered", mode,
                 N, E, D, K, S, Vb);
-  int nwg = encoder_workgroups(n_ions, B, workgroups);
+  int nwg = encoder_workgroups(n_ions, B, workgroups, N, E, mode);
   if (info_in) {  // run half: the plan's geometry is authoritative, and must be the geometry of this call
     const int32_t* v = info_in->v;
     REQ(v[0] == kInfoMagic, "plan info was not filled by impnn_encoder_plan");

@@ -130,7 +130,7 @@ struct EncoderArgs {
   size_t workspace_bytes;
 };
 bool encoder_fused_supported(int mode, int N, int E, int D, int K, int S, int Vb);
-int encoder_workgroups(int n_ions, int B, int requested);
+int encoder_workgroups(int n_ions, int B, int requested, int N, int E, int mode);
 size_t encoder_fused_workspace_bytes(int mode, int n_ions, int B, int N, int E, int D, int S, int Vb, int nwg);
 int launch_encoder_fused(const EncoderArgs& a, hipStream_t s);
 int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase);

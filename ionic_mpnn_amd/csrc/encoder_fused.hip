@@ -526,6 +526,7 @@ int launch_encoder_typed_run(const EncoderArgs& a, const enc::Ws& w, hipStream_t
 bool encoder_fused_supported(int mode, int N, int E, int D, int K, int S, int Vb) {
   using namespace enc;
   if (mode == 2 && D != kD) return encoder_wide_supported(N, E, D, K, S, Vb);  // atom_dim 64 / 128: encoder_wide.hip
+  if (mode == 3 && tecap_of(E) != kTECap) return false;  // the three-plane update image leaves no LDS for 640 edge slots
   if (mode == 2 || mode == 3) return K >= 1 && encoder_typed_supported(N, E, D, S, Vb);
   if (mode != 0 && mode != 1) return false;
   if (D != kD || K < 1 || K > kKMax || S < 0) return false;
@@ -564,19 +565,25 @@ int ensure_lds_limit(const void* kern, int slot) {
 }
 
 // Persistent workgroups of one encoder launch.  `requested` > 0: the caller's choice, clamped to [16, CUs];
-// 0: the default - IMPNN_ENCODER_WORKGROUPS from the environment if set, else one per CU.  For very large batches a
-// multiple of that, so that a share never holds more molecules than plan_chunks resolves in LDS (the extra
-// workgroups simply run in rounds).  A pure function of its arguments and the environment: no library state.
-int encoder_workgroups(int n_ions, int B, int requested) {
+// 0: the default - IMPNN_ENCODER_WORKGROUPS from the environment if set (read once per process: a diagnostics
+// override, see impnn.h), else one per CU.  For very large batches or padded shapes a multiple of that, so that a
+// share never holds more molecules (kShareCap) or chunks (kMaxHops) than plan_chunks resolves in LDS (the extra
+// workgroups simply run in rounds).  A pure function of its arguments.
+int encoder_workgroups(int n_ions, int B, int requested, int N, int E, int mode) {
   int cus = device_compute_units();
   int want = requested;
   if (want <= 0) {
-    const char* e = getenv("IMPNN_ENCODER_WORKGROUPS");
-    want = e ? atoi(e) : 0;
+    static const int env_want = [] {
+      const char* e = getenv("IMPNN_ENCODER_WORKGROUPS");
+      return e ? atoi(e) : 0;
+    }();
+    want = env_want;
   }
   if (want > 0) cus = want < 16 ? 16 : (want > cus ? cus : want);
   int f = 1;
-  while ((int64_t)2 * n_ions * B / ((int64_t)cus * f) + 64 > enc::kECap) ++f;
+  while ((int64_t)2 * n_ions * B / ((int64_t)cus * f) + 64 > enc::kShareCap ||
+         enc::ws_layout(n_ions, B, N, E, 1, 1, cus * f, mode >= 2, mode == 3).max_sub > enc::kMaxHops)
+    ++f;
   return cus * f;
 }
 
@@ -650,6 +657,7 @@ int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
   pp.rec = reinterpret_cast<unsigned char*>(base + w.rec_off);
   pp.header = reinterpret_cast<PlanHeader*>(base);
   pp.typed = typed ? 1 : 0;
+  pp.ecap = tecap_of(a.E);
   pp.n_ions = a.n_ions; pp.B = a.B; pp.N = a.N; pp.E = a.E; pp.Va = a.Va; pp.Vb = a.Vb;
   pp.grid_sub = w.max_sub < 5 ? w.max_sub : 5;  // 5 x 256 workgroups of 256 threads are resident at once on 256 CUs (<= 96 VGPRs)
   pp.nwg = w.nwg;

@@ -68,9 +68,14 @@ static_assert(kRecEnt + 4 * kECap <= kRecBytes && kRecEnt % 16 == 0, "record lay
 // "jagged diagonal" order - slot(row, d) = jdptr[d] + row for the d-th in-edge (edge-slot order) of placed row
 // `row`; rows are placed by descending in-degree, so the rows that have a d-th in-edge are a prefix - and every
 // atom row then sums its in-edges in edge-slot order (the reference's sequential scatter_nd, models/layers.py:78-82).
-constexpr int kTECap = 512;          // valid edges per chunk (2 per virtual row)
-constexpr int kTGrpCap = 384;        // = kTECap/4 + kTVbMax groups
+constexpr int kTECap = 512;          // valid edges per chunk (2 per virtual row) for padded shapes E <= 512 ...
+constexpr int kTECapBig = 640;       // ... and beyond: 2.5 per virtual row, so that a 160-atom explicit-hydrogen molecule
+                                     // (<= 160 bonds x 4 edge slots: train_viscosity.py:288-289) still fits one chunk; the
+                                     // message buffer then takes the LDS of the atom table copy (mode 2 only)
+__host__ __device__ constexpr int tecap_of(int E) { return E > kTECap ? kTECapBig : kTECap; }
 constexpr int kTVbMax = 256;         // bond ids travel as 8 bits
+constexpr int kTHS = 36;             // LDS row stride (floats) of h in the typed encoder (as kHS: rows spread over the banks)
+constexpr int kTAS = 32;             // row stride of the atom table copy (unpadded: the LDS budget of mode 3 needs the 2 KB)
 constexpr int kTRecRowdeg = 0;       // u16[kRCap]    : in-degree of the PLACED row
 constexpr int kTRecTilemax = 528;    // u8[16]
 constexpr int kTRecMoloff = 544;     // u16[kRCap + 2]
@@ -80,24 +85,42 @@ constexpr int kTRecRowatom = 2096;   // i32[kRCap]
 constexpr int kTRecCounts = 3120;    // u16 groups, u16 edges, u16 max in-degree
 constexpr int kTRecJdptr = 3136;     // u16[258]      : first message slot of in-edge index d
 constexpr int kTRecNrun = 3664;      // u16           : type runs (bond types present in the chunk)
-constexpr int kTRecGrp = 3712;       // uint4[kTGrpCap]: x = type | edges << 8 | groups of the type from here on << 24,
+constexpr int kTRecGrp = 3712;       // uint4[tgrp_cap(Vb)]: x = type | edges << 8 | groups of the type from here on << 24,
                                      //   y = 4 x u8 placed source row, z/w = 4 x u16 message key (tmsg_key of the edge's
                                      //   slot; the dump slot for unused lanes); in type order
-constexpr int kTRecRuns = kTRecGrp + 16 * kTGrpCap;  // u16[kTVbMax + 2]: first group of every type run, + end
-constexpr int kTRecBytes = 12288;
-static_assert(kTRecGrp % 16 == 0 && kTRecRuns + 2 * (kTVbMax + 2) <= kTRecBytes, "typed record layout");
-constexpr int kTMsgFloats = (kTECap + 1) * kD;  // message buffer, 128 B per slot, 16-byte units XOR-swizzled by slot;
-                                                // slot kTECap is a dump for the unused edge lanes of a group
+// A chunk holds <= ecap edges of <= Vb types: at most ecap/4 full groups plus one partial group per type.  The run
+// table (u16[Vb + 2]: first group of every type run, + end) follows the group table, so a record's used bytes - and the
+// LDS the encoder spends on it - depend on the bond vocabulary: 7.1 KB at Vb = 72, 12 KB at Vb = 256.
+__host__ __device__ constexpr int tgrp_cap(int Vb, int ecap) { return ecap / 4 + (Vb < kTVbMax ? Vb : kTVbMax); }
+__host__ __device__ constexpr int trec_runs_off(int Vb, int ecap) { return kTRecGrp + 16 * tgrp_cap(Vb, ecap); }
+__host__ __device__ constexpr int trec_used_bytes(int Vb, int ecap) {
+  return (trec_runs_off(Vb, ecap) + 2 * (Vb + 2) + 15) & ~15;
+}
+constexpr int kTRecBytes = 12288;    // stride of the records in the workspace
+constexpr int kTRecPart1 = 8192;     // the encoder copies a record as 8 B per thread (+ 4 B per thread beyond 8 KB)
+// LDS bytes the encoder reserves for the record: its used part
+__host__ __device__ constexpr int trec_lds_bytes(int Vb, int ecap) { return trec_used_bytes(Vb, ecap); }
+static_assert(kTRecGrp % 16 == 0 && trec_used_bytes(kTVbMax, kTECapBig) <= kTRecBytes, "typed record layout");
+// message buffer: ecap slots of 128 B (16-byte units XOR-swizzled by slot) + a dump slot (index ecap) for the unused edge
+// lanes of a group + a slot of zeros (index ecap + 1: what a row reads for the in-edges it does not have, so the Reduce
+// is branch-free)
+__host__ __device__ constexpr int tmsg_floats(int ecap) { return (ecap + 2) * kD; }
 // 16-byte unit u (0..7) of message slot s -> float offset.  16 consecutive slots x one unit cover all 16 bank quads
 // (the pull of a tile is conflict-free), and the 8 units of a slot stay a permutation of its 32 banks.
 __host__ __device__ constexpr int tmsg_off(int s, int u) { return s * kD + ((u ^ ((s >> 1) & 7)) << 2); }
 // the same as one XOR per lane: float offset of feature f (0..31) of slot s = tmsg_key(s) ^ f
 __host__ __device__ constexpr int tmsg_key(int s) { return s * kD + (((s >> 1) & 7) << 2); }
-static_assert(tmsg_key(kTECap) < 65536, "message keys travel as 16 bits");
-// per-step update image: gate kernels transposed (3 x 32 rows of kUpdRS) + 5 vectors, in a slot of 2 loads per thread
-constexpr int kTUpdFloats = 3 * kD * kUpdRS + 5 * kD;  // 6688
+static_assert(tmsg_key(kTECapBig + 1) < 65536, "message keys travel as 16 bits");
+// per-step update image (mode 2): the gate kernels in the A-operand order of v_mfma_f32_16x16x4_f32 - 24 blocks
+// (gate, T, half, u) of 64 lanes x 4 floats, lane (a = l & 15, q = l >> 4), element r:
+//     W_gate[(32 half + 16 u + 4 q + r) * 32 + 16 T + a]       (keras kernel (64, 32): [input][output])
+// so that every A fetch of the update GEMMs is one lane-linear (conflict-free) ds_read_b128 - then the 5 vectors
+// (bz, br, bh, gamma, beta).  Stored in a slot of 2 loads per thread.
+constexpr int kTUpdBlocks = 24;
+constexpr int kTVecFloatOff = kTUpdBlocks * 256;        // 6144
+constexpr int kTUpdFloats = kTVecFloatOff + 5 * kD;     // 6304
 constexpr int kTUpdSlot = 2 * kThreads * 4;             // 8192 floats
-constexpr int kTUpdLds = 6912;                          // floats kept in LDS (>= kTUpdFloats, multiple of 128)
+constexpr int kTUpdLds = 6400;                          // floats kept in LDS (>= kTUpdFloats, multiple of 128)
 static_assert(kTUpdFloats <= kTUpdLds && kTUpdLds <= kTUpdSlot, "typed update image");
 // mode 3 ("f32x3"): the update GEMMs on the bf16 matrix pipe with every f32 operand carried EXACTLY as three bf16 terms
 // (x = b0 + b1 + b2: 3 x 8 significant bits, fp32's exponent range) and all nine cross products accumulated in f32.
@@ -119,6 +142,9 @@ inline size_t typed_prepared_floats(int S, int Vb, bool x3 = false) {
   return s * (x3 ? kXUpdSlot : kTUpdSlot) + s * (size_t)Vb * kTMatFloats + (size_t)Vb * kTMatFloats;
 }
 
+constexpr int kShareCap = kECap;  // molecules of one share that plan_chunks resolves in LDS
+constexpr int kMaxHops = 128;     // chunks of one share (Ws::max_sub <= kMaxHops: encoder_workgroups sees to it)
+
 // chunk descriptor (int4): {first molecule, molecules, 0, rows | ion << 16}
 constexpr int kPB = 16;  // molecules per plan_stats workgroup (= partial-sum granularity)
 
@@ -133,17 +159,27 @@ struct Ws {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// virtual rows that `edges` valid edges occupy in a typed chunk: edges <= ecap  <=>  rows <= kRCap
+__host__ __device__ constexpr int tvr_of_edges(int edges, int ecap) { return (edges * kRCap + ecap - 1) / ecap; }
+
 inline int vr_max_of(int N, int E, bool typed = false) {
-  int v = typed ? (E + 1) / 2 : (E + 3) / 4;
+  int v = typed ? (E > 4 * kTECapBig ? kRCap + 1 : tvr_of_edges(E, tecap_of(E))) : (E + 3) / 4;
   int m = N > v ? N : v;
-  return m < 1 ? 1 : m;
+  m = m < 1 ? 1 : m;
+  // typed plans take any padded shape: a molecule is bounded by what it HOLDS (kept rows, valid edges: plan_stats), not
+  // by N and E, and one that exceeds a chunk raises PlanHeader::overflow
+  return typed && m > kRCap ? kRCap : m;
 }
 
 // The first 256 bytes of a workspace are the plan header (PlanHeader): written by the plan, checked by the encoder.
 struct PlanHeader {
   int32_t magic, kind, n_ions, B, N, E, nwg, max_sub;
+  int32_t overflow;  // typed plans: 1 when a molecule does not fit a chunk (more than kRCap rows / 2 kRCap valid edges, or an
+                     // in-degree above 255): the encoder then writes NaN (callers with such shapes read this word back)
 };
 constexpr int32_t kPlanMagic = 0x696d706e;  // "impn"
+constexpr int32_t kPlanBadBit = 1 << 30;     // in a block's partial sum of virtual rows: the block holds a molecule that
+                                             // does not fit a chunk
 
 inline Ws ws_layout(int n_ions, int B, int N, int E, int S, int Vb, int nwg, bool typed, bool x3 = false) {
   Ws w{};
@@ -154,7 +190,11 @@ inline Ws ws_layout(int n_ions, int B, int N, int E, int S, int Vb, int nwg, boo
   w.nblk = (B + kPB - 1) / kPB;
   // rows of one share <= 2 * (all rows) / nwg + vrmax (ion split rounds to whole workgroups)
   const int64_t share_rows = (2 * (int64_t)n_ions * B * vrmax) / nwg + vrmax;
-  w.max_sub = (int)(share_rows / win) + 2;
+  // chunks of a share: a chunk closed by next-fit holds >= win rows; and any two consecutive chunks hold more than
+  // kRCap rows together (else next-fit had merged them) - the bound that holds whatever the padded shape is
+  const int64_t by_win = win >= 1 ? share_rows / win + 2 : (int64_t)1 << 40;
+  const int64_t by_pairs = 2 * share_rows / (kRCap + 1) + 2;
+  w.max_sub = (int)(by_win < by_pairs ? by_win : by_pairs);
   size_t off = 256;  // plan header
   w.img_off = off;
   off = align_up(off + (typed ? (size_t)n_ions * typed_prepared_floats(S, Vb, x3)
@@ -189,7 +229,8 @@ struct PlanParams {
   unsigned char* rec; // [nwg][max_sub][kRecBytes]
   int n_ions, B, N, E, Va, Vb, nwg, max_sub, nblk;
   int grid_sub;  // plan_chunks workgroups launched per share (<= max_sub)
-  int typed;     // 1: typed records (kTRecBytes), 2 valid edges per virtual row
+  int typed;     // 1: typed records (kTRecBytes), ecap / kRCap valid edges per virtual row
+  int ecap;      // typed: valid edges per chunk, tecap_of(E)
   PlanHeader* header;          // written by plan_stats block 0
   unsigned long long* stamps;  // diagnostics only: 16 words written by plan_chunks workgroup 0
 };
@@ -237,6 +278,8 @@ struct TEncParams {
   int n_ions, B, S, Va, Vb, max_sub;
   int atab_lds;
   int upd_slot;  // floats between the update images of consecutive steps (kTUpdSlot or kXUpdSlot)
+  int rec_lds;   // LDS bytes reserved for the chunk record: trec_lds_bytes(Vb, ecap)
+  int ecap;      // valid edges per chunk: tecap_of(E)
   float ln_eps;
   unsigned long long* stamps;
 };

@@ -24,7 +24,7 @@ namespace {
 // the LDS image the encoder copies verbatim (message rows padded to 36, gate kernels transposed).
 // -----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * kPB) void plan_stats_kernel(PlanParams p) {
-  __shared__ int vsum[kPB];
+  __shared__ int vsum[kPB], vbad[kPB];
   // Plan kernels are short chains of dependent loads; when they run beside the issue-bound encoder of
   // the previous batch (pipelined callers) they must not queue behind its waves for every instruction.
   __builtin_amdgcn_s_setprio(3);
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64 * kPB) void plan_stats_kernel(PlanParams p) {
   const int b = blk * kPB + wv;
   const bool have = b < p.B;
   const int64_t item = (int64_t)g * p.B + (have ? b : 0);
-  int my_vr = 0;
+  int my_vr = 0, my_bad = 0;
   if (have) {
   const int32_t* ids = p.atom_ids[g] + (int64_t)b * p.N;
   const int32_t* cn = p.conn[g] + (int64_t)b * p.E * 2;
@@ -73,26 +73,40 @@ __global__ __launch_bounds__(64 * kPB) void plan_stats_kernel(PlanParams p) {
     rmax = rmax > res + 1 ? rmax : res + 1;
   }
   {
-    int vr = p.typed ? (cnt + 1) >> 1 : (cnt + 3) >> 2;  // edges per virtual row: 4 (pull records) or 2 (typed)
+    // edges per virtual row: 4 (pull records) or ecap / 256 = 2, 2.5 (typed)
+    int vr = p.typed ? tvr_of_edges(cnt < 0x100000 ? cnt : 0x100000, p.ecap) : (cnt + 3) >> 2;
     vr = vr > rmax ? vr : rmax;
     my_vr = vr < 1 ? 1 : vr;
+    // a molecule that does not fit one chunk (kRCap rows / kRCap virtual rows of edges): the plan is marked as
+    // overflowed (kPlanBadBit of the block's partial sum -> plan_chunks -> PlanHeader::overflow), nothing is built
+    if (my_vr > kRCap) {
+      my_vr = kRCap;
+      my_bad = 1;
+    }
     if (lane == 0) {
       p.rows[item] = rmax;
       p.vr[item] = my_vr;
     }
   }
   }
-  if (lane == 0) vsum[wv] = my_vr;
+  if (lane == 0) {
+    vsum[wv] = my_vr;
+    vbad[wv] = my_bad;
+  }
   lds_barrier();
   if (threadIdx.x == 0) {
-    int t = 0;
+    int t = 0, bad = 0;
 #pragma unroll
-    for (int i = 0; i < kPB; ++i) t += vsum[i];
-    p.partial[(int64_t)g * p.nblk + blk] = t;
+    for (int i = 0; i < kPB; ++i) {
+      t += vsum[i];
+      bad |= vbad[i];
+    }
+    p.partial[(int64_t)g * p.nblk + blk] = t | (bad ? kPlanBadBit : 0);  // t <= kPB * kRCap = 4096
     if (blockIdx.x == 0) {  // what this plan was made for: the encoder refuses a workspace planned differently
       PlanHeader h;
       h.magic = kPlanMagic; h.kind = p.typed; h.n_ions = p.n_ions; h.B = p.B; h.N = p.N; h.E = p.E;
       h.nwg = p.nwg; h.max_sub = p.max_sub;
+      h.overflow = 0;  // raised by plan_chunks (the next kernel on the stream)
       *p.header = h;
     }
   }
@@ -178,7 +192,7 @@ __global__ void weight_image_kernel(ImageParams p) {
 // typed_image: step `s` of the typed encoder's prepared buffer.  The canonical per-bond-type matrices
 // A[v] = sum_k bond_table[v,k] W[k] of the step (models/layers.py:108, computed by launch_bond_type_matrices
 // into the buffer's scratch area) are re-laid in the B-operand order of v_mfma_f32_4x4x1 (encoder_layout.h),
-// and the GatedUpdate weights of the step in the transposed / padded layout the update GEMMs read from LDS.
+// and the GatedUpdate kernels of the step in the MFMA A-operand order the update GEMMs read from LDS.
 // -----------------------------------------------------------------------------------------
 __global__ void typed_image_kernel(TImageParams p, int s) {
   const int t_begin = blockIdx.x * blockDim.x + threadIdx.x, t_stride = gridDim.x * blockDim.x;
@@ -232,16 +246,18 @@ __global__ void typed_image_kernel(TImageParams p, int s) {
     }
     return;
   }
-  constexpr int nupd = 3 * kD * kUpdRS;
   for (int t = t_begin; t < kTUpdSlot; t += t_stride) {
     float val = 0.f;
-    if (t < nupd) {
-      const int row = t / kUpdRS, jj = t - row * kUpdRS;  // row = gate*32 + i_out
-      const int gate = row / kD, io = row - gate * kD;
+    if (t < kTVecFloatOff) {
+      // A-operand order of v_mfma_f32_16x16x4_f32 (encoder_layout.h): t = (blk * 64 + lane) * 4 + r,
+      // blk = ((gate * 2 + T) * 2 + half) * 2 + u
+      const int r = t & 3, ln = (t >> 2) & 63, blk = t >> 8;
+      const int a = ln & 15, q = ln >> 4;
+      const int u = blk & 1, half = (blk >> 1) & 1, T = (blk >> 2) & 1, gate = blk >> 3;
       const float* Wg = gate == 0 ? Wz : (gate == 1 ? Wr : Wh);
-      val = jj < 2 * kD ? Wg[(int64_t)jj * kD + io] : 0.f;
-    } else if (t < nupd + 5 * kD) {
-      const int v = (t - nupd) / kD, i = (t - nupd) - v * kD;
+      val = Wg[(int64_t)(32 * half + 16 * u + 4 * q + r) * kD + 16 * T + a];
+    } else if (t < kTVecFloatOff + 5 * kD) {
+      const int v = (t - kTVecFloatOff) / kD, i = (t - kTVecFloatOff) - v * kD;
       const float* src = v == 0 ? bz : v == 1 ? br : v == 2 ? bh : v == 3 ? gamma : beta;
       val = src[i];
     }
@@ -259,8 +275,9 @@ __global__ void typed_image_kernel(TImageParams p, int s) {
 // from a separate single-workgroup kernel: one launch and one dependent stage fewer.
 // -----------------------------------------------------------------------------------------
 __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int lane, int& g, int& k0, int& bp0,
-                                              int& t_lo, int& t_hi) {
+                                              int& t_lo, int& t_hi, bool& bad) {
   const int nblk = p.nblk;
+  bad = false;
   // All partial sums are fetched up front with clamped, unconditional addresses (kPU x 64 per ion and
   // pass): the loads of a pass are in flight together, and the block search below works on the same
   // registers instead of reading the table a second time.
@@ -275,8 +292,10 @@ __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int la
         const int k = lane + 64 * i;
         const int kk = k < nblk ? k : nblk - 1;
         const int x = gi < p.n_ions ? p.partial[(int64_t)gi * nblk + kk] : 0;
-        v[gi][i] = k < nblk ? x : 0;
+        if (__ballot(k < nblk && (x & kPlanBadBit))) bad = true;
+        v[gi][i] = k < nblk ? (x & ~kPlanBadBit) : 0;
       }
+    if (bad) return false;
     int incl[2][kPU], tot[2];
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi) {
@@ -323,11 +342,17 @@ __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int la
   long long tot[2] = {0, 0};
   for (int gi = 0; gi < p.n_ions; ++gi) {
     const int32_t* part = p.partial + (int64_t)gi * nblk;
-    int acc = 0;
-    for (int k = lane; k < nblk; k += 64) acc += part[k];
+    int acc = 0, anybad = 0;
+    for (int k = lane; k < nblk; k += 64) {
+      const int x = part[k];
+      anybad |= x & kPlanBadBit;
+      acc += x & ~kPlanBadBit;
+    }
+    if (__ballot(anybad != 0)) bad = true;
     tot[gi] = wave_incl_scan(acc);
     tot[gi] = __shfl((int)tot[gi], 63);
   }
+  if (bad) return false;
   int nwg0 = p.nwg, nwg1 = 0;
   if (p.n_ions == 2) {
     const long long t0 = tot[0], t1 = tot[1];
@@ -351,7 +376,7 @@ __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int la
   bool found = false;
   for (int kbase = 0; kbase < nblk && !found; kbase += 64) {
     const int k = kbase + lane;
-    const int v = k < nblk ? part[k < nblk ? k : nblk - 1] : 0;
+    const int v = k < nblk ? (part[k < nblk ? k : nblk - 1] & ~kPlanBadBit) : 0;
     const int incl = wave_incl_scan(v);
     const int st = carry + incl - v;
     const unsigned long long hit = __ballot(k < nblk && st <= t_lo && t_lo < st + v);
@@ -370,8 +395,6 @@ __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int la
 // plan_chunks: 256 threads (= kRCap: one per row) per chunk.
 // -----------------------------------------------------------------------------------------
 constexpr int kDegBins = 18;    // in-degree 0..15, ">= 16", and "row beyond the chunk" (placed last)
-constexpr int kShareCap = kECap;  // molecules of one share resolved in LDS
-constexpr int kMaxHops = 128;     // chunks of one share (launch_plan checks max_sub against it)
 
 // Exclusive prefix sum over the 256 threads of a plan_chunks workgroup (4 waves); `total` gets the sum.
 __device__ __forceinline__ int block_excl_scan(int v, int32_t* wsum /* [4] LDS */, int& total) {
@@ -412,11 +435,13 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
   //      the next-fit chain of chunks; wave 0 does it, everybody else waits at the barrier.
   if (wave == 0) {
     int g = 0, k0 = 0, bp0 = 0, t_lo = 0, t_hi = 0;
-    const bool have = resolve_share(p, j, lane, g, k0, bp0, t_lo, t_hi);
+    bool bad = false;
+    const bool have = resolve_share(p, j, lane, g, k0, bp0, t_lo, t_hi, bad);
     if (!have) {
       if (lane == 0) {
         chunk_s[0] = -1; chunk_s[1] = 0; chunk_s[2] = 0;
         if (slot_i == 0) p.nsub[j] = 0;
+        if (bad && blockIdx.x == 0) p.header->overflow = 1;  // a molecule larger than a chunk: every share is empty
       }
     } else {
     const int32_t* vrg = p.vr + (int64_t)g * p.B;
@@ -574,6 +599,7 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
   if constexpr (TYPED) {
     // exact bins: 255 - in-degree (in-degree <= E <= 255); rows beyond the chunk go last
     const int dcl = my_deg > 255 ? 255 : my_deg;
+    if (tid < R && my_deg > 255) p.header->overflow = 1;  // in-degrees travel as 8 bits: the encoder refuses this plan
     if (tid < R) atomicAdd(&bins[255 - dcl], 1);
     lds_barrier();
     CSTAMP(4);
@@ -701,7 +727,7 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
     tgb[tid] = gb;
     thist[tid] = 0;  // becomes the fill cursor of the type
     {
-      const uint32_t dump = (uint32_t)tmsg_key(kTECap) * 0x10001u;  // unused edge lanes write to the dump slot
+      const uint32_t dump = (uint32_t)tmsg_key(p.ecap) * 0x10001u;  // unused edge lanes write to the dump slot
       for (int i = tid; i < ngrp; i += kRCap) grp[i] = make_uint4(0u, 0u, dump, dump);
     }
     lds_barrier();
@@ -716,7 +742,7 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
     {
       int nrun = 0;
       const int ridx = block_excl_scan(ng > 0 ? 1 : 0, scratch, nrun);
-      uint16_t* runs = reinterpret_cast<uint16_t*>(rec + kTRecRuns);
+      uint16_t* runs = reinterpret_cast<uint16_t*>(rec + trec_runs_off(p.Vb, p.ecap));
       if (ng > 0) runs[ridx] = (uint16_t)gb;
       if (tid == 0) {
         runs[nrun] = (uint16_t)ngrp;
@@ -743,7 +769,8 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
       int rank = 0;
       for (int jx = b0; jx < b1; ++jx) rank += ent2[jx] < v;
       const uint32_t srow = v & 0xffu, bid = (v >> 8) & 0xffu;
-      const uint32_t mslot = (uint32_t)(jdp[rank] + lo);  // jagged diagonal: d-th in-edge of placed row lo
+      // jagged diagonal: d-th in-edge of placed row lo (rank > 255 only in a plan that is marked overflowed)
+      const uint32_t mslot = (uint32_t)(jdp[rank < 256 ? rank : 255] + lo);
       const int idx = atomicAdd(&thist[bid], 1);
       unsigned char* ge = reinterpret_cast<unsigned char*>(&grp[tgb[bid] + (idx >> 2)]);
       ge[4 + (idx & 3)] = (unsigned char)srow;
@@ -809,7 +836,7 @@ int launch_plan(const PlanParams& pp, hipStream_t s) {
   if (pp.max_sub > kMaxHops)
     return fail(IMPNN_E_UNSUPPORTED, "encoder plan: %d chunk slots per workgroup", pp.max_sub);
   if (pp.typed)
-    plan_chunks_kernel<true><<<pp.nwg * pp.grid_sub, kRCap, sizeof(uint4) * (kTECap / 4 + pp.Vb), s>>>(pp);
+    plan_chunks_kernel<true><<<pp.nwg * pp.grid_sub, kRCap, sizeof(uint4) * tgrp_cap(pp.Vb, pp.ecap), s>>>(pp);
   else
     plan_chunks_kernel<false><<<pp.nwg * pp.grid_sub, kRCap, 0, s>>>(pp);
   return check_launch("plan_chunks");

@@ -28,25 +28,16 @@ namespace enc {
 
 namespace {
 
-__device__ __forceinline__ f32x4 mfma1(float a, float b, f32x4 c) {
-  // CBSZ = 3, ABID = 0: blocks 0-7 take A from block 0 (lanes 0-3), blocks 8-15 from block 8 (lanes 32-35)
-  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 3, 0, 0);
-}
-// A value the compiler treats as defined without emitting an instruction: the A operand of the lanes whose
-// block is not a broadcast source is never read by the hardware.
-__device__ __forceinline__ f32x4 any4() {
-  f32x4 v;
-  asm volatile("" : "=v"(v));
-  return v;
-}
-
 constexpr int kOffUpd = 0;
 constexpr int off_h(bool x3) { return kOffUpd + (x3 ? kXUpdLds : kTUpdLds); }
-constexpr int off_msg(bool x3) { return off_h(x3) + kRCap * kHS; }
-constexpr int off_rec(bool x3) { return off_msg(x3) + kTMsgFloats; }
-constexpr int off_tab(bool x3) { return off_rec(x3) + kTRecBytes / 4; }
-constexpr size_t lds_fixed_bytes(bool x3) { return sizeof(float) * (size_t)off_tab(x3); }
-static_assert(lds_fixed_bytes(true) <= 160 * 1024, "LDS budget");
+constexpr int off_msg(bool x3) { return off_h(x3) + kRCap * kTHS; }
+constexpr int off_rec(bool x3, int ecap) { return off_msg(x3) + tmsg_floats(ecap); }
+// then: the record (trec_lds_bytes(Vb, ecap)) and, when it fits, the atom table ((Va + 1) rows of kTAS floats)
+constexpr size_t lds_fixed_bytes(bool x3, int Vb, int ecap) {
+  return sizeof(float) * (size_t)off_rec(x3, ecap) + trec_lds_bytes(Vb, ecap);
+}
+static_assert(lds_fixed_bytes(true, kTVbMax, kTECap) <= 160 * 1024 && lds_fixed_bytes(false, kTVbMax, kTECapBig) <= 160 * 1024,
+              "LDS budget");
 
 // ---- mode 3 ("f32x3"): f32 GEMM products on the bf16 matrix pipe without narrowing them.  An f32 value is the exact
 // sum of three bf16 terms (bf16 keeps fp32's exponent; 3 x 8 significant bits): b0 = the upper half of the word, b1 =
@@ -87,22 +78,59 @@ __device__ __forceinline__ B3 split8x3(f32x4 a, f32x4 b) {
 __device__ __forceinline__ f32x4 mfmab(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
-// acc += W (three planes at blk, blk + 512, blk + 1024) * b: all nine cross products, smallest first.
-// (Alternating two accumulators over the nine products was measured: 31 spilled VGPRs, slower.)
-__device__ __forceinline__ void mma9(f32x4& acc, const __bf16* blk, int lane, const B3& b) {
-  const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(blk + lane * 8);
-  const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(blk + 512 + lane * 8);
-  const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(blk + 1024 + lane * 8);
-  acc = mfmab(a2, b.p2, acc);
-  acc = mfmab(a1, b.p2, acc);
-  acc = mfmab(a2, b.p1, acc);
-  acc = mfmab(a0, b.p2, acc);
-  acc = mfmab(a2, b.p0, acc);
-  acc = mfmab(a1, b.p1, acc);
-  acc = mfmab(a0, b.p1, acc);
-  acc = mfmab(a1, b.p0, acc);
-  acc = mfmab(a0, b.p0, acc);
+// c0 += W0 b, c1 += W1 b (W: three planes at blk, blk + 512, blk + 1024): all nine cross products, smallest first, the
+// two accumulator chains interleaved (a dependent v_mfma_f32_16x16x32_bf16 waits ~4 cycles for its predecessor).
+__device__ __forceinline__ void mma9x2(f32x4& c0, f32x4& c1, const __bf16* blk0, const __bf16* blk1, int lane, const B3& b) {
+  const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(blk0 + lane * 8);
+  const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(blk0 + 512 + lane * 8);
+  const bf16x8 a02 = *reinterpret_cast<const bf16x8*>(blk0 + 1024 + lane * 8);
+  const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(blk1 + lane * 8);
+  const bf16x8 a11 = *reinterpret_cast<const bf16x8*>(blk1 + 512 + lane * 8);
+  const bf16x8 a12 = *reinterpret_cast<const bf16x8*>(blk1 + 1024 + lane * 8);
+  c0 = mfmab(a02, b.p2, c0);  c1 = mfmab(a12, b.p2, c1);
+  c0 = mfmab(a01, b.p2, c0);  c1 = mfmab(a11, b.p2, c1);
+  c0 = mfmab(a02, b.p1, c0);  c1 = mfmab(a12, b.p1, c1);
+  c0 = mfmab(a00, b.p2, c0);  c1 = mfmab(a10, b.p2, c1);
+  c0 = mfmab(a02, b.p0, c0);  c1 = mfmab(a12, b.p0, c1);
+  c0 = mfmab(a01, b.p1, c0);  c1 = mfmab(a11, b.p1, c1);
+  c0 = mfmab(a00, b.p1, c0);  c1 = mfmab(a10, b.p1, c1);
+  c0 = mfmab(a01, b.p0, c0);  c1 = mfmab(a11, b.p0, c1);
+  c0 = mfmab(a00, b.p0, c0);  c1 = mfmab(a10, b.p0, c1);
 }
+
+// v_mfma_f32_4x4x1_16b_f32 with CBSZ = 3: the 16 blocks form two groups of 8 (lanes 0-31 / 32-63) and every block of a
+// group takes its A operand from block ABID of the group.  So ONE register carries the A operands of EIGHT
+// instructions: the 4 lanes of block b hold what instruction ABID = b multiplies.
+template <int ABID>
+__device__ __forceinline__ f32x4 mfma1(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 3, ABID, 0);
+}
+
+// One group of the message phase: its record entry and the A operands of its 16 MFMAs - lane l = 32 kh + 4 b + i holds
+// h[source row of edge i][16 kh + 2 b] and [.. + 2 b + 1]: one ds_read_b64 per lane, no lane idle, two registers.
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+struct Grp {
+  uint4 ge;
+  f32x2v aq;
+};
+// One type run: the matrix rows of this lane, and the run's first group (requested as soon as the run is known).
+struct Run {
+  f32x4 bq[4];
+  Grp first;
+};
+
+// Where the loads of the NEXT step are issued (diagnostics builds may override):
+//   kPfWhere   0: the step's update image at the top of its own message phase; 1: during the previous step's atom phase,
+//              in front of the GEMMs; 2: behind the GEMMs (registers are free there, the vector-memory path still idle)
+//   kRunsEarly how many of a wave's two fixed type runs (0-2) have their matrix rows requested in front of the previous
+//              step's GEMMs (16 VGPRs each through the GEMMs); the others at the top of the message phase
+#ifndef IMPNN_T_PF
+#define IMPNN_T_PF 0
+#endif
+#ifndef IMPNN_T_EARLY
+#define IMPNN_T_EARLY 0
+#endif
+constexpr int kPfWhere = IMPNN_T_PF, kRunsEarly = IMPNN_T_EARLY;
 
 template <bool STAMPS, bool X3>
 __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel(TEncParams p) {
@@ -110,21 +138,22 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
   constexpr int kUpdLds = X3 ? kXUpdLds : kTUpdLds, kUpdSlot = X3 ? kXUpdSlot : kTUpdSlot;
   constexpr int kNPf = X3 ? 3 : 2;  // 16-byte loads per thread that carry one update image
   float* const wupd = smem + kOffUpd;
-  float* const wvec = wupd + (X3 ? kXVecFloatOff : 3 * kD * kUpdRS);
+  float* const wvec = wupd + (X3 ? kXVecFloatOff : kTVecFloatOff);
   float* const hbuf = smem + off_h(X3);
   float* const msg = smem + off_msg(X3);
-  unsigned char* const recl = reinterpret_cast<unsigned char*>(smem + off_rec(X3));
-  float* const atab = smem + off_tab(X3);  // Va rows + one zero row at the h buffer's stride (when it fits)
+  const int zero_slot = p.ecap + 1;  // (dump slot: p.ecap)
+  unsigned char* const recl = reinterpret_cast<unsigned char*>(smem + off_rec(X3, p.ecap));
+  const int rec_lds = p.rec_lds;                                 // trec_lds_bytes(Vb)
+  float* const atab = reinterpret_cast<float*>(recl + rec_lds);  // Va rows + one zero row (when it fits)
   const uint16_t* const r_rowdeg = reinterpret_cast<const uint16_t*>(recl + kTRecRowdeg);
   const unsigned char* const r_tilemax = recl + kTRecTilemax;
   const uint16_t* const r_moloff = reinterpret_cast<const uint16_t*>(recl + kTRecMoloff);
   const uint16_t* const r_molrows = reinterpret_cast<const uint16_t*>(recl + kTRecMolrows);
   const uint16_t* const r_poolrow = reinterpret_cast<const uint16_t*>(recl + kTRecPoolrow);
   const int32_t* const r_rowatom = reinterpret_cast<const int32_t*>(recl + kTRecRowatom);
-  const uint16_t* const r_counts = reinterpret_cast<const uint16_t*>(recl + kTRecCounts);
   const uint16_t* const r_jdptr = reinterpret_cast<const uint16_t*>(recl + kTRecJdptr);
-  const uint16_t* const r_runs = reinterpret_cast<const uint16_t*>(recl + kTRecRuns);
-  int* const run_ctr = reinterpret_cast<int*>(recl + kTRecCounts + 8);  // next type run of the message phase
+  const uint16_t* const r_runs = reinterpret_cast<const uint16_t*>(recl + trec_runs_off(p.Vb, p.ecap));
+  int* const run_ctr = reinterpret_cast<int*>(recl + kTRecCounts + 8);  // next dynamically assigned type run
   const uint4* const r_grp = reinterpret_cast<const uint4*>(recl + kTRecGrp);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -134,11 +163,12 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
   if (stamp && tid == 0) stamp[0] = __builtin_amdgcn_s_memtime();
 
   // The workspace must hold a typed plan made for this launch geometry (impnn_encoder_plan with the same
-  // arguments): anything else would be read at wrong offsets.  A mismatch poisons the outputs instead.
+  // arguments): anything else would be read at wrong offsets.  A mismatch - or a batch the plan found it cannot
+  // cut into chunks (PlanHeader::overflow) - poisons the outputs instead.
   {
     const PlanHeader hd = *p.header;
     if (hd.magic != kPlanMagic || hd.kind != 1 || hd.nwg != (int)gridDim.x || hd.max_sub != p.max_sub ||
-        hd.B != p.B || hd.n_ions != p.n_ions) {
+        hd.B != p.B || hd.n_ions != p.n_ions || hd.overflow != 0) {
       const float nan = __builtin_nanf("");
       for (int g = 0; g < p.n_ions; ++g)
         for (int64_t t = (int64_t)blockIdx.x * kThreads + tid; t < (int64_t)p.B * kD; t += (int64_t)gridDim.x * kThreads)
@@ -151,20 +181,85 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
   if (c_begin >= c_end) return;
 
   if (p.atab_lds)
-    for (int t = tid; t < (p.Va + 1) * (kD / 4); t += kThreads) {
-      const int r = t >> 3, c = t & 7;
-      st4(atab + r * kHS + 4 * c, r < p.Va ? ld4(p.atom_table + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f});
-    }
+    for (int t = tid; t < (p.Va + 1) * (kTAS / 4); t += kThreads)  // kTAS == kD: a verbatim copy + one zero row
+      st4(atab + 4 * t, t < p.Va * (kD / 4) ? ld4(p.atom_table + 4 * t) : f32x4{0.f, 0.f, 0.f, 0.f});
+  if (tid < kD) msg[zero_slot * kD + tid] = 0.f;  // never written again: what a row reads beyond its in-degree
   unsigned long long t_pro = 0, t_steps = 0, t_pool = 0, t_mark = 0, t_msg = 0;
   if (stamp && tid == 0) t_mark = __builtin_amdgcn_s_memtime();
 
-  // The record of the NEXT chunk travels in three registers per thread while the current chunk runs; the step-0
-  // update image of the next chunk (same ion: a share never mixes ions) is what the last step's prefetch brings in.
+  // ---- GlobalSumPool (models/layers.py:161-164), as in encoder_fused.hip: eight lanes share one
+  //      (molecule, 4 features), ascending rows, then a fixed 3-step butterfly on the DPP network.
+  auto pool = [&](int M, int m0, int g) {
+    float* out_g = p.pooled[g];
+    for (int t0 = 0; t0 < M * 64; t0 += kThreads) {
+      const int t = t0 + tid;
+      const int part = t & 7, f4 = (t >> 3) & 7, m = t >> 6;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (m < M) {
+        const int nr = r_molrows[m], mo = r_moloff[m];
+        for (int n = part; n < nr; n += 8) {
+          const int pr = r_poolrow[mo + n];
+          if (pr & 0x8000) acc += ld4(hbuf + (pr & 0xff) * kTHS + 4 * f4);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = acc[i];
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+        acc[i] = v;
+      }
+      if (m < M && part == 0) st4(out_g + (int64_t)(m0 + m) * kD + 4 * f4, acc);
+    }
+  };
+  // h0 = atom_table[atom id of the placed row]: 4 threads per row, 2 x 16 B each; slack rows: zeros
+  auto fill_h0 = [&]() {
+    const int row = tid >> 2, sub = tid & 3;
+    const int id = r_rowatom[row];
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if ((unsigned)id < (unsigned)p.Va) {
+      if (p.atab_lds) {
+        v0 = ld4(atab + id * kTAS + 8 * sub);
+        v1 = ld4(atab + id * kTAS + 8 * sub + 4);
+      } else {
+        v0 = ld4(p.atom_table + (int64_t)id * kD + 8 * sub);
+        v1 = ld4(p.atom_table + (int64_t)id * kD + 8 * sub + 4);
+      }
+    }
+    st4(hbuf + row * kTHS + 8 * sub, v0);
+    st4(hbuf + row * kTHS + 8 * sub + 4, v1);
+  };
+
+  if (p.S == 0) {  // no message passing: pooled = GlobalSumPool(Embedding(atom ids)); kept apart from the step machinery
+    for (int c = c_begin; c < c_end; ++c) {
+      const unsigned char* rc = p.rec + (size_t)c * kTRecBytes;
+      if (8 * tid < rec_lds) reinterpret_cast<uint2*>(recl)[tid] = reinterpret_cast<const uint2*>(rc)[tid];
+      const int4 dsc = reinterpret_cast<const int4*>(p.desc)[c];
+      lds_barrier();
+      fill_h0();
+      lds_barrier();
+      pool(__builtin_amdgcn_readfirstlane(dsc.y), __builtin_amdgcn_readfirstlane(dsc.x),
+           __builtin_amdgcn_readfirstlane(dsc.w) >> 16);
+      lds_barrier();
+    }
+    return;
+  }
+
+  // The record of the NEXT chunk travels in registers while the current chunk runs.
+  const bool rec_big = rec_lds > kTRecPart1;  // workgroup-uniform
   const unsigned char* rec_c = p.rec + (size_t)c_begin * kTRecBytes;
   uint2 rec_n8 = reinterpret_cast<const uint2*>(rec_c)[tid];
-  uint32_t rec_n4 = reinterpret_cast<const uint32_t*>(rec_c + 8 * kThreads)[tid];
+  uint32_t rec_n4 = rec_big ? reinterpret_cast<const uint32_t*>(rec_c + kTRecPart1)[tid] : 0u;
   int4 dsc_next = reinterpret_cast<const int4*>(p.desc)[c_begin];
-  bool image_ready = false;
+
+  // message-phase lane roles (see the message phase below)
+  const uint32_t* const grp_x = reinterpret_cast<const uint32_t*>(r_grp);
+  const int kh = lane >> 5, f = lane & 31;
+  const int boff = kh * 512 + f * 4;
+  const int ysh = 8 * (lane & 3), zsh = 16 * kh;
+  const int acol = 16 * kh + 2 * ((lane >> 2) & 7);  // first of the two h columns this lane feeds (see Grp)
+
   for (int c = c_begin; c < c_end; ++c) {
     // ---- chunk prologue: descriptor, record -> LDS, h0 = atom_table[atom ids] (only without the LDS table)
     const int4 dsc = dsc_next;
@@ -174,58 +269,65 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
     const int ntiles = (R + 15) >> 4;
     const float* upd_g = p.upd[g];
     const float* tmat_g = p.tmat[g];
-    reinterpret_cast<uint2*>(recl)[tid] = rec_n8;
-    reinterpret_cast<uint32_t*>(recl + 8 * kThreads)[tid] = rec_n4;
+    if (8 * tid < rec_lds) reinterpret_cast<uint2*>(recl)[tid] = rec_n8;
+    if (rec_big && kTRecPart1 + 4 * tid < rec_lds) reinterpret_cast<uint32_t*>(recl + kTRecPart1)[tid] = rec_n4;
     {
       const int cn = (c + 1) < c_end ? (c + 1) : c;  // clamped: unconditional loads
       const unsigned char* rn = p.rec + (size_t)cn * kTRecBytes;
       rec_n8 = reinterpret_cast<const uint2*>(rn)[tid];
-      rec_n4 = reinterpret_cast<const uint32_t*>(rn + 8 * kThreads)[tid];
+      if (rec_big) rec_n4 = reinterpret_cast<const uint32_t*>(rn + kTRecPart1)[tid];
       dsc_next = reinterpret_cast<const int4*>(p.desc)[cn];
     }
-    f32x4 pf[kNPf];
-    const bool need_image = p.S > 0 && !image_ready;  // workgroup-uniform
-    if (need_image) {
-#pragma unroll
-      for (int i = 0; i < kNPf; ++i) pf[i] = ld4(upd_g + 4 * (tid + i * kThreads));
-    }
     lds_barrier();
-    if (!p.atab_lds || p.S == 0) {  // 4 threads per placed row, 2 x 16 B each; slack rows: zeros
-      const int row = tid >> 2, sub = tid & 3;
-      const int id = r_rowatom[row];
-      f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-      if ((unsigned)id < (unsigned)p.Va) {
-        if (p.atab_lds) {
-          v0 = ld4(atab + id * kHS + 8 * sub);
-          v1 = ld4(atab + id * kHS + 8 * sub + 4);
-        } else {
-          v0 = ld4(p.atom_table + (int64_t)id * kD + 8 * sub);
-          v1 = ld4(p.atom_table + (int64_t)id * kD + 8 * sub + 4);
-        }
-      }
-      st4(hbuf + row * kHS + 8 * sub, v0);
-      st4(hbuf + row * kHS + 8 * sub + 4, v1);
-    }
-    if (need_image) {
-#pragma unroll
-      for (int i = 0; i < kNPf; ++i)
-        if (4 * (tid + i * kThreads) < kUpdLds) st4(wupd + 4 * (tid + i * kThreads), pf[i]);
-    }
-    image_ready = p.S > 0;
-    if (tid == 0) *run_ctr = 0;  // (the record's bytes there are not written by the plan)
+    if (!p.atab_lds) fill_h0();
+    if (tid == 0) *run_ctr = 2 * kWaves;  // runs 0 .. 2 kWaves - 1 are assigned statically (two per wave)
     lds_barrier();
     if (stamp && tid == 0) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
       t_pro += t - t_mark;
       t_mark = t;
     }
+    const int nrun = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint16_t*>(recl + kTRecNrun));
 
+    // Two type runs per wave are in flight at any time (P, Q).  The first two of every step are fixed - runs `wave` and
+    // `wave + 16` of the chunk's run table, the same in all S steps - so their group range and bond type are resolved
+    // once per chunk, and their matrix rows for step s + 1 are requested during step s's atom phase, in front of the
+    // GEMMs: the vector-memory path, which bounds the message phase (~280 KB of matrix rows per chunk-step through one
+    // CU's L2 port), has nothing else to do there.  The step's update image travels the same way.
+    Run P, Q;
+    int gP = 0, nP = 0, gQ = 0, nQ = 0;
+    bool haveP = false, haveQ = false;
+    const bool sP = wave < nrun, sQ = wave + kWaves < nrun;
+    const int sgP = __builtin_amdgcn_readfirstlane(r_runs[sP ? wave : 0]);
+    const int snP = __builtin_amdgcn_readfirstlane(r_runs[(sP ? wave : 0) + 1]) - sgP;
+    const int sgQ = __builtin_amdgcn_readfirstlane(r_runs[sQ ? wave + kWaves : 0]);
+    const int snQ = __builtin_amdgcn_readfirstlane(r_runs[(sQ ? wave + kWaves : 0) + 1]) - sgQ;
+    // (matrix offset of the run's type; `have` false: four cache lines of type 0 that nobody uses - see `fetch`)
+    const int soP = sP ? (__builtin_amdgcn_readfirstlane(grp_x[4 * sgP]) & 0xff) * kTMatFloats : 0;
+    const int soQ = sQ ? (__builtin_amdgcn_readfirstlane(grp_x[4 * sgQ]) & 0xff) * kTMatFloats : 0;
+    const int lboffP = sP ? boff : 0, lboffQ = sQ ? boff : 0;
+    f32x4 pf[kNPf];
+    auto fetch_pf = [&](int s_) {  // update image of step s_
+#pragma unroll
+      for (int i = 0; i < kNPf; ++i) pf[i] = ld4(upd_g + (int64_t)s_ * kUpdSlot + 4 * (tid + i * kThreads));
+    };
+    auto fetch_P = [&](int s_) {  // matrix rows of the wave's first / second fixed run in step s_
+      const float* tm = tmat_g + (size_t)s_ * p.Vb * kTMatFloats;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) P.bq[i] = ld4(tm + soP + lboffP + i * 128);
+    };
+    auto fetch_Q = [&](int s_) {
+      const float* tm = tmat_g + (size_t)s_ * p.Vb * kTMatFloats;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Q.bq[i] = ld4(tm + soQ + lboffQ + i * 128);
+    };
+    // step 0: everything that later steps request during the previous atom phase is requested here
+    if (kPfWhere != 0) fetch_pf(0);
+    if (kRunsEarly >= 1) fetch_P(0);
+    if (kRunsEarly >= 2) fetch_Q(0);
     for (int s = 0; s < p.S; ++s) {
       const bool g0 = p.atab_lds && s == 0;  // step 0 reads h0 = atom_table[id] straight from the LDS table
-      const int sn = (s + 1) < p.S ? (s + 1) : 0;  // the last step fetches the step-0 image for the next chunk
-      const float* nxt = upd_g + (int64_t)sn * kUpdSlot;
       const float* tm_s = tmat_g + (size_t)s * p.Vb * kTMatFloats;
-
       // ---- message phase: m_e = A[type_e] h[src_e], one group of <= 4 edges of one bond type per 16 MFMAs.
       // v_mfma_f32_4x4x1_16b: 16 independent 4x4 blocks.  Block b < 8 accumulates, for feature quad b, the k < 16
       // half of the dot products of the group's 4 edges; block 8 + b the k >= 16 half:
@@ -233,105 +335,157 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
       // The edge operand h[src_i][k] comes from ONE block per half-wave (lanes 0-3 / 32-35) and is broadcast to the
       // other seven by CBSZ/ABID: 8 lanes read LDS, not 64.  The matrix operand of lane l is half a row of A[type]
       // (16 floats = 4 x 16 B, straight from L2).  All groups of a type run on one wave, so a type's 4 KB are
-      // fetched once per chunk-step, and the next type's matrix is in flight while the current one is used
-      // (two register sets, the type loop unrolled by two so that neither is ever copied).  The two k-halves meet in
-      // one v_permlane32_swap per edge pair; the sums go to the LDS message buffer in jagged-diagonal order.
+      // fetched once per chunk-step.  The two k-halves meet in one v_permlane32_swap per edge pair; the sums go to
+      // the LDS message buffer in jagged-diagonal order.
       // The f32 MFMA shares its issue port with the VALU (tools/ubench: no co-execution), so every VALU instruction in
       // this loop costs matrix time: the plan hands over ready-made LDS keys (message slot incl. swizzle; unused edge
       // lanes point at a dump slot, so the stores are unconditional) and the loop body is branch-free.
       __builtin_amdgcn_s_setprio(2);
       {
-        const uint32_t* const grp_x = reinterpret_cast<const uint32_t*>(r_grp);
-        const int kh = lane >> 5, f = lane & 31;
-        const bool feeds = f < 4;
-        const int boff = kh * 512 + f * 4;
-        const int aoff = (g0 ? (int)(atab - smem) : (int)(hbuf - smem)) + 16 * kh;
-        const int ysh = 8 * (lane & 3), zsh = 16 * kh;
-        auto run_type = [&](int g, int n, const f32x4 (&bq)[4]) {
-          for (int e = g; e < g + n; ++e) {
-            const uint4 ge = r_grp[e];
-            f32x4 aq[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) aq[i] = any4();
-            if (feeds) {
-              int src = __builtin_amdgcn_ubfe(ge.y, ysh, 8);
-              if (g0) {
-                const int id = r_rowatom[src];
-                src = (unsigned)id < (unsigned)p.Va ? id : p.Va;
-              }
-              const float* base = smem + src * kHS + aoff;
-#pragma unroll
-              for (int i = 0; i < 4; ++i) aq[i] = ld4(base + 4 * i);
-            }
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        const float* const abase = (g0 ? atab : hbuf) + acol;
+        const int astride = g0 ? kTAS : kTHS;
+        auto load_group = [&](int e, Grp& G) {
+          G.ge = r_grp[e];
+          int src = __builtin_amdgcn_ubfe(G.ge.y, ysh, 8);
+          if (g0) {
+            const int id = r_rowatom[src];
+            src = (unsigned)id < (unsigned)p.Va ? id : p.Va;
+          }
+          G.aq = *reinterpret_cast<const f32x2v*>(abase + src * astride);
+        };
+        auto compute = [&](const Grp& G, const f32x4 (&bq)[4]) {
+          f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
 #ifndef IMPNN_DIAG_NO_MSG_MFMA  // (diagnostics builds only: wrong results)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              acc0 = mfma1(aq[i][0], bq[i][0], acc0);
-              acc1 = mfma1(aq[i][1], bq[i][1], acc1);
-              acc0 = mfma1(aq[i][2], bq[i][2], acc0);
-              acc1 = mfma1(aq[i][3], bq[i][3], acc1);
-            }
+          // instruction k (= h column 16 kh + k): A from register k & 1, block k >> 1; B = the lane's matrix element k.
+          // (Two accumulator chains; four were measured: +4 % kernel time, the registers cost more than the s_nops.)
+          acc0 = mfma1<0>(G.aq[0], bq[0][0], acc0);
+          acc1 = mfma1<0>(G.aq[1], bq[0][1], acc1);
+          acc0 = mfma1<1>(G.aq[0], bq[0][2], acc0);
+          acc1 = mfma1<1>(G.aq[1], bq[0][3], acc1);
+          acc0 = mfma1<2>(G.aq[0], bq[1][0], acc0);
+          acc1 = mfma1<2>(G.aq[1], bq[1][1], acc1);
+          acc0 = mfma1<3>(G.aq[0], bq[1][2], acc0);
+          acc1 = mfma1<3>(G.aq[1], bq[1][3], acc1);
+          acc0 = mfma1<4>(G.aq[0], bq[2][0], acc0);
+          acc1 = mfma1<4>(G.aq[1], bq[2][1], acc1);
+          acc0 = mfma1<5>(G.aq[0], bq[2][2], acc0);
+          acc1 = mfma1<5>(G.aq[1], bq[2][3], acc1);
+          acc0 = mfma1<6>(G.aq[0], bq[3][0], acc0);
+          acc1 = mfma1<6>(G.aq[1], bq[3][1], acc1);
+          acc0 = mfma1<7>(G.aq[0], bq[3][2], acc0);
+          acc1 = mfma1<7>(G.aq[1], bq[3][3], acc1);
 #else
-            acc0[0] = aq[0][0] + bq[0][0] + aq[3][3] + bq[3][3];
-            acc1[1] = aq[1][1] + bq[1][1] + aq[2][2] + bq[2][2];
+          acc0[0] = G.aq[0] + bq[0][0] + bq[3][3];
+          acc1[1] = G.aq[1] + bq[1][1] + bq[2][2];
 #endif
-            acc0 += acc1;
-            // element i of lane l: edge i, feature l & 31, k-half l >> 5.
-            // v_permlane32_swap x, y: lanes 32-63 of x <-> lanes 0-31 of y.  Afterwards x = {x.lo, y.lo},
-            // y = {x.hi, y.hi}, so x + y is edge 0 (2) complete in lanes 0-31 and edge 1 (3) in lanes 32-63.
-            // (Inline asm: the compiler's builtin for this gfx950 instruction folded its two operands into one here.
-            //  The s_nop covers the VALU-write -> permlane-read wait states the assembler does not insert.)
-            float x0 = acc0[0], x1 = acc0[1], x2 = acc0[2], x3 = acc0[3];
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3"
-                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
-            msg[__builtin_amdgcn_ubfe(ge.z, zsh, 16) ^ f] = x0 + x1;
-            msg[__builtin_amdgcn_ubfe(ge.w, zsh, 16) ^ f] = x2 + x3;
+          acc0 += acc1;
+          // element i of lane l: edge i, feature l & 31, k-half l >> 5.
+          // v_permlane32_swap x, y: lanes 32-63 of x <-> lanes 0-31 of y.  Afterwards x = {x.lo, y.lo},
+          // y = {x.hi, y.hi}, so x + y is edge 0 (2) complete in lanes 0-31 and edge 1 (3) in lanes 32-63.
+          // (Inline asm: the compiler's builtin for this gfx950 instruction folded its two operands into one here.
+          //  The s_nop covers the VALU-write -> permlane-read wait states the assembler does not insert.)
+          float x0 = acc0[0], x1 = acc0[1], x2 = acc0[2], x3 = acc0[3];
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3"
+                       : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+          msg[__builtin_amdgcn_ubfe(G.ge.z, zsh, 16) ^ f] = x0 + x1;
+          msg[__builtin_amdgcn_ubfe(G.ge.w, zsh, 16) ^ f] = x2 + x3;
+        };
+        // A run's groups, software-pipelined: the operands of group e + 1 are requested from LDS in front of group e's
+        // MFMAs (two buffers, loop unrolled by two so that neither is ever copied); the first group's were requested
+        // when the run was taken.
+        auto run_type = [&](int g_, int n_, Run& Rn) {
+          const int end = g_ + n_;
+          Grp T;
+          int e = g_;
+          while (true) {
+            if (e + 1 < end) load_group(e + 1, T);
+            compute(Rn.first, Rn.bq);
+            if (++e >= end) break;
+            if (e + 1 < end) load_group(e + 1, Rn.first);
+            compute(T, Rn.bq);
+            if (++e >= end) break;
           }
         };
-        // Type runs are handed out one at a time through an LDS counter (the runs differ in length and in how long their
-        // matrix rows take to arrive; a static split left the slowest wave 20 % behind the median).  A wave holds two
-        // runs: the one it multiplies and the next one, whose matrix rows are already in flight (two register sets,
-        // loop unrolled by two so that neither is ever copied).
-        const int nrun = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const uint16_t*>(recl + kTRecNrun));
-        auto grab = [&](int& g, int& n, f32x4 (&bq)[4]) {  // -> false when the runs are used up
+        // Matrix rows of run r -> Rn.bq.  ALWAYS four loads: beyond the last run (`have` false) they read four cache
+        // lines of type 0 that nobody uses - the number of vector-memory operations in flight behind any fetch is
+        // then the same on every path, so the compiler can wait for a run's rows with a COUNTED s_waitcnt vmcnt(n)
+        // and leave the younger fetches in flight (vmcnt retires in order; with conditional loads it must drain).
+        auto fetch = [&](bool have, int r, int& g_, int& n_, Run& Rn, const float* tm) {
+          const int rc = have ? r : 0;
+          g_ = __builtin_amdgcn_readfirstlane(r_runs[rc]);
+          n_ = __builtin_amdgcn_readfirstlane(r_runs[rc + 1]) - g_;
+          const int type = have ? (__builtin_amdgcn_readfirstlane(grp_x[4 * g_]) & 0xff) : 0;
+          const float* bp = tm + (size_t)type * kTMatFloats + (have ? boff : 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) Rn.bq[i] = ld4(bp + i * 128);
+        };
+        // dynamically assigned runs (beyond the two static ones per wave) come from an LDS counter: the runs differ in
+        // length and in how long their matrix rows take to arrive (a static split left the slowest wave 20 % behind).
+        auto next_run = [&]() {
           int r = 0;
           if (lane == 0) r = atomicAdd(run_ctr, 1);
-          r = __builtin_amdgcn_readfirstlane(r);
-          if (r >= nrun) return false;
-          g = __builtin_amdgcn_readfirstlane(r_runs[r]);
-          n = __builtin_amdgcn_readfirstlane(r_runs[r + 1]) - g;
-          const int type = __builtin_amdgcn_readfirstlane(grp_x[4 * g]) & 0xff;
-          const float* bp = tm_s + (size_t)type * kTMatFloats + boff;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) bq[i] = ld4(bp + i * 128);
-          return true;
+          return __builtin_amdgcn_readfirstlane(r);
+        };
+        auto take = [&](int r, int& g_, int& n_, Run& Rn) {  // r < nrun
+          fetch(true, r, g_, n_, Rn, tm_s);
+          load_group(g_, Rn.first);
         };
         // `landed`: the rows are consumed here (an empty asm that reads and rewrites the registers), so the compiler
-        // places its s_waitcnt vmcnt HERE - before the next run's loads are issued.  vmcnt counts in order: waiting for
-        // the current rows after the prefetch has been issued would wait for the prefetch as well.
+        // places its s_waitcnt vmcnt HERE.
         auto landed = [](f32x4 (&b)[4]) {
           asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : : "memory");
         };
-        f32x4 bP[4], bQ[4];
-        int gP = 0, nP = 0, gQ = 0, nQ = 0;
-        bool haveP = grab(gP, nP, bP);
-        while (haveP) {
-          landed(bP);
-          const bool haveQ = grab(gQ, nQ, bQ);
-          run_type(gP, nP, bP);
-          if (!haveQ) break;
-          landed(bQ);
-          haveP = grab(gP, nP, bP);
-          run_type(gQ, nQ, bQ);
+        // the first two runs of a wave are fixed; the rest comes from the counter.  (Loads in program order on every
+        // path: image, P, Q - so that the counted waits below hold.)
+        if (kPfWhere == 0) fetch_pf(s);
+        if (kRunsEarly < 1) fetch_P(s);
+        if (kRunsEarly < 2) fetch_Q(s);
+        haveP = sP; gP = sgP; nP = snP;
+        haveQ = sQ; gQ = sgQ; nQ = snQ;
+        if (haveP) load_group(gP, P.first);
+        if (haveQ) load_group(gQ, Q.first);
+        // Runs are taken in the order P, Q, P, ... (run `wave + 16` exists only if run `wave` does).  Inside the loop
+        // every path issues the same loads in the same order, so each `landed` is a counted wait that leaves the other
+        // run's rows in flight; the first counter value beyond the last run leaves the loop through a tail that issues
+        // no loads at all.
+        if (haveP) {
+          if (!haveQ) {
+            landed(P.bq);
+            run_type(gP, nP, P);
+          } else {
+            while (true) {
+              landed(P.bq);
+              run_type(gP, nP, P);
+              const int rP = next_run();
+              if (rP >= nrun) {
+                landed(Q.bq);
+                run_type(gQ, nQ, Q);
+                break;
+              }
+              take(rP, gP, nP, P);
+              landed(Q.bq);
+              run_type(gQ, nQ, Q);
+              const int rQ = next_run();
+              if (rQ >= nrun) {
+                landed(P.bq);
+                run_type(gP, nP, P);
+                break;
+              }
+              take(rQ, gQ, nQ, Q);
+            }
+          }
         }
       }
+      // this step's update image -> LDS (ordered by the mid-step barrier)
+#pragma unroll
+      for (int i = 0; i < kNPf; ++i)
+        if (4 * (tid + i * kThreads) < kUpdLds) st4(wupd + 4 * (tid + i * kThreads), pf[i]);
       const bool mstamp = stamp && c == c_begin && s == 1;
       if (mstamp && lane == 0) stamp[16 + wave] = __builtin_amdgcn_s_memtime();
       // Mid-step barrier: every message is in LDS and every read of h by the message phase is done (h is updated in
-      // place below); the update image of this step, stored after the previous step's barrier, is in place too.
+      // place below); the update image of this step is in place too.
       lds_barrier();
-      if (tid == 0) *run_ctr = 0;  // for the next step's message phase (ordered by the end-of-step barrier)
+      if (tid == 0) *run_ctr = 2 * kWaves;  // for the next step's message phase (ordered by the end-of-step barrier)
       if (mstamp && tid == 0) stamp[12] = __builtin_amdgcn_s_memtime();
       if (stamp && tid == 0 && c == c_begin && s == 1) t_msg = __builtin_amdgcn_s_memtime();
 
@@ -348,34 +502,50 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
         }
       }
       const bool has_tile = my_tile >= 0 && my_tile < ntiles;
-      bool pf_issued = false;
       if (has_tile) {
         const int tile = my_tile;
         const int row = tile * 16 + a;
-        // ---- Reduce (models/layers.py:57-83): in-edge messages summed in edge-slot order
+        // ---- Reduce (models/layers.py:57-83): in-edge messages summed in edge-slot order, four in-edge ranks per
+        // round trip: the ranks a row does not have read the slot of zeros (x + 0 = x: no branch, every load of a
+        // round is in flight together).
         const int deg = r_rowdeg[row];
         const int maxdeg = __builtin_amdgcn_readfirstlane(r_tilemax[tile]);
         f32x4 agg0 = {0.f, 0.f, 0.f, 0.f}, agg1 = agg0;
-        for (int d = 0; d < maxdeg; ++d) {
-          if (d < deg) {
-            const int sl = r_jdptr[d] + row;
-            agg0 += ld4(msg + tmsg_off(sl, q));
-            agg1 += ld4(msg + tmsg_off(sl, 4 + q));
+        for (int d0 = 0; d0 < maxdeg; d0 += 4) {
+          const uint2 jd = *reinterpret_cast<const uint2*>(r_jdptr + d0);  // d0 + 3 <= 258 (u16[260] incl. padding)
+          int sl[4];
+          sl[0] = d0 + 0 < deg ? (int)(jd.x & 0xffffu) + row : zero_slot;
+          sl[1] = d0 + 1 < deg ? (int)(jd.x >> 16) + row : zero_slot;
+          sl[2] = d0 + 2 < deg ? (int)(jd.y & 0xffffu) + row : zero_slot;
+          sl[3] = d0 + 3 < deg ? (int)(jd.y >> 16) + row : zero_slot;
+          f32x4 m0v[4], m1v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int o = tmsg_off(sl[j], q);
+            m0v[j] = ld4(msg + o);
+            m1v[j] = ld4(msg + (o ^ 16));  // unit 4 + q of the same slot
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            agg0 += m0v[j];
+            agg1 += m1v[j];
           }
         }
+        if (mstamp && wave == 1 && lane == 0) stamp[8] = __builtin_amdgcn_s_memtime();
         __builtin_amdgcn_s_setprio(1);
-        int own = row * kHS + (int)(hbuf - smem);
+        if (s + 1 < p.S) {  // in flight under the GEMMs (see above)
+          if (kPfWhere == 1) fetch_pf(s + 1);
+          if (kRunsEarly >= 1) fetch_P(s + 1);
+          if (kRunsEarly >= 2) fetch_Q(s + 1);
+        }
+        int own = row * kTHS + (int)(hbuf - smem);
         if (g0) {
           const int id = r_rowatom[row];
-          own = ((unsigned)id < (unsigned)p.Va ? id : p.Va) * kHS + (int)(atab - smem);
+          own = ((unsigned)id < (unsigned)p.Va ? id : p.Va) * kTAS + (int)(atab - smem);
         }
         own += 4 * q;
         const f32x4 h0 = ld4(smem + own);
         const f32x4 h1 = ld4(smem + own + 16);
-        // next step's update image starts its flight now
-#pragma unroll
-        for (int i = 0; i < kNPf; ++i) pf[i] = ld4(nxt + 4 * (tid + i * kThreads));
-        pf_issued = true;
 
         // ---- gates z, r (models/layers.py:144-147) and candidate (:150-151): out^T = W^T [h | agg]^T
         f32x4 z0 = ld4(wvec + 0 * kD + 4 * q), z1 = ld4(wvec + 0 * kD + 16 + 4 * q);
@@ -385,64 +555,65 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
           const __bf16* wb = reinterpret_cast<const __bf16*>(wupd);  // block ((gate*2 + T)*2 + half): 3 x 512 bf16
           const B3 sh = split8x3(h0, h1);
           const B3 sa = split8x3(agg0, agg1);
-          mma9(z0, wb + ((0 * 2 + 0) * 2 + 0) * 1536, lane, sh);
-          mma9(z1, wb + ((0 * 2 + 1) * 2 + 0) * 1536, lane, sh);
-          mma9(r0, wb + ((1 * 2 + 0) * 2 + 0) * 1536, lane, sh);
-          mma9(r1, wb + ((1 * 2 + 1) * 2 + 0) * 1536, lane, sh);
-          mma9(z0, wb + ((0 * 2 + 0) * 2 + 1) * 1536, lane, sa);
-          mma9(z1, wb + ((0 * 2 + 1) * 2 + 1) * 1536, lane, sa);
-          mma9(r0, wb + ((1 * 2 + 0) * 2 + 1) * 1536, lane, sa);
-          mma9(r1, wb + ((1 * 2 + 1) * 2 + 1) * 1536, lane, sa);
+          mma9x2(z0, z1, wb + ((0 * 2 + 0) * 2 + 0) * 1536, wb + ((0 * 2 + 1) * 2 + 0) * 1536, lane, sh);
+          mma9x2(r0, r1, wb + ((1 * 2 + 0) * 2 + 0) * 1536, wb + ((1 * 2 + 1) * 2 + 0) * 1536, lane, sh);
+          mma9x2(z0, z1, wb + ((0 * 2 + 0) * 2 + 1) * 1536, wb + ((0 * 2 + 1) * 2 + 1) * 1536, lane, sa);
+          mma9x2(r0, r1, wb + ((1 * 2 + 0) * 2 + 1) * 1536, wb + ((1 * 2 + 1) * 2 + 1) * 1536, lane, sa);
           z0 = sigmoid4<false>(z0);
           z1 = sigmoid4<false>(z1);
           const f32x4 rh0 = sigmoid4<false>(r0) * h0;  // :149
           const f32x4 rh1 = sigmoid4<false>(r1) * h1;
           const B3 srh = split8x3(rh0, rh1);
-          mma9(t0, wb + ((2 * 2 + 0) * 2 + 0) * 1536, lane, srh);
-          mma9(t1, wb + ((2 * 2 + 1) * 2 + 0) * 1536, lane, srh);
-          mma9(t0, wb + ((2 * 2 + 0) * 2 + 1) * 1536, lane, sa);
-          mma9(t1, wb + ((2 * 2 + 1) * 2 + 1) * 1536, lane, sa);
+          mma9x2(t0, t1, wb + ((2 * 2 + 0) * 2 + 0) * 1536, wb + ((2 * 2 + 1) * 2 + 0) * 1536, lane, srh);
+          mma9x2(t0, t1, wb + ((2 * 2 + 0) * 2 + 1) * 1536, wb + ((2 * 2 + 1) * 2 + 1) * 1536, lane, sa);
         } else {
+          // A operands: block ((gate*2 + T)*2 + half)*2 + u of the image, 16 B per lane, lane-linear (conflict-free)
+          const float* wl = wupd + 4 * lane;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+          for (int half = 0; half < 2; ++half) {
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int col = 32 * half + 16 * u + 4 * q;
-            const f32x4 Az0 = ld4(wupd + (0 * kD + a) * kUpdRS + col);
-            const f32x4 Az1 = ld4(wupd + (0 * kD + 16 + a) * kUpdRS + col);
-            const f32x4 Ar0 = ld4(wupd + (1 * kD + a) * kUpdRS + col);
-            const f32x4 Ar1 = ld4(wupd + (1 * kD + 16 + a) * kUpdRS + col);
-            const f32x4 Bv = half == 0 ? (u == 0 ? h0 : h1) : (u == 0 ? agg0 : agg1);
+            for (int u = 0; u < 2; ++u) {
+              const int hu = half * 2 + u;
+              const f32x4 Az0 = ld4(wl + ((0 * 2 + 0) * 4 + hu) * 256);
+              const f32x4 Az1 = ld4(wl + ((0 * 2 + 1) * 4 + hu) * 256);
+              const f32x4 Ar0 = ld4(wl + ((1 * 2 + 0) * 4 + hu) * 256);
+              const f32x4 Ar1 = ld4(wl + ((1 * 2 + 1) * 4 + hu) * 256);
+              const f32x4 Bv = half == 0 ? (u == 0 ? h0 : h1) : (u == 0 ? agg0 : agg1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              z0 = mfma4(Az0[r], Bv[r], z0);
-              z1 = mfma4(Az1[r], Bv[r], z1);
-              r0 = mfma4(Ar0[r], Bv[r], r0);
-              r1 = mfma4(Ar1[r], Bv[r], r1);
+              for (int r = 0; r < 4; ++r) {
+                z0 = mfma4(Az0[r], Bv[r], z0);
+                z1 = mfma4(Az1[r], Bv[r], z1);
+                r0 = mfma4(Ar0[r], Bv[r], r0);
+                r1 = mfma4(Ar1[r], Bv[r], r1);
+              }
             }
           }
-        }
-        z0 = sigmoid4<false>(z0);
-        z1 = sigmoid4<false>(z1);
-        const f32x4 rh0 = sigmoid4<false>(r0) * h0;  // :149
-        const f32x4 rh1 = sigmoid4<false>(r1) * h1;
+          z0 = sigmoid4<false>(z0);
+          z1 = sigmoid4<false>(z1);
+          const f32x4 rh0 = sigmoid4<false>(r0) * h0;  // :149
+          const f32x4 rh1 = sigmoid4<false>(r1) * h1;
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+          for (int half = 0; half < 2; ++half) {
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int col = 32 * half + 16 * u + 4 * q;
-            const f32x4 Ah0 = ld4(wupd + (2 * kD + a) * kUpdRS + col);
-            const f32x4 Ah1 = ld4(wupd + (2 * kD + 16 + a) * kUpdRS + col);
-            const f32x4 Bv = half == 0 ? (u == 0 ? rh0 : rh1) : (u == 0 ? agg0 : agg1);
+            for (int u = 0; u < 2; ++u) {
+              const int hu = half * 2 + u;
+              const f32x4 Ah0 = ld4(wl + ((2 * 2 + 0) * 4 + hu) * 256);
+              const f32x4 Ah1 = ld4(wl + ((2 * 2 + 1) * 4 + hu) * 256);
+              const f32x4 Bv = half == 0 ? (u == 0 ? rh0 : rh1) : (u == 0 ? agg0 : agg1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              t0 = mfma4(Ah0[r], Bv[r], t0);
-              t1 = mfma4(Ah1[r], Bv[r], t1);
+              for (int r = 0; r < 4; ++r) {
+                t0 = mfma4(Ah0[r], Bv[r], t0);
+                t1 = mfma4(Ah1[r], Bv[r], t1);
+              }
             }
           }
-        }
         }
         __builtin_amdgcn_s_setprio(0);
+        if (kPfWhere == 2 && s + 1 < p.S) {
+          asm volatile("" ::: "memory");  // behind the GEMMs: their registers are free only now
+          fetch_pf(s + 1);
+        }
+        if (mstamp && wave == 1 && lane == 0) stamp[9] = __builtin_amdgcn_s_memtime();
         // ---- blend, LayerNorm, residual  (models/layers.py:153-155); (1-z) h + z t == h + z (t - h)
         f32x4 n0 = z0 * (tanh4<false>(t0) - h0) + h0;
         f32x4 n1 = z1 * (tanh4<false>(t1) - h1) + h1;
@@ -462,17 +633,19 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
         const f32x4 bt0 = ld4(wvec + 4 * kD + 4 * q), bt1 = ld4(wvec + 4 * kD + 16 + 4 * q);
         const f32x4 o0 = n0 * (gm0 * inv) + (bt0 + h0);
         const f32x4 o1 = n1 * (gm1 * inv) + (bt1 + h1);
-        st4(hbuf + row * kHS + 4 * q, o0);
-        st4(hbuf + row * kHS + 16 + 4 * q, o1);
+        st4(hbuf + row * kTHS + 4 * q, o0);
+        st4(hbuf + row * kTHS + 16 + 4 * q, o1);
+        if (mstamp && wave == 1 && lane == 0) stamp[10] = __builtin_amdgcn_s_memtime();
       }
-      if (!pf_issued) {  // waves without a tile in this chunk still carry their share of the image
-#pragma unroll
-        for (int i = 0; i < kNPf; ++i) pf[i] = ld4(nxt + 4 * (tid + i * kThreads));
+      if (!has_tile && s + 1 < p.S) {  // waves without a tile in this chunk
+        if (kPfWhere != 0) fetch_pf(s + 1);
+        if (kRunsEarly >= 1) fetch_P(s + 1);
+        if (kRunsEarly >= 2) fetch_Q(s + 1);
       }
-      __syncthreads();
-#pragma unroll
-      for (int i = 0; i < kNPf; ++i)
-        if (4 * (tid + i * kThreads) < kUpdLds) st4(wupd + 4 * (tid + i * kThreads), pf[i]);
+      if (mstamp && wave == 1 && lane == 0) stamp[11] = __builtin_amdgcn_s_memtime();
+      // End-of-step barrier: every row of h is updated, every read of the message buffer and of the update image is
+      // done.  (LDS traffic only: the run prefetch above stays in flight across it.)
+      lds_barrier();
       if (stamp && c == c_begin && s < 2 && tid == 0) stamp[14 + s] = __builtin_amdgcn_s_memtime();
     }
     if (stamp && tid == 0) {
@@ -481,30 +654,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
       t_mark = t;
     }
 
-    // ---- GlobalSumPool (models/layers.py:161-164), as in encoder_fused.hip: eight lanes share one
-    //      (molecule, 4 features), ascending rows, then a fixed 3-step butterfly on the DPP network.
-    float* out_g = p.pooled[g];
-    for (int t0 = 0; t0 < M * 64; t0 += kThreads) {
-      const int t = t0 + tid;
-      const int part = t & 7, f4 = (t >> 3) & 7, m = t >> 6;
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      if (m < M) {
-        const int nr = r_molrows[m], mo = r_moloff[m];
-        for (int n = part; n < nr; n += 8) {
-          const int pr = r_poolrow[mo + n];
-          if (pr & 0x8000) acc += ld4(hbuf + (pr & 0xff) * kHS + 4 * f4);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v = acc[i];
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));
-        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
-        acc[i] = v;
-      }
-      if (m < M && part == 0) st4(out_g + (int64_t)(m0 + m) * kD + 4 * f4, acc);
-    }
+    pool(M, m0, g);
     lds_barrier();  // the record / h buffers are rewritten by the next chunk's prologue
     if (stamp && tid == 0) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
@@ -528,10 +678,12 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
 bool encoder_typed_supported(int N, int E, int D, int S, int Vb) {
   using namespace enc;
   if (D != kD || S < 0) return false;
-  if (N < 1 || N > 0xffff || E < 0 || E > 255) return false;  // in-degrees travel as 8 bits in the plan
+  // Any padded shape: what bounds a chunk is what a molecule HOLDS - kept rows <= 256, valid edges <= 512, in-degrees
+  // <= 255 (640 valid edges for padded E > 512) - and that is checked per batch by the plan kernels
+  // (PlanHeader::overflow), not here.
+  if (N < 1 || N > 0xffff || E < 0 || E > 0xffff) return false;
   if (Vb < 1 || Vb > kTVbMax) return false;
-  if (vr_max_of(N, E, true) > kRCap / 2) return false;
-  return true;
+  return true;  // (mode 3 takes E <= 512 only: encoder_fused_supported)
 }
 
 size_t encoder_typed_prepared_bytes(int S, int Vb, bool x3) {
@@ -588,11 +740,13 @@ int launch_encoder_typed_run(const EncoderArgs& a, const enc::Ws& w, hipStream_t
     if (sp && sb >= (size_t)w.nwg * 32 * sizeof(unsigned long long)) ep.stamps = static_cast<unsigned long long*>(sp);
   }
   ep.upd_slot = (int)uslot;
+  ep.ecap = tecap_of(a.E);
+  ep.rec_lds = trec_lds_bytes(a.Vb, ep.ecap);
   void (*kern)(TEncParams) = x3 ? (ep.stamps ? encoder_typed_kernel<true, true> : encoder_typed_kernel<false, true>)
                                 : (ep.stamps ? encoder_typed_kernel<true, false> : encoder_typed_kernel<false, false>);
   if (int rc = ensure_lds_limit((const void*)kern, (ep.stamps ? 5 : 4) + (x3 ? 2 : 0))) return rc;
-  size_t lds = lds_fixed_bytes(x3);
-  const size_t atab_bytes = ((size_t)a.Va + 1) * kHS * sizeof(float);
+  size_t lds = lds_fixed_bytes(x3, a.Vb, ep.ecap);
+  const size_t atab_bytes = ((size_t)a.Va + 1) * kTAS * sizeof(float);
   ep.atab_lds = lds + atab_bytes <= 160 * 1024;
   if (ep.atab_lds) lds += atab_bytes;
   profile_record_start(s);

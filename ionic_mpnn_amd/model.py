@@ -376,10 +376,15 @@ class MPNNModel:
             if mode is None:
                 raise ops.EncoderUnsupported("no fused encoder mode covers this model / batch shape")
             prepared = self._prepared_weights(mode) if self.num_steps > 0 else None
-            pc, pa = ops.encoder_fused([(ca, cb, cc), (aa, ab, ac)], self.atom_emb.embeddings,
-                                       self.bond_emb.embeddings, None if prepared else self._packed_weights(),
-                                       self.num_steps, mode=mode, prepared=prepared,
-                                       workgroups=self.encoder_workgroups)
+            try:
+                pc, pa = ops.encoder_fused([(ca, cb, cc), (aa, ab, ac)], self.atom_emb.embeddings,
+                                           self.bond_emb.embeddings, None if prepared else self._packed_weights(),
+                                           self.num_steps, mode=mode, prepared=prepared,
+                                           workgroups=self.encoder_workgroups)
+            except ops.EncoderOverflow:
+                # a molecule of THIS batch exceeds a chunk (possible only for N > 256 or E > 255): layer at a time
+                self.overflow_fallbacks = getattr(self, "overflow_fallbacks", 0) + 1
+                return self.encode_pooled(inputs, fused=False, trace=trace)
             if trace is not None:
                 trace["cat/pooled"], trace["an/pooled"] = pc, pa
             return pc, pa

@@ -330,8 +330,26 @@ def encoder_fused_supported(N, E, D, K, S, Vb, mode="f32t"):
     return rc == 0
 
 
+def encoder_overflow_possible(N, E, D, mode):
+    """Can a batch of this padded shape hold a molecule that does not fit one chunk of the typed D = 32 encoder (more than
+    256 kept rows, more than 512 valid edges, an in-degree above 255)?  Only then is the plan's overflow word read back
+    (one 4-byte device-to-host copy per call)."""
+    return D == 32 and mode in ("f32t", "f32x3") and (N > 256 or E > 255)
+
+
+def _raise_on_overflow(ws):
+    off = int(_lib.load().impnn_encoder_plan_overflow_offset())
+    if int(ws[off:off + 4].view(torch.int32).item()) != 0:
+        raise EncoderOverflow("a molecule of this batch does not fit one chunk of the fused encoder "
+                              "(> 256 kept rows, > 512 valid edges or an in-degree > 255)")
+
+
 class EncoderUnsupported(RuntimeError):
     pass
+
+
+class EncoderOverflow(EncoderUnsupported):
+    """The shape is covered, this BATCH is not (PlanHeader::overflow): the caller takes the layer-at-a-time path."""
 
 
 def split_mode_degree_limit(atom_table, bond_table, steps, D):
@@ -440,6 +458,8 @@ def encoder_fused(ions, atom_table, bond_table, packed_weights, num_steps, eps=L
                     raise ValueError(f"packed step weights must hold S*{step_f} floats")
             check(lib.impnn_encoder_fused(n, *common, mk(ws_w), mode_i, mk(pooled), B, N, E, D, K, S, float(eps), wgs,
                                           ptr(ws), ws.numel(), stream_ptr()))
+    if B > 0 and encoder_overflow_possible(N, E, D, mode):
+        _raise_on_overflow(ws)
     return pooled
 
 
@@ -523,6 +543,8 @@ class EncoderPipeline:
             done = torch.cuda.Event()
             done.record(cur)
         plan.slot["done"] = done
+        if B > 0 and encoder_overflow_possible(N, E, D, mode):
+            _raise_on_overflow(ws)
         return pooled
 
 

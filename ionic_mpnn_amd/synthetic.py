@@ -81,6 +81,84 @@ def make_batch(batch, max_atoms=40, max_edges=80, atom_vocab_size=DEFAULT_VA,
     return out
 
 
+def _one_ion_explicit_h(rng, B, N, E, Va, Vb, min_atoms, max_atoms, max_degree=4):
+    """Explicit-hydrogen-like molecules as the reference's trainers hand them to the model: featurize.py:45,54-63
+    adds hydrogens and lists every bond in both directions; preprocess_edges_and_bonds (utils/mp_utils.py:18-45,
+    train_viscosity.py:76-110) then follows every listed (src, tgt) with its reverse and repeats the bond id - FOUR
+    edge slots per bond, (u,v),(v,u),(v,u),(u,v) - and pads to E = 2 * max(len(edge_indices)) = 4 * max_bonds slots
+    (train_viscosity.py:288-289).  Skeleton: a random tree with atom degree <= max_degree plus up to two ring closures,
+    so in-degrees stay <= 2 * max_degree."""
+    max_atoms = min(max_atoms, N, E // 4)  # n - 1 tree bonds + rings must fit the slots
+    n = rng.integers(min(min_atoms, max_atoms), max_atoms + 1, size=B)
+    atom_ids = np.where(np.arange(N)[None, :] < n[:, None], rng.integers(1, Va, size=(B, N)), 0).astype(np.int32)
+    deg = np.zeros((B, N), dtype=np.int64)
+    par = np.zeros((B, N), dtype=np.int64)
+    rows = np.arange(B)
+    for v in range(1, N):
+        u = np.floor(rng.random(B) * v).astype(np.int64)
+        for _ in range(8):  # re-draw parents that are saturated
+            full = deg[rows, u] >= max_degree
+            if not full.any():
+                break
+            u = np.where(full, np.floor(rng.random(B) * v).astype(np.int64), u)
+        full = deg[rows, u] >= max_degree
+        if full.any():  # first unsaturated earlier atom (a tree of v atoms always has one)
+            first = np.argmax(deg[:, :v] < max_degree, axis=1)
+            u = np.where(full, first, u)
+        live = v < n
+        par[:, v] = u
+        deg[rows[live], u[live]] += 1
+        deg[rows[live], v] += 1
+    nb_slots = E // 4
+    bu = np.zeros((B, nb_slots), dtype=np.int64)
+    bv = np.zeros((B, nb_slots), dtype=np.int64)
+    bvalid = np.zeros((B, nb_slots), dtype=bool)
+    jt = min(N - 1, nb_slots)
+    vv = np.arange(1, jt + 1)
+    bu[:, :jt] = par[:, 1:jt + 1]
+    bv[:, :jt] = vv[None, :]
+    bvalid[:, :jt] = vv[None, :] < n[:, None]
+    for ring in range(2):  # ring closures between unsaturated atoms, in the slots after the tree bonds
+        cu = np.floor(rng.random(B) * n).astype(np.int64)
+        cv = np.floor(rng.random(B) * n).astype(np.int64)
+        slot = n - 1 + ring
+        ok = (cu != cv) & (par[rows, cv] != cu) & (par[rows, cu] != cv) & (slot < nb_slots) \
+            & (deg[rows, cu] < max_degree) & (deg[rows, cv] < max_degree)
+        slot = np.minimum(slot, nb_slots - 1)
+        bu[rows[ok], slot[ok]] = cu[ok]
+        bv[rows[ok], slot[ok]] = cv[ok]
+        bvalid[rows[ok], slot[ok]] = True
+        deg[rows[ok], cu[ok]] += 1
+        deg[rows[ok], cv[ok]] += 1
+    bid = np.where(bvalid, rng.integers(1, Vb, size=(B, nb_slots)), 0)
+    bu = np.where(bvalid, bu, 0)
+    bv = np.where(bvalid, bv, 0)
+    # the ring slot may sit beyond a gap-free prefix only when a ring was refused: compact nothing, the reference's
+    # lists are gap-free but padding slots in the middle are legal inputs too ([0,0] / bond 0 = masked, layers.py:114)
+    conn = np.zeros((B, E, 2), dtype=np.int32)
+    bond = np.zeros((B, E), dtype=np.int32)
+    for k, (s_, t_) in enumerate(((bu, bv), (bv, bu), (bv, bu), (bu, bv))):
+        conn[:, k:4 * nb_slots:4, 0] = s_
+        conn[:, k:4 * nb_slots:4, 1] = t_
+        bond[:, k:4 * nb_slots:4] = bid
+    return atom_ids, bond, conn
+
+
+def make_explicit_h_batch(batch, max_atoms=160, max_edges=640, atom_vocab_size=DEFAULT_VA, bond_vocab_size=DEFAULT_VB,
+                          min_atoms=20, seed=0, with_temperature=True):
+    """As make_batch, for the padded shapes of the reference's real (explicit-hydrogen) data sets: up to `max_atoms`
+    atoms of degree <= 4, every bond in four edge slots, E = 4 * max_bonds (see _one_ion_explicit_h)."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for p in ("cat", "an"):
+        a, b, c = _one_ion_explicit_h(rng, batch, max_atoms, max_edges, atom_vocab_size, bond_vocab_size, min_atoms,
+                                      max_atoms)
+        out[f"{p}_atom"], out[f"{p}_bond"], out[f"{p}_connectivity"] = a, b, c
+    if with_temperature:
+        out["temperature"] = rng.uniform(253.0, 393.0, size=(batch, 1)).astype(np.float32)
+    return out
+
+
 def make_id_records(num, seed=0, min_atoms=3, max_atoms=12, atom_vocab=20, bond_vocab=6, kind="viscosity"):
     """Synthetic ``*_id_data.pkl`` records in the schema of src/dataset.py:15-20,51-62
     (0-based ids, featurize-style bidirectional edge list, python lists)."""

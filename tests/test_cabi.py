@@ -72,7 +72,12 @@ def test_encoder_shape_coverage_is_reported():
     assert lib.impnn_encoder_workspace_bytes(2, 8192, 40, 80, 32, 1024, 4, 72, TYPED, 0, C.byref(need)) == 0
     assert lib.impnn_encoder_workspace_bytes(2, 4096, 40, 80, 32, 1024, 3, 72, F32, 0, C.byref(need)) == -2
     assert b"not covered" in lib.impnn_last_error_string()
-    assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 300, 32, 8, 3, 72, TYPED, 0, C.byref(need)) == -2   # E > 255
+    # the typed records take any padded shape (explicit-H molecules: N = 160, E = 640, train_viscosity.py:288-289): a
+    # chunk is bounded by what a molecule HOLDS, checked per batch by the plan kernels (round 3); K = D^2 included
+    assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 300, 32, 8, 3, 72, TYPED, 0, C.byref(need)) == 0
+    assert lib.impnn_encoder_workspace_bytes(2, 4096, 160, 640, 32, 8, 3, 72, TYPED, 0, C.byref(need)) == 0 and need.value > 0
+    assert lib.impnn_encoder_workspace_bytes(2, 4096, 160, 640, 32, 1024, 4, 72, TYPED, 0, C.byref(need)) == 0 and need.value > 0
+    assert lib.impnn_encoder_workspace_bytes(2, 4096, 160, 640, 32, 8, 3, 72, F32, 0, C.byref(need)) == -2   # pull form: N <= 128
     assert lib.impnn_encoder_workspace_bytes(3, 16, 40, 80, 32, 8, 3, 72, F32, 0, C.byref(need)) == -1
     assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 80, 32, 8, 3, 72, 3, 0, C.byref(need)) == 0        # f32x3
     assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 80, 32, 8, 3, 72, 4, 0, C.byref(need)) == -1       # no mode 4

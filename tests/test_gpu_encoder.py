@@ -57,9 +57,6 @@ def test_fused_encoder_random_shapes(N, E, K, S, B, seed, mode):
                                min_atoms=min(3, N), seed=seed)
     w = weights.init_weights("viscosity", Va, Vb, atom_dim=32, bond_dim=K, num_steps=S, seed=seed + 100, perturb=True)
     m = make_model(w, Va, Vb, K=K, mode=mode)
-    if mode in ("f32t", "f32x3") and E > 255:
-        assert not m.fused_supported(N, E)  # typed records carry in-degrees as 8 bits; "auto" takes the pull form
-        m.encoder_mode = "auto"
     assert m.fused_supported(N, E)
     pc, pa = m.encode_pooled(to_dev(inp), fused=True)
     rc = O.encode(w, "cat", inp["cat_atom"], inp["cat_bond"], inp["cat_connectivity"], pooled_only=True)
@@ -244,7 +241,7 @@ def test_mode_resolution_exact_by_default_split_only_inside_its_range_bound():
     w = weights.init_weights("viscosity", synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, num_steps=3, seed=1)
     m = make_model(w, synthetic.DEFAULT_VA, synthetic.DEFAULT_VB)
     assert m.resolve_encoder_mode(40, 80) == "f32t"
-    assert m.resolve_encoder_mode(40, 300) == "f32"      # E > 255: outside the typed records, pull form covers it
+    assert m.resolve_encoder_mode(40, 300) == "f32t"     # any padded shape since round 3 (per-batch checks in the plan)
     m.encoder_mode = "f16x2"
     assert m.resolve_encoder_mode(40, 80) == "f16x2" and m._split_deg_limit > 80
     big = dict(w)
@@ -543,3 +540,98 @@ def test_f32x3_is_as_accurate_as_the_f32_mfma():
     for i in range(3):
         assert err["f32x3"][i] <= 2.0 * err["f32t"][i] + 1e-7, err
     assert err["f32x3"][0] <= 1e-5 and err["f32t"][0] <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 3: the padded shapes of the reference's real (explicit-hydrogen) data sets.  featurize.py:45 adds hydrogens and
+# the trainers pad to E = 4 * max_bonds edge slots (train_viscosity.py:95,288-289): N = 160, E = 640 here.  The typed
+# encoder bounds a chunk by what a molecule HOLDS (plan kernels, per batch), not by the padded shape.
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind,K,S", [("viscosity", 8, 3), ("melting_point", 1024, 4)])
+def test_explicit_h_shape_runs_in_the_typed_encoder(kind, K, S):
+    Va, Vb, B, N, E = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, 4096, 160, 640
+    inp = synthetic.make_explicit_h_batch(B, max_atoms=N, max_edges=E, seed=41, with_temperature=(kind == "viscosity"))
+    valid = (inp["cat_connectivity"][:, :, 0] > 0) & (inp["cat_connectivity"][:, :, 1] > 0)
+    assert valid.sum(axis=1).max() > 512 and (inp["cat_atom"] > 0).sum(axis=1).max() > 128  # beyond round 2's limits
+    w = weights.init_weights(kind, Va, Vb, atom_dim=32, bond_dim=K, num_steps=S, seed=42, perturb=True)
+    if kind == "viscosity":
+        m = MM.build_model(Va, Vb, atom_dim=32, bond_dim=K, num_steps=S, device=DEV)
+    else:
+        m = MM.build_melting_point_model(Va, Vb, atom_dim=32, num_steps=S, device=DEV)   # bond_dim = 32 ** 2
+    m.load_weights(w)
+    assert m.bond_dim == K and m.resolve_encoder_mode(N, E) == "f32t"
+    d = to_dev(inp)
+    pc, pa = m.encode_pooled(d, fused=True)
+    torch.cuda.synchronize()
+    assert getattr(m, "overflow_fallbacks", 0) == 0          # every molecule fits a chunk: the fused kernel ran
+    assert torch.isfinite(pc).all() and torch.isfinite(pa).all()
+    idx = np.random.default_rng(7).choice(B, size=20, replace=False)
+    idx[0] = int(valid.sum(axis=1).argmax())                   # the largest cation is in the sample
+    sub = {k: v[idx] for k, v in inp.items()}
+    rc = O.encode(w, "cat", sub["cat_atom"], sub["cat_bond"], sub["cat_connectivity"], pooled_only=True)
+    ra = O.encode(w, "an", sub["an_atom"], sub["an_bond"], sub["an_connectivity"], pooled_only=True)
+    assert_close(pc.cpu().numpy()[idx], rc, what="explicit-H cat pooled (sample)")
+    assert_close(pa.cpu().numpy()[idx], ra, what="explicit-H an pooled (sample)")
+    # batch shards recomputed separately are the same rows bit for bit
+    h = B // 2 + 17
+    c0, a0 = m.encode_pooled({k: v[:h].contiguous() for k, v in d.items()}, fused=True)
+    c1, a1 = m.encode_pooled({k: v[h:].contiguous() for k, v in d.items()}, fused=True)
+    assert torch.equal(torch.cat([c0, c1]), pc) and torch.equal(torch.cat([a0, a1]), pa)
+    # and the layer-at-a-time HIP path agrees
+    lc, la = m.encode_pooled({k: v[:64].contiguous() for k, v in d.items()}, fused=False)
+    assert_close(lc.cpu().numpy(), pc[:64].cpu().numpy(), what="explicit-H layered vs fused cat")
+    assert_close(la.cpu().numpy(), pa[:64].cpu().numpy(), what="explicit-H layered vs fused an")
+
+
+def test_molecule_beyond_a_chunk_is_flagged_and_falls_back():
+    """A molecule that truly exceeds a chunk (here: 700 valid edges in E = 800 slots; 300 kept rows) makes the plan raise
+    its overflow word: the fused entry returns NaN + EncoderOverflow, the model takes the layer-at-a-time path for
+    that batch and the answer is the oracle's."""
+    Va, Vb, B = 30, 11, 12
+    for N, E, fat in ((200, 800, "edges"), (300, 400, "rows"), (40, 600, "indegree")):
+        inp = synthetic.make_batch(B, max_atoms=min(N, 60), max_edges=80, atom_vocab_size=Va, bond_vocab_size=Vb, seed=5)
+        pad = lambda a, shape: np.pad(a, [(0, t - s_) for s_, t in zip(a.shape, shape)])
+        inp = {k: (pad(v, (B, N)) if k.endswith("atom") else pad(v, (B, E)) if k.endswith("bond") else
+                   pad(v, (B, E, 2)) if k.endswith("connectivity") else v) for k, v in inp.items()}
+        rng = np.random.default_rng(9)
+        if fat == "edges":      # molecule 3 of the cation: 700 valid edges over 180 atoms
+            n = 180
+            inp["cat_atom"][3, :n] = rng.integers(1, Va, size=n)
+            src = rng.integers(1, n, size=700)
+            tgt = 1 + (src + rng.integers(0, n - 2, size=700)) % (n - 1)
+            inp["cat_connectivity"][3, :700, 0], inp["cat_connectivity"][3, :700, 1] = src, tgt
+            inp["cat_bond"][3, :700] = rng.integers(1, Vb, size=700)
+        elif fat == "rows":     # molecule 5 of the anion: 300 atoms in a chain
+            inp["an_atom"][5, :] = rng.integers(1, Va, size=N)
+            k = np.arange(1, 200)
+            inp["an_connectivity"][5, :199, 0], inp["an_connectivity"][5, :199, 1] = k, k + 1
+            inp["an_bond"][5, :199] = rng.integers(1, Vb, size=199)
+        else:                   # 300 edges into one atom: in-degree beyond the 8-bit field
+            inp["cat_atom"][2, :40] = rng.integers(1, Va, size=40)
+            inp["cat_connectivity"][2, :300, 0] = rng.integers(1, 40, size=300)
+            inp["cat_connectivity"][2, :300, 1] = 7
+            inp["cat_bond"][2, :300] = rng.integers(1, Vb, size=300)
+        w = weights.init_weights("viscosity", Va, Vb, atom_dim=32, bond_dim=8, num_steps=2, seed=77, perturb=True)
+        m = make_model(w, Va, Vb, mode="f32t")
+        d = to_dev(inp)
+        with pytest.raises(ops.EncoderOverflow):
+            ops.encoder_fused([(d["cat_atom"], d["cat_bond"], d["cat_connectivity"]),
+                               (d["an_atom"], d["an_bond"], d["an_connectivity"])], m.atom_emb.embeddings,
+                              m.bond_emb.embeddings, None, 2, mode="f32t", prepared=m._prepared_weights("f32t"))
+        pc, pa = m.encode_pooled(d)          # fused by default -> overflow -> layered
+        assert m.overflow_fallbacks == 1, fat
+        rc = O.encode(w, "cat", inp["cat_atom"], inp["cat_bond"], inp["cat_connectivity"], pooled_only=True)
+        ra = O.encode(w, "an", inp["an_atom"], inp["an_bond"], inp["an_connectivity"], pooled_only=True)
+        assert_close(pc.cpu().numpy(), rc, what=f"fallback cat pooled ({fat})")
+        assert_close(pa.cpu().numpy(), ra, what=f"fallback an pooled ({fat})")
+        # the same shapes WITHOUT the fat molecule run fused
+        for k in ("cat", "an"):
+            for r in (2, 3, 5):
+                inp[f"{k}_atom"][r] = 0
+                inp[f"{k}_bond"][r] = 0
+                inp[f"{k}_connectivity"][r] = 0
+        m.overflow_fallbacks = 0
+        pc, _ = m.encode_pooled(to_dev(inp))
+        assert m.overflow_fallbacks == 0 and torch.isfinite(pc).all()
+        assert_close(pc.cpu().numpy(), O.encode(w, "cat", inp["cat_atom"], inp["cat_bond"], inp["cat_connectivity"],
+                                                pooled_only=True), what=f"fused after removing the fat molecule ({fat})")

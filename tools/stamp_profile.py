@@ -64,6 +64,11 @@ if mode in ("f32t", "f32x3"):
     print(f"step 1 of the first chunk ({ok.sum()} workgroups): duration {end.mean():.0f}; message phase: waves done at "
           f"min {srt[:, 0].mean():.0f} / median {srt[:, 8].mean():.0f} / last {srt[:, 15].mean():.0f}, barrier released "
           f"{mid.mean():.0f}; atom phase + end barrier {(end - mid).mean():.0f}")
+    if (st[:, 11] > 0).any():  # round 3: wave 1's atom phase in detail (its tile: one of the heaviest)
+        a = st[ok]
+        seg = [a[:, 8] - a[:, 12], a[:, 9] - a[:, 8], a[:, 10] - a[:, 9], a[:, 11] - a[:, 10], a[:, 15] - a[:, 11]]
+        print("  wave 1, atom phase: Reduce %d | GEMMs + gates %d | epilogue %d | next-step fetches %d | wait at the end barrier %d"
+              % tuple(int(x.mean()) for x in seg))
     sys.exit(0)
 
 # one step (first chunk, step 1) in detail: when each wave reaches the step barrier, barrier + image copy cost
