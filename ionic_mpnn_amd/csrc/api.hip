@@ -178,8 +178,10 @@ int64_t impnn_encoder_step_floats(int32_t D, int32_t K) {
 
 namespace {
 constexpr int32_t kInfoMagic = 0x706c616e;  // "plan"
-// impnn_encoder_plan_info.v: magic, mode class (0 pull records / 1 typed records), n_ions, B, N, E, S, Vb, nwg
+// impnn_encoder_plan_info.v: magic, mode class (0 pull records / 1 typed records), n_ions, B, N, E, S, Vb, nwg, D, K,
+// record kind (0 pull, 1 typed atom_dim 32, 2 wide atom_dim 64 / 128: three different workspace layouts)
 inline int mode_class(int mode) { return mode >= 2 ? 1 : 0; }
+inline int record_kind(int mode, int D) { return mode >= 2 ? (D == 32 ? 1 : 2) : 0; }
 }  // namespace
 
 int impnn_encoder_workspace_bytes(int32_t n_ions, int32_t B, int32_t N, int32_t E, int32_t D, int32_t K,
@@ -221,17 +223,18 @@ static int encoder_common(const char* fn, int32_t n_ions, const int32_t* const* 
   if (info_in) {  // run half: the plan's geometry is authoritative, and must be the geometry of this call
     const int32_t* v = info_in->v;
     REQ(v[0] == kInfoMagic, "plan info was not filled by impnn_encoder_plan");
-    if (v[1] != mode_class(mode) || v[2] != n_ions || v[3] != B || v[4] != N || v[5] != E || v[6] != S || v[7] != Vb)
+    if (v[1] != mode_class(mode) || v[2] != n_ions || v[3] != B || v[4] != N || v[5] != E || v[6] != S || v[7] != Vb ||
+        v[9] != D || v[10] != K || v[11] != record_kind(mode, D))
       return fail(IMPNN_E_BADARG, "%s: the workspace was planned for another batch shape or record kind "
-                  "(planned: kind %d, n_ions %d, B %d, N %d, E %d, S %d, Vb %d)", fn, v[1], v[2], v[3], v[4], v[5],
-                  v[6], v[7]);
+                  "(planned: kind %d/%d, n_ions %d, B %d, N %d, E %d, S %d, Vb %d, D %d, K %d)", fn, v[1], v[11], v[2],
+                  v[3], v[4], v[5], v[6], v[7], v[9], v[10]);
     nwg = v[8];
   }
   if (info_out) {
     int32_t* v = info_out->v;
     for (int i = 0; i < 12; ++i) v[i] = 0;
     v[0] = kInfoMagic; v[1] = mode_class(mode); v[2] = n_ions; v[3] = B; v[4] = N; v[5] = E; v[6] = S; v[7] = Vb;
-    v[8] = nwg;
+    v[8] = nwg; v[9] = D; v[10] = K; v[11] = record_kind(mode, D);
   }
   if (B == 0) return IMPNN_OK;
   EncoderArgs a{};

@@ -553,7 +553,7 @@ int device_compute_units() {
 
 // 160 KB dynamic LDS opt-in, once per (kernel slot, device).
 int ensure_lds_limit(const void* kern, int slot) {
-  static std::atomic<uint64_t> done[8];
+  static std::atomic<uint64_t> done[16];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   const uint64_t bit = 1ull << dev;

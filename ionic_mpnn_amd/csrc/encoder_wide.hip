@@ -1053,7 +1053,13 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   //  slices and barriers, not its rows - at 256 pairs 16-row tiles took 666 us per forward against 526 us)
   const int64_t max_tiles = ((int64_t)mols * a.N + R - 1) / R;
   int tile_rows = 4 * max_tiles <= 2 * cus ? 16 : R;  // (32-row tiles: 574 us at 200 pairs against ~500 us)
-  if (const char* e = getenv("IMPNN_WIDE_TILE_ROWS")) tile_rows = atoi(e) == 16 ? 16 : (atoi(e) == 32 ? 32 : R);  // diagnostics
+  {  // diagnostics override, read once per process (impnn.h: results depend on the arguments only)
+    static const int env_rows = [] {
+      const char* e = getenv("IMPNN_WIDE_TILE_ROWS");
+      return e ? atoi(e) : 0;
+    }();
+    if (env_rows) tile_rows = env_rows == 16 ? 16 : (env_rows == 32 ? 32 : R);
+  }
   const int gu_grid = (int)(w.rmax / tile_rows);
   unsigned long long* stamps = nullptr;  // [gu_grid x 8 | cus x 8] words, the last step's launches win
   {

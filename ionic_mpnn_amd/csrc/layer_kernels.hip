@@ -455,7 +455,11 @@ __global__ __launch_bounds__(256) void gated_update_d32_kernel(
     const float* __restrict__ beta, float eps, float* __restrict__ out, int64_t rows,
     const int32_t* __restrict__ ridx, const int32_t* __restrict__ nrows_dev) {
   constexpr int D = 32;
-  if (nrows_dev) rows = *nrows_dev;  // row list (impnn_gated_update_rows): rows ridx[0 .. *nrows_dev) only
+  const int64_t max_rows = rows;  // what the launch and every buffer are sized for
+  if (nrows_dev) {  // row list (impnn_gated_update_rows): rows ridx[0 .. *nrows_dev) only; never beyond the sizing
+    const int64_t n = *nrows_dev;
+    rows = n < 0 ? 0 : (n < max_rows ? n : max_rows);
+  }
   __shared__ __align__(16) float wimg[3 * D * kGuRS + 5 * D];
   for (int t = threadIdx.x; t < 3 * D * 2 * D; t += blockDim.x) {
     const int gate = t / (2 * D * D), rem = t - gate * 2 * D * D;
@@ -477,7 +481,10 @@ __global__ __launch_bounds__(256) void gated_update_d32_kernel(
   for (int64_t tile = wave_id; tile < ntiles; tile += nwaves) {
     const int64_t row = tile * 16 + a;
     int64_t rl = row < rows ? row : rows - 1;  // clamped load address; the store is masked
-    if (ridx) rl = ridx[rl];
+    if (ridx) {
+      rl = ridx[rl];
+      rl = rl < 0 ? 0 : (rl < max_rows ? rl : max_rows - 1);
+    }
     const f32x4_t h0 = ldv4(h + rl * D + 4 * q), h1 = ldv4(h + rl * D + 16 + 4 * q);
     const f32x4_t a0 = ldv4(agg + rl * D + 4 * q), a1 = ldv4(agg + rl * D + 16 + 4 * q);
     f32x4_t z0 = ldv4(wvec + 4 * q), z1 = ldv4(wvec + 16 + 4 * q);
@@ -739,7 +746,11 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
   // tile_rows = 64, or 16 when the launch has too few rows to fill the chip with 64-row tiles (the reference trains
   // with 32 pairs per step: 1 280 rows = 20 tiles on 256 CUs): only the four waves of row tile 0 - one per SIMD -
   // multiply then, the others just help moving the weight slices, and a tile's MFMA time drops 4x.
-  if (nrows_dev) rows = *nrows_dev;
+  const int64_t max_rows = rows;  // what the launch and every buffer are sized for
+  if (nrows_dev) {  // a stale or foreign device count never reaches beyond the sizing (indices are never trusted)
+    const int64_t n = *nrows_dev;
+    rows = n < 0 ? 0 : (n < max_rows ? n : max_rows);
+  }
   constexpr int D = 16 * NT, LDC = 2 * D + 4, LDR = D + 4;
   constexpr int LDW = 2 * D;  // slice layout: element (input row 4*qq + r, column c) at ((qq * LDW + c) * 4 + r)
   extern __shared__ __align__(16) float smem[];
@@ -760,7 +771,8 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
     for (int i = 0; i < kQ; ++i) {
       const int t = tid + 1024 * i, r = t / (D / 4), c4 = t - r * (D / 4);
       const bool in = row0 + r < rows && r < tile_rows;
-      const int64_t src = in ? (ridx ? (int64_t)ridx[row0 + r] : row0 + r) : 0;
+      int64_t src = in ? (ridx ? (int64_t)ridx[row0 + r] : row0 + r) : 0;
+      src = src < 0 ? 0 : (src < max_rows ? src : max_rows - 1);
       hv[i] = in ? ldv4(h + src * D + 4 * c4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
       av[i] = in ? ldv4(agg + src * D + 4 * c4) : f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
@@ -977,7 +989,8 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
     for (int g = 0; g < 4; ++g) {
       const int rl = 16 * wave + 4 * q + g;
       if (row0 + rl < rows) {
-        const int64_t dst = ridx ? (int64_t)ridx[row0 + rl] : row0 + rl;
+        int64_t dst = ridx ? (int64_t)ridx[row0 + rl] : row0 + rl;
+        dst = dst < 0 ? 0 : (dst < max_rows ? dst : max_rows - 1);
         out[dst * D + f] = (tt[TL][g] - mean[g]) * inv[g] * gm + bt + cs[rl * LDC + f];
       }
     }
@@ -1427,7 +1440,10 @@ int launch_model_head(int kind, const float* pc, const float* pa, const float* T
     return fail(IMPNN_E_UNSUPPORTED, "model_head: dims D=%d (<= %d) F=%d Mx=%d (<= %d)", D, kHeadMaxX, F, Mx, kHeadMaxDim);
   const int wfloats = (int)impnn_model_head_floats(kind, D, F, Mx);
   const size_t lds = sizeof(float) * (((size_t)wfloats + 3) / 4 * 4 + (size_t)kHeadSPB * (2 * kHeadMaxX + 4 * kHeadMaxDim));
-  if (lds > 64 * 1024) return fail(IMPNN_E_UNSUPPORTED, "model_head: weights do not fit LDS");
+  // every (D <= 128, F <= 64, Mx <= 64) fits the 160 KB of a gfx950 CU: 29 057 weight floats + 16 KB of sample scratch
+  if (lds > 160 * 1024) return fail(IMPNN_E_UNSUPPORTED, "model_head: weights do not fit LDS");
+  if (lds > 64 * 1024)
+    if (int rc = ensure_lds_limit((const void*)model_head_kernel, 8)) return rc;
   model_head_kernel<<<(B + kHeadSPB - 1) / kHeadSPB, 256, lds, s>>>(kind, pc, pa, T, w, out, B, D, F, Mx, wfloats);
   return check_launch("model_head");
 }

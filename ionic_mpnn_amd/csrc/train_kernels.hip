@@ -1358,7 +1358,11 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
   // ridx / nrows_dev (optional): the kernel works on the rows ridx[0 .. *nrows_dev) of h / agg / dout / dh / dagg
   // (impnn_gated_update_rows_bwd: the kept rows of an encode() loop); dpre, r*h and the copies hc / aggc of the rows'
   // inputs are written compactly (list position), which is what the weight-gradient GEMMs behind this kernel read.
-  if (nrows_dev) rows = *nrows_dev;
+  const int64_t max_rows = rows;  // what the launch and every buffer are sized for
+  if (nrows_dev) {  // a stale or foreign device count never reaches beyond the sizing (indices are never trusted)
+    const int64_t n = *nrows_dev;
+    rows = n < 0 ? 0 : (n < max_rows ? n : max_rows);
+  }
   constexpr int D = 16 * NT, LDC = 2 * D + 4, LDR = D + 4, LDW = 2 * D, NL = NT / 4;
   extern __shared__ __align__(16) float smem[];
   float* cs = smem;                   // 64 x LDC
@@ -1415,7 +1419,10 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     float* rh_t = rh_out + row0 * D;
     float* dpre_t = dpre + row0 * 3 * D;
     __syncthreads();
-    if (tid < 64) grow_s[tid] = tid < nrt ? (ridx ? ridx[row0 + tid] : (int32_t)(row0 + tid)) : 0;
+    if (tid < 64) {
+      int64_t gr = tid < nrt ? (ridx ? (int64_t)ridx[row0 + tid] : row0 + tid) : 0;
+      grow_s[tid] = (int32_t)(gr < 0 ? 0 : (gr < max_rows ? gr : max_rows - 1));
+    }
     __syncthreads();
     for (int t = tid; t < 64 * D; t += 1024) {
       const int r = t / D, c = t - r * D;
@@ -1788,7 +1795,10 @@ __global__ __launch_bounds__(kBlock) void strided_gemm_splitk_kernel(GemmProblem
                                                                      int64_t a_rs, int64_t a_cs, int64_t b_rs,
                                                                      int64_t b_cs, int nchunk, int tilesN,
                                                                      const int32_t* __restrict__ rows_dev) {
-  if (rows_dev) rows = *rows_dev;  // (the contraction length lives on the device: kept rows of a batch)
+  if (rows_dev) {  // (the contraction length lives on the device: kept rows of a batch; never beyond the sizing)
+    const int64_t n = *rows_dev;
+    rows = n < 0 ? 0 : (n < rows ? n : rows);
+  }
   // LDS tiles of kGR contraction rows; row strides chosen so that the four k-rows of one MFMA step fall into
   // disjoint bank groups (80 = 64 + 16, 48 = 32 + 16 floats)
   constexpr int kLA = kGM + 16, kLB = kGN + 16;
@@ -1917,7 +1927,10 @@ __global__ __launch_bounds__(kBlock) void strided_gemm_splitk_big_kernel(GemmPro
                                                                          int64_t rows, int M, int Mh, int N,
                                                                          int64_t a_rs, int64_t b_rs, int nchunk,
                                                                          int tilesN, const int32_t* __restrict__ rows_dev) {
-  if (rows_dev) rows = *rows_dev;
+  if (rows_dev) {
+    const int64_t n = *rows_dev;
+    rows = n < 0 ? 0 : (n < rows ? n : rows);
+  }
   constexpr int kLA = kBM + 16, kLB = kBN + 16;  // row strides: the four k rows of an MFMA step on disjoint bank groups
   __shared__ __align__(16) float As[kGR * kLA];
   __shared__ __align__(16) float Bs[kGR * kLB];

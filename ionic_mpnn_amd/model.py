@@ -194,6 +194,9 @@ class MPNNModel:
     def load_weight_file(path):
         """-> (config dict, weights dict) from a file written by save_weights (no pickle is involved)."""
         import json
+        import os as _os
+        if not _os.path.exists(path) and _os.path.exists(str(path) + ".npz"):
+            path = str(path) + ".npz"  # files written before round 2 (np.savez appended the suffix then)
         with np.load(path, allow_pickle=False) as z:
             cfg = json.loads(bytes(z["__config__"].tobytes()).decode())
             return cfg, {k: z[k] for k in z.files if k != "__config__"}

@@ -316,6 +316,27 @@ def test_model_head_kernel_vs_oracle_and_torch_head(name):
     assert_close(m(inp).cpu().numpy(), outs["final"], what="full forward")
 
 
+@pytest.mark.parametrize("kind", ["viscosity", "melting_point"])
+def test_model_head_kernel_at_the_widest_head(kind):
+    """atom_dim 128 with fp_size = mixing_size = 64: 29 K weight floats, more than the 64 KB default LDS limit holds
+    (the head kernel refused what model.head() sent it) - the launch raises its limit to the CU's 160 KB."""
+    Va, Vb, B = 20, 6, 37
+    w = weights.init_weights(kind, Va, Vb, atom_dim=128, bond_dim=8 if kind == "viscosity" else 128 * 128, fp_size=64,
+                             mixing_size=64, num_steps=0, seed=3, perturb=True)
+    if kind == "viscosity":
+        m = MM.build_model(Va, Vb, atom_dim=128, bond_dim=8, fp_size=64, mixing_size=64, num_steps=0, device=DEV)
+    else:
+        m = MM.build_melting_point_model(Va, Vb, atom_dim=128, fp_size=64, mixing_size=64, num_steps=0, device=DEV)
+    m.load_weights(w)
+    rng = np.random.default_rng(0)
+    pc = torch.from_numpy(rng.normal(size=(B, 128)).astype(np.float32)).to(DEV)
+    pa = torch.from_numpy(rng.normal(size=(B, 128)).astype(np.float32)).to(DEV)
+    T = torch.from_numpy(rng.uniform(253, 393, size=(B, 1)).astype(np.float32)).to(DEV) if kind == "viscosity" else None
+    y_kernel = m.head(pc, pa, T)                # ops.model_head (one launch)
+    y_torch = m.head(pc, pa, T, trace={})       # Dense layers
+    assert_close(y_kernel.cpu().numpy(), y_torch.cpu().numpy(), what="widest head: kernel vs torch head")
+
+
 def test_config1_dataset_plumbing_batch32():
     """BASELINE config 1: records in the *_id_data.pkl schema -> restated loader -> batch 32 -> HIP forward
     vs the oracle."""
