@@ -39,7 +39,9 @@ def init_distributed(backend=None, timeout_s=600):
     if world == 1:
         return rank, local_rank, world
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # (HSA_ENABLE_IPC_MODE_LEGACY=0 - dmabuf IPC, which RCCL needs on this driver - only acts when it is in the
+    #  environment before the process's FIRST GPU call: launchers export it, bench.py sets it before importing torch.
+    #  Setting it here, after the caller has touched the device, would do nothing, so this function does not pretend to.)
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
