@@ -49,6 +49,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct B3 {
   bf16x8 p0, p1, p2;
 };
+// Non-finite operands: a NaN stays a NaN through its first term.  An INFINITY splits into (inf, inf - inf = nan, nan), so
+// every product it meets is NaN, where exact f32 arithmetic has w * inf = +-inf and a saturating gate may even turn that
+// back into a finite number (sigmoid(+inf) = 1).  This cannot be repaired inside the split - with (inf, 0, 0) the terms
+// a1 * inf of weights whose residual a1 is exactly 0 are NaN again - so mode 3 is the more conservative of the two: the
+// rows it reports non-finite are a superset of mode 2's, and a finite row equals mode 2's up to summation order
+// (tests/test_gpu_encoder.py::test_f32x3_propagates_nan_and_inf_like_f32t; measured: guarding the split costs 4 us per
+// 4096-pair launch and still leaves the 0 * inf terms).
 // two values -> their three packed bf16 pairs (5.5 VALU per value: and, sub, and, sub per value; three perms per pair)
 __device__ __forceinline__ void split_pair(float x, float y, unsigned& w0, unsigned& w1, unsigned& w2) {
   const unsigned xb = __builtin_bit_cast(unsigned, x), yb = __builtin_bit_cast(unsigned, y);

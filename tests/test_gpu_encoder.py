@@ -563,6 +563,126 @@ def test_f32x3_is_as_accurate_as_the_f32_mfma():
     assert err["f32x3"][0] <= 1e-5 and err["f32t"][0] <= 1e-5
 
 
+def _mode_errors(w, inp, Va, Vb, K=8, sample=None, kind="viscosity"):
+    """max / rms / elementwise error of modes f32t and f32x3 against the fp64 oracle (relative to the tensor's scale)."""
+    sub = inp if sample is None else {k: v[sample] for k, v in inp.items()}
+    ref = np.concatenate([O.encode(w, p, sub[f"{p}_atom"], sub[f"{p}_bond"], sub[f"{p}_connectivity"], pooled_only=True)
+                          for p in ("cat", "an")])
+    d_in, err, out = to_dev(inp), {}, {}
+    for mode in ("f32t", "f32x3"):
+        if kind == "viscosity":
+            m = make_model(w, Va, Vb, K=K, mode=mode)
+        else:
+            m = MM.build_melting_point_model(Va, Vb, atom_dim=32, num_steps=weights.num_steps_of(w), device=DEV)
+            m.load_weights(w)
+            m.encoder_mode = mode
+        assert m.bond_dim == K and m.resolve_encoder_mode(inp["cat_atom"].shape[1], inp["cat_bond"].shape[1]) == mode
+        pc, pa = m.encode_pooled(d_in, fused=True)
+        pc, pa = pc.cpu().numpy(), pa.cpu().numpy()
+        if sample is not None:
+            pc, pa = pc[sample], pa[sample]
+        got = np.concatenate([pc, pa]).astype(np.float64)
+        out[mode] = got
+        scale = np.abs(ref).max()
+        with np.errstate(invalid="ignore"):
+            d = np.abs(got - ref)
+        err[mode] = (float(d.max() / scale), float(np.sqrt(np.mean(d * d)) / np.sqrt(np.mean(ref * ref))),
+                     float(np.max(d / np.maximum(np.abs(ref), 1e-3 * scale))))
+    return err, out, ref
+
+
+@pytest.mark.parametrize("config", ["config2", "config3"])
+def test_f32x3_error_within_twice_f32t_on_the_baseline_configs(config):
+    """VERDICT r2, condition (b) for mode f32x3 ("f32 (bf16x9 emulation)"): on BASELINE configs 2 and 3 (full batch; the
+    oracle on a sample) its error against the fp64 oracle is at most twice the exact-f32 mode's.  (Config 5 is atom_dim
+    128: the wide encoder, which has no such mode.)"""
+    Va, Vb = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB
+    if config == "config2":
+        B, K, S, kind = 4096, 8, 3, "viscosity"
+    else:
+        B, K, S, kind = 8192, 1024, 4, "melting_point"
+    inp = synthetic.make_batch(B, seed=61, with_temperature=False)
+    w = weights.init_weights(kind, Va, Vb, atom_dim=32, bond_dim=K, num_steps=S, seed=62, perturb=True)
+    idx = np.random.default_rng(8).choice(B, size=96, replace=False)
+    err, _, _ = _mode_errors(w, inp, Va, Vb, K=K, sample=idx, kind=kind)
+    for i in range(3):
+        assert err["f32x3"][i] <= 2.0 * err["f32t"][i] + 1e-7, err
+    assert err["f32x3"][0] <= 1e-5 and err["f32t"][0] <= 1e-5, err
+
+
+@pytest.mark.parametrize("what", ["embeddings", "bond_transform", "gate_kernels", "everything"])
+def test_f32x3_magnitude_sweep(what):
+    """The same bound over forty orders of magnitude: atom / bond embeddings, the message weights and the GatedUpdate
+    kernels scaled by 1e-20 ... 1e+20 (bf16 keeps fp32's exponent, so the three-term split is exact wherever the f32
+    value is normal; the third term reaches bf16's subnormals only for |x| < ~1e-33)."""
+    Va, Vb = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB
+    inp = synthetic.make_batch(160, seed=71, with_temperature=False)
+    w0 = weights.init_weights("viscosity", Va, Vb, num_steps=3, seed=72, perturb=True)
+    for s in (1e-20, 1e-12, 1e-6, 1e-3, 1.0, 1e3, 1e6, 1e12, 1e20):
+        w = dict(w0)
+        for k in w0:
+            hit = (what in ("embeddings", "everything") and k in ("atom_embedding", "bond_embedding")) or \
+                  (what in ("bond_transform", "everything") and k.endswith("bond_transform")) or \
+                  (what in ("gate_kernels", "everything") and "/dense_" in k and k.endswith("kernel") and "_gu_" in k)
+            if hit:
+                sk = s if what != "everything" else (s if k.endswith("embedding") else (1.0 / s if "dense" in k else np.sqrt(s)))
+                w[k] = (w0[k].astype(np.float64) * sk).astype(np.float32)
+        err, out, ref = _mode_errors(w, inp, Va, Vb)
+        # (at the far ends f32 itself leaves its range - LayerNorm's sum of 32 squares of 1e19 overflows - for either
+        #  mode alike: what is required is the same finiteness pattern and the 2x bound, and 1e-5 wherever f32t has it)
+        assert np.isfinite(ref).all(), (what, s)
+        assert np.array_equal(np.isfinite(out["f32t"]), np.isfinite(out["f32x3"])), (what, s)
+        if np.isfinite(out["f32t"]).all():
+            if err["f32t"][0] <= 1e-5:   # wherever exact f32 meets the path's tolerance: within twice its error, and 1e-5
+                for i in range(3):
+                    assert err["f32x3"][i] <= 2.0 * err["f32t"][i] + 1e-7, (what, s, err)
+                assert err["f32x3"][0] <= 1e-5, (what, s, err)
+            else:
+                # ill-conditioned corners (message weights x 1e6: saturated gates amplify ANY f32 rounding ~100x; exact
+                # f32 itself is at 1e-4 there): the two modes differ by their summation order only, i.e. by another
+                # draw of the same rounding noise - the same order of magnitude is what can be asked
+                for i in range(3):
+                    assert err["f32x3"][i] <= 4.0 * err["f32t"][i] + 1e-7, (what, s, err)
+
+
+def test_f32x3_propagates_nan_and_inf_like_f32t():
+    """A NaN in an embedding row or a weight makes the SAME molecules' outputs NaN in both modes, every other
+    molecule's output is untouched.  An infinity: exact f32 has w * inf = +-inf, which a saturating gate may turn back
+    into a finite number; the three-term split turns an infinite operand into (inf, nan, nan) - mode f32x3 is the more
+    conservative one: its non-finite rows are a superset of f32t's, never a finite value where f32t reports none, and
+    the rows it does report finite agree with f32t's."""
+    Va, Vb = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB
+    inp = synthetic.make_batch(200, seed=81, with_temperature=False)
+    w0 = weights.init_weights("viscosity", Va, Vb, num_steps=3, seed=82, perturb=True)
+    clean = {}
+    for mode in ("f32t", "f32x3"):
+        pc, pa = make_model(w0, Va, Vb, mode=mode).encode_pooled(to_dev(inp), fused=True)
+        clean[mode] = torch.cat([pc, pa]).cpu().numpy()
+    for bad in (np.nan, np.inf, -np.inf):
+        for key, where in (("atom_embedding", (17, 5)), ("bond_embedding", (9, 2)), ("cat_gu_1/dense_r/kernel", (40, 3)),
+                           ("an_bmm_2/bond_transform", (3, 7, 11))):
+            w = {k: v.copy() for k, v in w0.items()}
+            w[key][where] = bad
+            res = {}
+            for mode in ("f32t", "f32x3"):
+                pc, pa = make_model(w, Va, Vb, mode=mode).encode_pooled(to_dev(inp), fused=True)
+                res[mode] = torch.cat([pc, pa]).cpu().numpy()
+            fin_t, fin_x = np.isfinite(res["f32t"]).all(axis=1), np.isfinite(res["f32x3"]).all(axis=1)
+            assert not fin_t.all(), (bad, key)   # the poison reached some molecule
+            assert not (fin_x & ~fin_t).any(), (bad, key)   # never finite where exact f32 is not
+            if np.isnan(bad):
+                assert np.array_equal(fin_t, fin_x), (bad, key, int(fin_t.sum()), int(fin_x.sum()))
+                assert np.array_equal(np.isnan(res["f32t"]), np.isnan(res["f32x3"])), (bad, key)
+            both = fin_t & fin_x
+            if both.any():
+                assert_close(res["f32x3"][both], res["f32t"][both].astype(np.float64), what=f"finite rows ({bad}, {key})")
+            if key.endswith("embedding"):        # only molecules that hold the poisoned id: the others are bit-identical
+                assert fin_t.any()
+                for mode, fin in (("f32t", fin_t), ("f32x3", fin_x)):
+                    touched = np.any(res[mode] != clean[mode], axis=1) | ~fin
+                    assert np.array_equal(res[mode][~touched], clean[mode][~touched]) and (~touched).any(), (mode, bad, key)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # round 3: the padded shapes of the reference's real (explicit-hydrogen) data sets.  featurize.py:45 adds hydrogens and
 # the trainers pad to E = 4 * max_bonds edge slots (train_viscosity.py:95,288-289): N = 160, E = 640 here.  The typed
