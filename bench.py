@@ -82,7 +82,7 @@ def pmc_field(name, kernel="encoder_typed"):
     FETCH_SIZE correction of MI355X_MICROARCH.md's HBM section.  (PMC passes are separate rocprofv3 runs of this
     same command, tools/pmc_profile.sh; the figure is per launch of the named kernel.)"""
     best, src = None, None
-    key = "encoder_typed" if "typed" in kernel else "encoder_fused"
+    key = kernel if kernel in ("encoder_typed", "encoder_typed_x3") else ("encoder_typed" if "typed" in kernel else "encoder_fused")
     for f in sorted((ROOT / "profiles").glob("pmc_*.json")):
         try:
             v = json.loads(f.read_text()).get(key, {}).get(name)
@@ -640,8 +640,9 @@ def main():
         if not k_ms:
             return None
         kname = "encoder_typed_kernel" if mode in ("f32t", "f32x3") else "encoder_fused_kernel"
-        traffic, tsrc = pmc_field("hbm_bytes_per_launch", kname)
-        busy, _ = pmc_field("mfma_pipe_busy_frac", kname)
+        pkey = "encoder_typed_x3" if mode == "f32x3" else kname
+        traffic, tsrc = pmc_field("hbm_bytes_per_launch", pkey)
+        busy, _ = pmc_field("mfma_pipe_busy_frac", pkey)
         ach = flops_launch / (k_ms * 1e-3) / 1e12
         r = {"bound": "mfma", "kernel": kname + ("<x3>" if mode == "f32x3" else ""), "achieved": ach,
              "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,

@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 run() {  # name counters...
   local name=$1; shift
   timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d "$ROOT/$OUT/$name" -- \
-      python3 "$ROOT/bench.py" --steps 5 --warmup 2 --ramp-ms 20 --streams 1 --no-cpu-baseline ${PMC_BENCH_ARGS:-} > "$ROOT/$OUT/$name.log" 2>&1
+      python3 "$ROOT/bench.py" --steps 5 --warmup 2 --ramp-ms 20 --streams 1 --no-cpu-baseline --no-other-configs ${PMC_BENCH_ARGS:-} > "$ROOT/$OUT/$name.log" 2>&1
 }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES
 run sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
