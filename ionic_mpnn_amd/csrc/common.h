@@ -144,9 +144,9 @@ int device_compute_units();  // CUs of the current device (cached per device ind
 inline int gu_wide_tile_rows(int64_t rows) { return rows < 8192 ? 16 : 64; }
 // ---- wide states (encoder_wide.hip: atom_dim 64 / 128 behind the same entries, mode 2)
 bool encoder_wide_supported(int N, int E, int D, int K, int S, int Vb);
-size_t encoder_wide_workspace_bytes(int n_ions, int B, int N, int E, int D, int S, int Vb);
-size_t encoder_wide_prepared_bytes(int D, int S, int Vb);
-int launch_encoder_wide_prepare(const float* weights, const float* bond_table, int D, int K, int S, int Vb,
+size_t encoder_wide_workspace_bytes(int n_ions, int B, int N, int E, int D, int S, int Vb, bool x3);
+size_t encoder_wide_prepared_bytes(int D, int S, int Vb, bool x3);
+int launch_encoder_wide_prepare(const float* weights, const float* bond_table, int D, int K, int S, int Vb, bool x3,
                                 void* prepared, hipStream_t s);
 int launch_encoder_wide(const EncoderArgs& a, hipStream_t s);
 

@@ -525,7 +525,7 @@ int launch_encoder_typed_run(const EncoderArgs& a, const enc::Ws& w, hipStream_t
 
 bool encoder_fused_supported(int mode, int N, int E, int D, int K, int S, int Vb) {
   using namespace enc;
-  if (mode == 2 && D != kD) return encoder_wide_supported(N, E, D, K, S, Vb);  // atom_dim 64 / 128: encoder_wide.hip
+  if ((mode == 2 || mode == 3) && D != kD) return encoder_wide_supported(N, E, D, K, S, Vb);  // atom_dim 64 / 128: encoder_wide.hip
   if (mode == 3 && tecap_of(E) != kTECap) return false;  // the three-plane update image leaves no LDS for 640 edge slots
   if (mode == 2 || mode == 3) return K >= 1 && encoder_typed_supported(N, E, D, S, Vb);
   if (mode != 0 && mode != 1) return false;
@@ -588,12 +588,12 @@ int encoder_workgroups(int n_ions, int B, int requested, int N, int E, int mode)
 }
 
 size_t encoder_fused_workspace_bytes(int mode, int n_ions, int B, int N, int E, int D, int S, int Vb, int nwg) {
-  if (D != enc::kD) return encoder_wide_workspace_bytes(n_ions, B, N, E, D, S, Vb);
+  if (D != enc::kD) return encoder_wide_workspace_bytes(n_ions, B, N, E, D, S, Vb, mode == 3);
   return enc::ws_layout(n_ions, B, N, E, S, Vb, nwg, mode >= 2, mode == 3).total;
 }
 
 size_t encoder_prepared_bytes(int mode, int D, int S, int Vb) {
-  if (D != enc::kD) return encoder_wide_prepared_bytes(D, S, Vb);
+  if (D != enc::kD) return encoder_wide_prepared_bytes(D, S, Vb, mode == 3);
   if (mode >= 2) return encoder_typed_prepared_bytes(S, Vb, mode == 3);
   return (size_t)(S > 0 ? S : 1) * enc::kImgSlot * sizeof(float);
 }
@@ -601,7 +601,7 @@ size_t encoder_prepared_bytes(int mode, int D, int S, int Vb) {
 int launch_encoder_prepare(const float* weights, const float* bond_table, int D, int K, int S, int Vb, int mode,
                            void* prepared, hipStream_t s) {
   if (S <= 0) return IMPNN_OK;
-  if (D != enc::kD) return launch_encoder_wide_prepare(weights, bond_table, D, K, S, Vb, prepared, s);
+  if (D != enc::kD) return launch_encoder_wide_prepare(weights, bond_table, D, K, S, Vb, mode == 3, prepared, s);
   if (mode >= 2) return launch_encoder_typed_prepare(weights, bond_table, K, S, Vb, mode == 3, prepared, s);
   enc::ImageParams ip{};
   ip.weights = weights;

@@ -95,10 +95,15 @@ inline int tile_edges(int D) { return D >= 128 ? 64 : 128; }
 
 // floats of one step of a prepared image: Vb type matrices (D x D, row-major [i][j]) | [Wz|Wr] slices | Wh slices |
 // bz br bh gamma beta
-inline size_t step_floats(int D, int Vb) { return (size_t)Vb * D * D + 6 * (size_t)D * D + 5 * (size_t)D; }
-inline size_t prepared_bytes(int D, int S, int Vb) { return align_up((size_t)(S > 0 ? S : 1) * step_floats(D, Vb) * 4, 256); }
+// (mode 3: the gate kernels as three bf16 planes: 9 D^2 floats' worth of bytes instead of 6 D^2)
+inline size_t step_floats(int D, int Vb, bool x3 = false) {
+  return (size_t)Vb * D * D + (x3 ? 9 : 6) * (size_t)D * D + 5 * (size_t)D;
+}
+inline size_t prepared_bytes(int D, int S, int Vb, bool x3 = false) {
+  return align_up((size_t)(S > 0 ? S : 1) * step_floats(D, Vb, x3) * 4, 256);
+}
 
-inline Ws ws_layout(int n_ions, int B, int N, int E, int D, int S, int Vb) {
+inline Ws ws_layout(int n_ions, int B, int N, int E, int D, int S, int Vb, bool x3 = false) {
   Ws w{};
   const int64_t mols = (int64_t)n_ions * B;
   w.nT = n_ions * Vb;
@@ -123,7 +128,7 @@ inline Ws ws_layout(int n_ions, int B, int N, int E, int D, int S, int Vb) {
   w.h = take((size_t)w.rmax * D * 4);
   w.agg = take((size_t)w.rmax * D * 4);
   w.m = take((size_t)w.vmax * D * 4);
-  w.img = take((size_t)n_ions * prepared_bytes(D, S, Vb));
+  w.img = take((size_t)n_ions * prepared_bytes(D, S, Vb, x3));
   w.total = o;
   return w;
 }
@@ -878,6 +883,337 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
   WIDE_STAMP_REAL(p.stamps, 6);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// a7 in mode IMPNN_ENCODER_F32X3_TYPED ("f32 (bf16x9 emulation)"): the same GatedUpdate with its three GEMMs on the bf16
+// matrix pipe.  Every f32 operand is carried EXACTLY as three bf16 terms (x = b0 + b1 + b2: bf16 keeps fp32's exponent,
+// 3 x 8 significant bits) and all nine cross products are accumulated in f32 - the f32 products themselves, summed in
+// another order (encoder_typed.hip has the D = 32 form and the discussion of non-finite operands).  Nine
+// v_mfma_f32_16x16x32_bf16 (16 cycles, 32 k) replace eight v_mfma_f32_16x16x4_f32 (32 cycles, 4 k): 9/16 of the matrix
+// time, on a pipe that - unlike the exact-f32 one - co-executes with the vector ALU.
+//   * the gate kernels arrive pre-split from the prepared image (wide_gu_image_x3_kernel), in 32-k slices of MFMA
+//     B-operand order [plane][k octet][column][8 k]: a slice is copied global -> registers -> LDS verbatim;
+//   * the rows ([h | agg], then [r*h | agg]) are split when a slice is parked in LDS (A-operand order
+//     [plane][k octet][row][8 k]; 5.5 vector instructions per value);
+//   * one workgroup of 8 waves per CU (a 32-k slice of [Wz|Wr] is 48 KB in three planes: two stages fill the LDS),
+//     wave = 32 rows x NL feature tiles of z and of r: 72 MFMAs per wave and slice between barriers.
+// ------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4_t mfma_bf16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// two f32 -> their three packed bf16 pairs (low half <- x, high half <- y)
+__device__ __forceinline__ void split_pair_w(float x, float y, unsigned& w0, unsigned& w1, unsigned& w2) {
+  const unsigned xb = __builtin_bit_cast(unsigned, x), yb = __builtin_bit_cast(unsigned, y);
+  const float x1 = x - __builtin_bit_cast(float, xb & 0xffff0000u), y1 = y - __builtin_bit_cast(float, yb & 0xffff0000u);
+  const unsigned x1b = __builtin_bit_cast(unsigned, x1), y1b = __builtin_bit_cast(unsigned, y1);
+  const float x2 = x1 - __builtin_bit_cast(float, x1b & 0xffff0000u), y2 = y1 - __builtin_bit_cast(float, y1b & 0xffff0000u);
+  w0 = __builtin_amdgcn_perm(yb, xb, 0x07060302u);
+  w1 = __builtin_amdgcn_perm(y1b, x1b, 0x07060302u);
+  w2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, y2), __builtin_bit_cast(unsigned, x2), 0x07060302u);
+}
+
+constexpr int kGuX3Threads = 512;
+// LDS bytes: two stages of (rows 12 KB + [Wz|Wr] slice 3 x 4 x 2D x 16 B) - phase 2 re-cuts the same memory into two
+// stages of (rows + Wh slice) and the f32 copy of r*h - plus the LayerNorm partials
+constexpr size_t gu_x3_lds_bytes(int D) { return 2 * (size_t)(12288 + 12 * 2 * D * 16) + 8 * kRT * 4; }
+
+template <int NT>
+__global__ __launch_bounds__(kGuX3Threads, 2) void wide_update_x3_kernel(GuParams p) {
+  constexpr int D = 16 * NT, R = kRT, LDR = D + 4;
+  constexpr int RG = 2, FG = 4, NL = NT / FG;
+  constexpr int NS = NT;                     // 32-k slices of a 2D-deep GEMM
+  constexpr int UA = 3 * 4 * R;              // 16-byte units of a row slice (768)
+  constexpr int UB1 = 3 * 4 * 2 * D;         // ... of a [Wz|Wr] slice
+  constexpr int UB2 = 3 * 4 * D;             // ... of a Wh slice
+  constexpr int ST1 = UA + UB1, ST2 = UA + UB2;  // stage sizes (units)
+  constexpr int kQ1 = (UB1 + kGuX3Threads - 1) / kGuX3Threads, kQ2 = (UB2 + kGuX3Threads - 1) / kGuX3Threads;
+  static_assert(NL >= 1 && NT % 2 == 0, "tile shape");
+  static_assert((size_t)2 * ST2 * 16 + (size_t)R * LDR * 4 <= (size_t)2 * ST1 * 16, "phase 2 fits phase 1's stages");
+  extern __shared__ __align__(16) unsigned char smem_b[];
+  uint4* const stage = reinterpret_cast<uint4*>(smem_b);                       // phase 1: 2 x ST1 units
+  float* const rhs = reinterpret_cast<float*>(smem_b + (size_t)2 * ST2 * 16);  // phase 2: R x LDR f32, r * h
+  float* const part = reinterpret_cast<float*>(smem_b + (size_t)2 * ST1 * 16);  // 2 x FG x R LayerNorm partials
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, a = lane & 15, q = lane >> 4;
+  const int rg = wv % RG, fg = wv / RG;
+  const int64_t row0 = (int64_t)blockIdx.x * p.tile_rows;
+  const int end = p.meta[kMetaEnd];
+  if (row0 >= end) return;
+  const int g = (p.n_ions > 1 && row0 >= p.meta[kMetaBase + 1]) ? 1 : 0;
+  const int64_t ion_end = p.meta[kMetaBase + g] + p.meta[kMetaRows + g];
+  const int64_t row_end = row0 + p.tile_rows < ion_end ? row0 + p.tile_rows : ion_end;
+  if (row0 >= row_end) return;
+  const bool lv[2] = {32 * rg < p.tile_rows, 32 * rg + 16 < p.tile_rows};  // (wave-uniform) this wave's two row tiles
+  const float* img = p.img[g] + p.gu_off;
+  const uint4* P1 = reinterpret_cast<const uint4*>(img);
+  const uint4* P2 = P1 + (size_t)NS * UB1;
+  const float* bias = reinterpret_cast<const float*>(P2 + (size_t)NS * UB2);  // bz br bh gamma beta
+  // a thread's piece of a row slice: row a_row, k = 4 a_pc .. 4 a_pc + 3 of the slice's 32
+  const int a_row = tid >> 3, a_pc = tid & 7;
+  const float* hsrc = p.h + (row0 + a_row) * D + 4 * a_pc;
+  const float* gsrc = p.agg + (row0 + a_row) * D + 4 * a_pc;
+  // unit (plane, k octet a_pc >> 1, row a_row), 8-byte half a_pc & 1
+  const int a_unit = (a_pc >> 1) * R + a_row, a_half = a_pc & 1;
+  auto park_rows = [&](uint4* st, f32x4_t v) {  // 4 values -> three planes of 4 bf16
+    unsigned w0[2], w1[2], w2[2];
+    split_pair_w(v[0], v[1], w0[0], w1[0], w2[0]);
+    split_pair_w(v[2], v[3], w0[1], w1[1], w2[1]);
+    uint2* s2 = reinterpret_cast<uint2*>(st);
+    s2[(0 * 4 * R + a_unit) * 2 + a_half] = make_uint2(w0[0], w0[1]);
+    s2[(1 * 4 * R + a_unit) * 2 + a_half] = make_uint2(w1[0], w1[1]);
+    s2[(2 * 4 * R + a_unit) * 2 + a_half] = make_uint2(w2[0], w2[1]);
+  };
+  struct Pre {
+    f32x4_t av;
+    uint4 bv[kQ1];
+  };
+  Pre preA, preB;
+  auto fetch1 = [&](int u, Pre& pre) {
+#pragma unroll
+    for (int i = 0; i < kQ1; ++i)
+      if (tid + kGuX3Threads * i < UB1) pre.bv[i] = P1[(size_t)u * UB1 + tid + kGuX3Threads * i];
+    pre.av = ldv4((u < NS / 2 ? hsrc : gsrc - D) + 32 * u);
+  };
+  auto park1 = [&](uint4* st, const Pre& pre) {
+#pragma unroll
+    for (int i = 0; i < kQ1; ++i)
+      if (tid + kGuX3Threads * i < UB1) st[UA + tid + kGuX3Threads * i] = pre.bv[i];
+    park_rows(st, pre.av);
+  };
+  f32x4_t z[2][NL], rr[2][NL];
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL) {
+    const int f = 16 * (fg * NL + TL) + a;
+    const float b0 = bias[f], b1 = bias[D + f];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      z[rt][TL] = f32x4_t{b0, b0, b0, b0};
+      rr[rt][TL] = f32x4_t{b1, b1, b1, b1};
+    }
+  }
+  // operands of one slice: rows (A) and kernel columns (B), three planes each
+  auto read_a = [&](const uint4* st, int rt, bf16x8_t (&av)[3]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      av[pl] = __builtin_bit_cast(bf16x8_t, st[(pl * 4 + q) * R + 32 * rg + 16 * rt + a]);
+  };
+  auto read_b = [&](const uint4* st, int ncols, int col, bf16x8_t (&bv)[3]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) bv[pl] = __builtin_bit_cast(bf16x8_t, st[UA + (pl * 4 + q) * ncols + col]);
+  };
+  // acc += A B: all nine cross products, smallest first
+  auto mma9 = [&](f32x4_t& acc, const bf16x8_t (&av)[3], const bf16x8_t (&bv)[3]) {
+    acc = mfma_bf16(av[2], bv[2], acc);
+    acc = mfma_bf16(av[1], bv[2], acc);
+    acc = mfma_bf16(av[2], bv[1], acc);
+    acc = mfma_bf16(av[0], bv[2], acc);
+    acc = mfma_bf16(av[2], bv[0], acc);
+    acc = mfma_bf16(av[1], bv[1], acc);
+    acc = mfma_bf16(av[0], bv[1], acc);
+    acc = mfma_bf16(av[1], bv[0], acc);
+    acc = mfma_bf16(av[0], bv[0], acc);
+  };
+  // One slice of phase 1 on stage `cur` while slice u + 1 is parked in stage `oth`.  The MFMAs of a wave are paced by
+  // the matrix pipe (16 cycles each); everything else of the iteration - the LDS reads of the second feature tile's
+  // operands, the split of the next row slice and its LDS stores - is interleaved with them (sched_group_barrier:
+  // without it the compiler emits reads, stores and MFMAs as three serial blocks and the pipe idles half the time).
+  // (Row tiles beyond tile_rows are multiplied too - wasted only in launches too small to fill the chip - so that
+  //  the iteration is one basic block.)
+  auto slice1 = [&](const uint4* cur, uint4* oth, const Pre* pre, bool do_park) {
+    bf16x8_t av[2][3], bz[NL][3], br[NL][3];
+    read_a(cur, 0, av[0]);
+    read_a(cur, 1, av[1]);
+    read_b(cur, 2 * D, 16 * (fg * NL) + a, bz[0]);
+    read_b(cur, 2 * D, D + 16 * (fg * NL) + a, br[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int TL = 1; TL < NL; ++TL) {
+      read_b(cur, 2 * D, 16 * (fg * NL + TL) + a, bz[TL]);
+      read_b(cur, 2 * D, D + 16 * (fg * NL + TL) + a, br[TL]);
+    }
+    if (do_park) park1(oth, *pre);
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL) {
+      mma9(z[0][TL], av[0], bz[TL]);
+      mma9(z[1][TL], av[1], bz[TL]);
+      mma9(rr[0][TL], av[0], br[TL]);
+      mma9(rr[1][TL], av[1], br[TL]);
+    }
+    // 36 NL MFMAs; 6 (NL - 1) LDS reads, ~10 LDS stores and ~45 vector instructions to hide between them
+#pragma unroll
+    for (int i = 0; i < 6 * (NL - 1); ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // VALU
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+    }
+  };
+  fetch1(0, preA);
+  fetch1(1, preB);
+  park1(stage, preA);
+  __syncthreads();
+  float hreg[2][NL][4];
+  auto load_hreg = [&]() {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          hreg[rt][TL][gq] = p.h[(row0 + 32 * rg + 16 * rt + 4 * q + gq) * D + 16 * (fg * NL + TL) + a];
+  };
+  // iteration u: slice u is in stage u & 1, slice u + 1 in registers, slice u + 2 is requested
+  for (int u = 0; u < NS; u += 2) {
+    if (u + 2 < NS) fetch1(u + 2, preA);
+    else load_hreg();
+    slice1(stage, stage + ST1, &preB, true);
+    __syncthreads();
+    if (u + 3 < NS) fetch1(u + 3, preB);
+    slice1(stage + ST1, stage, &preA, u + 2 < NS);
+    __syncthreads();
+  }
+  // ---- gates; r * h (f32) into LDS: phase 2 parks its first NS / 2 row slices from there
+  struct Pre2 {
+    f32x4_t av;
+    uint4 bv[kQ2];
+  };
+  Pre2 qA, qB;
+  auto fetch2 = [&](int u, Pre2& pre) {
+#pragma unroll
+    for (int i = 0; i < kQ2; ++i)
+      if (tid + kGuX3Threads * i < UB2) pre.bv[i] = P2[(size_t)u * UB2 + tid + kGuX3Threads * i];
+    if (u >= NS / 2) pre.av = ldv4(gsrc + 32 * (u - NS / 2));
+  };
+  auto park2 = [&](int u, uint4* st, const Pre2& pre) {
+#pragma unroll
+    for (int i = 0; i < kQ2; ++i)
+      if (tid + kGuX3Threads * i < UB2) st[UA + tid + kGuX3Threads * i] = pre.bv[i];
+    park_rows(st, u < NS / 2 ? ldv4(rhs + a_row * LDR + 32 * u + 4 * a_pc) : pre.av);
+  };
+  fetch2(0, qA);
+  fetch2(1, qB);
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        z[rt][TL][gq] = fsig(z[rt][TL][gq]);
+        rhs[(32 * rg + 16 * rt + 4 * q + gq) * LDR + 16 * (fg * NL + TL) + a] = fsig(rr[rt][TL][gq]) * hreg[rt][TL][gq];
+      }
+  f32x4_t tt[2][NL];
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL) {
+    const float b2 = bias[2 * D + 16 * (fg * NL + TL) + a];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) tt[rt][TL] = f32x4_t{b2, b2, b2, b2};
+  }
+  __syncthreads();  // r * h complete (and every read of phase 1's stages is done)
+  uint4* const stage2 = stage;  // 2 x ST2 units
+  park2(0, stage2, qA);
+  __syncthreads();
+  auto slice2 = [&](const uint4* cur, int u_next, uint4* oth, const Pre2* pre, bool do_park) {
+    bf16x8_t av[2][3], bv[NL][3];
+    read_a(cur, 0, av[0]);
+    read_a(cur, 1, av[1]);
+    read_b(cur, D, 16 * (fg * NL) + a, bv[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int TL = 1; TL < NL; ++TL) read_b(cur, D, 16 * (fg * NL + TL) + a, bv[TL]);
+    if (do_park) park2(u_next, oth, *pre);
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL) {
+      mma9(tt[0][TL], av[0], bv[TL]);
+      mma9(tt[1][TL], av[1], bv[TL]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3 * (NL - 1); ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+    }
+  };
+  for (int u = 0; u < NS; u += 2) {
+    if (u + 2 < NS) fetch2(u + 2, qA);
+    slice2(stage2, u + 1, stage2 + ST2, &qB, true);
+    __syncthreads();
+    if (u + 3 < NS) fetch2(u + 3, qB);
+    slice2(stage2 + ST2, u + 2, stage2, &qA, u + 2 < NS);
+    __syncthreads();
+  }
+  // ---- blend, LayerNorm over the D features of a row, residual (models/layers.py:150-156): as wide_update_kernel
+  float sum[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL) {
+        const float hv = hreg[rt][TL][gq];
+        const float nv = (1.0f - z[rt][TL][gq]) * hv + z[rt][TL][gq] * ftanh(tt[rt][TL][gq]);
+        tt[rt][TL][gq] = nv;
+        sacc += nv;
+      }
+      sum[rt][gq] = row16_sum_f(sacc);
+      if (a == 0) part[fg * R + 32 * rg + 16 * rt + 4 * q + gq] = sum[rt][gq];
+    }
+  __syncthreads();
+  float mean[2][4], inv[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int rl = 32 * rg + 16 * rt + 4 * q + gq;
+      float ms = 0.f;
+#pragma unroll
+      for (int f2 = 0; f2 < FG; ++f2) ms += part[f2 * R + rl];
+      mean[rt][gq] = ms * (1.0f / D);
+      float vs = 0.f;
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL) {
+        const float dv = tt[rt][TL][gq] - mean[rt][gq];
+        vs = fmaf(dv, dv, vs);
+      }
+      vs = row16_sum_f(vs);
+      if (a == 0) part[FG * R + fg * R + rl] = vs;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int rl = FG * R + 32 * rg + 16 * rt + 4 * q + gq;
+      float vs = 0.f;
+#pragma unroll
+      for (int f2 = 0; f2 < FG; ++f2) vs += part[f2 * R + rl];
+      inv[rt][gq] = 1.0f / sqrtf(vs * (1.0f / D) + p.eps);
+    }
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL) {
+    const int f = 16 * (fg * NL + TL) + a;
+    const float gm = bias[3 * D + f], bt = bias[4 * D + f];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int64_t row = row0 + 32 * rg + 16 * rt + 4 * q + gq;
+        if (row < row_end)
+          p.h[row * D + f] = (tt[rt][TL][gq] - mean[rt][gq]) * inv[rt][gq] * gm + bt + hreg[rt][TL][gq];
+      }
+  }
+}
+
 // a8: one thread per 16-byte piece of a pooled row, 4 rows in flight, ascending n.
 __global__ __launch_bounds__(256) void wide_pool_kernel(Inputs in, const int32_t* __restrict__ kept,
                                                         const int32_t* __restrict__ rowbase,
@@ -939,6 +1275,46 @@ __global__ void wide_gu_image_kernel(const float* __restrict__ src, float* __res
   }
 }
 
+// The same for mode 3: [Wz|Wr] and Wh as three bf16 planes (w = b0 + b1 + b2 exactly) in 32-k slices of MFMA B-operand
+// order [slice][plane][k octet][column][8 k] (16-byte units: a lane's operand of one v_mfma_f32_16x16x32_bf16), then the
+// five f32 vectors.
+__global__ void wide_gu_image_x3_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int D) {
+  const float* Wz = src;
+  const float* bz = Wz + 2 * D * D;
+  const float* Wr = bz + D;
+  const float* br = Wr + 2 * D * D;
+  const float* Wh = br + D;
+  const float* bh = Wh + 2 * D * D;
+  const float* gamma = bh + D;
+  const float* beta = gamma + D;
+  const int NS = D / 16;                    // 32-k slices of a 2D-deep GEMM
+  const int n1 = 2 * D * 2 * D, n2 = 2 * D * D;  // weights of [Wz|Wr], of Wh
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n1 + n2; t += gridDim.x * blockDim.x) {
+    const bool first = t < n1;
+    const int e = first ? t : t - n1, ncol = first ? 2 * D : D;
+    // e = ((u * 4 + kq) * ncol + col) * 8 + j   (plane-independent index inside a slice's plane)
+    const int j = e & 7, col = (e >> 3) % ncol, kq = ((e >> 3) / ncol) & 3, u = ((e >> 3) / ncol) >> 2;
+    const int k = 32 * u + 8 * kq + j;
+    const float w = first ? (col < D ? Wz[k * D + col] : Wr[k * D + col - D]) : Wh[k * D + col];
+    const unsigned u0 = __float_as_uint(w) & 0xffff0000u;
+    const float r1 = w - __uint_as_float(u0);
+    const unsigned u1 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(u1);
+    const unsigned u2 = __float_as_uint(r2);  // <= 8 significant bits left: its low half is zero
+    const size_t plane = (size_t)4 * ncol * 8;                   // bf16 elements of one plane of a slice
+    const size_t base = (first ? 0 : (size_t)NS * 3 * 4 * 2 * D * 8) + (size_t)u * 3 * plane + ((size_t)kq * ncol + col) * 8 + j;
+    dst[base] = (unsigned short)(u0 >> 16);
+    dst[base + plane] = (unsigned short)(u1 >> 16);
+    dst[base + 2 * plane] = (unsigned short)(u2 >> 16);
+  }
+  float* vec = reinterpret_cast<float*>(dst + (size_t)NS * 3 * 4 * 3 * D * 8);
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < 5 * D; t += gridDim.x * blockDim.x) {
+    const int which = t / D, f = t - which * D;
+    const float* v = which == 0 ? bz : which == 1 ? br : which == 2 ? bh : which == 3 ? gamma : beta;
+    vec[t] = v[f];
+  }
+}
+
 }  // namespace wide
 
 // ------------------------------------------------------------------------------------------------------------
@@ -950,22 +1326,26 @@ bool encoder_wide_supported(int N, int E, int D, int K, int S, int Vb) {
          Vb <= kMaxVb;
 }
 
-size_t encoder_wide_workspace_bytes(int n_ions, int B, int N, int E, int D, int S, int Vb) {
-  return wide::ws_layout(n_ions, B, N, E, D, S, Vb).total;
+size_t encoder_wide_workspace_bytes(int n_ions, int B, int N, int E, int D, int S, int Vb, bool x3) {
+  return wide::ws_layout(n_ions, B, N, E, D, S, Vb, x3).total;
 }
 
-size_t encoder_wide_prepared_bytes(int D, int S, int Vb) { return wide::prepared_bytes(D, S, Vb); }
+size_t encoder_wide_prepared_bytes(int D, int S, int Vb, bool x3) { return wide::prepared_bytes(D, S, Vb, x3); }
 
-int launch_encoder_wide_prepare(const float* weights, const float* bond_table, int D, int K, int S, int Vb,
+int launch_encoder_wide_prepare(const float* weights, const float* bond_table, int D, int K, int S, int Vb, bool x3,
                                 void* prepared, hipStream_t s) {
   using namespace wide;
   float* img = static_cast<float*>(prepared);
   const size_t canon = (size_t)impnn_encoder_step_floats(D, K);
   for (int st = 0; st < S; ++st) {
     const float* w = weights + (size_t)st * canon;
-    float* dst = img + (size_t)st * step_floats(D, Vb);
+    float* dst = img + (size_t)st * step_floats(D, Vb, x3);
     if (int rc = launch_bond_type_matrices(bond_table, w, dst, Vb, K, D, s)) return rc;
-    wide_gu_image_kernel<<<64, 256, 0, s>>>(w + (size_t)K * D * D, dst + (size_t)Vb * D * D, D);
+    if (x3)
+      wide_gu_image_x3_kernel<<<128, 256, 0, s>>>(w + (size_t)K * D * D,
+                                                  reinterpret_cast<unsigned short*>(dst + (size_t)Vb * D * D), D);
+    else
+      wide_gu_image_kernel<<<64, 256, 0, s>>>(w + (size_t)K * D * D, dst + (size_t)Vb * D * D, D);
     if (int rc = check_launch("encoder_wide_prepare")) return rc;
   }
   return IMPNN_OK;
@@ -990,7 +1370,8 @@ int raise_lds(K kern, size_t bytes) {
 
 int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   using namespace wide;
-  const Ws w = ws_layout(a.n_ions, a.B, a.N, a.E, a.D, a.S, a.Vb);
+  const bool x3 = a.mode == 3;
+  const Ws w = ws_layout(a.n_ions, a.B, a.N, a.E, a.D, a.S, a.Vb, x3);
   if (!aligned16(a.workspace)) return fail(IMPNN_E_BADARG, "encoder_fused: workspace must be 16B aligned");
   if (w.vmax >= INT_MAX || w.rmax >= INT_MAX)  // sorted positions and compact rows are 32-bit indices
     return fail(IMPNN_E_UNSUPPORTED, "encoder_fused: batch of %d pairs x (N=%d, E=%d) exceeds 32-bit row / edge indices",
@@ -1026,8 +1407,8 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
       if (!aligned16(a.prepared[g])) return fail(IMPNN_E_BADARG, "encoder_fused: prepared weights must be 16B aligned");
       img[g] = static_cast<const float*>(a.prepared[g]);
     } else {
-      float* dst = reinterpret_cast<float*>(base + w.img + (size_t)g * prepared_bytes(a.D, a.S, a.Vb));
-      if (int rc = launch_encoder_wide_prepare(a.weights[g], a.bond_table, a.D, a.K, a.S, a.Vb, dst, s)) return rc;
+      float* dst = reinterpret_cast<float*>(base + w.img + (size_t)g * prepared_bytes(a.D, a.S, a.Vb, x3));
+      if (int rc = launch_encoder_wide_prepare(a.weights[g], a.bond_table, a.D, a.K, a.S, a.Vb, x3, dst, s)) return rc;
       img[g] = dst;
     }
   }
@@ -1038,13 +1419,13 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   const size_t msg_lds = ((size_t)a.D * (a.D + 4) + 2 * (size_t)te * (a.D + 4)) * 4 + (size_t)(w.nT + 1) * 4;
   const int nt = a.D / 16;
   constexpr int R = kRT;
-  const size_t gu_lds = gu_lds_floats(a.D) * 4;
+  const size_t gu_lds = x3 ? gu_x3_lds_bytes(a.D) : gu_lds_floats(a.D) * 4;
   if (a.D == 128) {
     if (int rc = raise_lds<0>(wide_message_kernel<8, 64>, msg_lds)) return rc;
-    if (int rc = raise_lds<1>(wide_update_kernel<8>, gu_lds)) return rc;
+    if (int rc = x3 ? raise_lds<4>(wide_update_x3_kernel<8>, gu_lds) : raise_lds<1>(wide_update_kernel<8>, gu_lds)) return rc;
   } else {
     if (int rc = raise_lds<2>(wide_message_kernel<4, 128>, msg_lds)) return rc;
-    if (int rc = raise_lds<3>(wide_update_kernel<4>, gu_lds)) return rc;
+    if (int rc = x3 ? raise_lds<5>(wide_update_x3_kernel<4>, gu_lds) : raise_lds<3>(wide_update_kernel<4>, gu_lds)) return rc;
   }
   const int64_t red_threads = w.rmax * (a.D / 4);
   // update tiles: kRT rows, or 16 rows for batches of up to ~100 pairs (the kept rows are only known on the device: the
@@ -1068,7 +1449,7 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     if (sp && sb >= ((size_t)gu_grid + cus) * 8 * sizeof(unsigned long long)) stamps = static_cast<unsigned long long*>(sp);
   }
   for (int stp = 0; stp < a.S; ++stp) {
-    const size_t step_off = (size_t)stp * step_floats(a.D, a.Vb);
+    const size_t step_off = (size_t)stp * step_floats(a.D, a.Vb, x3);
     MsgParams mp{};
     mp.h = F(w.h); mp.m = F(w.m);
     mp.img[0] = img[0]; mp.img[1] = img[1];
@@ -1088,8 +1469,14 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     gp.gu_off = step_off + (size_t)a.Vb * a.D * a.D;
     gp.meta = I(w.meta); gp.eps = a.ln_eps; gp.n_ions = a.n_ions; gp.tile_rows = tile_rows;
     gp.stamps = stamps;
-    if (nt == 8) wide_update_kernel<8><<<gu_grid, kGuThreads, gu_lds, s>>>(gp);
-    else wide_update_kernel<4><<<gu_grid, kGuThreads, gu_lds, s>>>(gp);
+    if (x3) {
+      if (nt == 8) wide_update_x3_kernel<8><<<gu_grid, kGuX3Threads, gu_lds, s>>>(gp);
+      else wide_update_x3_kernel<4><<<gu_grid, kGuX3Threads, gu_lds, s>>>(gp);
+    } else if (nt == 8) {
+      wide_update_kernel<8><<<gu_grid, kGuThreads, gu_lds, s>>>(gp);
+    } else {
+      wide_update_kernel<4><<<gu_grid, kGuThreads, gu_lds, s>>>(gp);
+    }
   }
   const int64_t pool_threads = (int64_t)mols * (a.D / 4);
   wide_pool_kernel<<<(unsigned)((pool_threads + 255) / 256), 256, 0, s>>>(in, I(w.kept), I(w.rowbase), F(w.h),

@@ -67,7 +67,7 @@ def test_encoder_shape_coverage_is_reported():
     assert lib.impnn_encoder_workspace_bytes(2, 64, 40, 80, 64, 8, 3, 72, TYPED, 0, C.byref(need)) == 0        # D=64
     assert lib.impnn_encoder_workspace_bytes(2, 64, 40, 80, 48, 8, 3, 72, TYPED, 0, C.byref(need)) == -2       # D=48
     assert lib.impnn_encoder_workspace_bytes(2, 64, 40, 600, 128, 8, 3, 72, TYPED, 0, C.byref(need)) == -2     # E > 512
-    assert lib.impnn_encoder_workspace_bytes(2, 64, 40, 80, 128, 8, 3, 72, 3, 0, C.byref(need)) == -2          # no f32x3
+    assert lib.impnn_encoder_workspace_bytes(2, 64, 40, 80, 128, 8, 3, 72, 3, 0, C.byref(need)) == 0           # f32x3 (round 3)
     # K = D*D (train_melting_point.py:146): the typed mode covers it (BASELINE config 3), the pull form does not
     assert lib.impnn_encoder_workspace_bytes(2, 8192, 40, 80, 32, 1024, 4, 72, TYPED, 0, C.byref(need)) == 0
     assert lib.impnn_encoder_workspace_bytes(2, 4096, 40, 80, 32, 1024, 3, 72, F32, 0, C.byref(need)) == -2
@@ -84,6 +84,7 @@ def test_encoder_shape_coverage_is_reported():
     assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 80, 32, 8, 3, 72, F32, -1, C.byref(need)) == -1
     assert lib.impnn_encoder_prepared_bytes(32, 3, 72, 3) > lib.impnn_encoder_prepared_bytes(32, 3, 72, TYPED) > lib.impnn_encoder_prepared_bytes(32, 3, 72, F32) > 0
     assert lib.impnn_encoder_prepared_bytes(128, 6, 72, TYPED) == 6 * (72 * 128 * 128 + 6 * 128 * 128 + 5 * 128) * 4
+    assert lib.impnn_encoder_prepared_bytes(128, 6, 72, 3) == 6 * (72 * 128 * 128 + 9 * 128 * 128 + 5 * 128) * 4   # bf16 planes
     assert lib.impnn_encoder_prepared_bytes(128, 6, 72, F32) == 0 and lib.impnn_encoder_prepared_bytes(48, 6, 72, TYPED) == 0
 
 

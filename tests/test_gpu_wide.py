@@ -19,10 +19,14 @@ def to_dev(inputs):
     return {k: torch.from_numpy(np.ascontiguousarray(v)).to(DEV) for k, v in inputs.items()}
 
 
-def make_model(w, Va, Vb, D, K=8):
+def make_model(w, Va, Vb, D, K=8, mode="auto"):
     m = MM.build_model(Va, Vb, atom_dim=D, bond_dim=K, num_steps=weights.num_steps_of(w), device=DEV)
     m.load_weights(w)
+    m.encoder_mode = mode
     return m
+
+
+WIDE_MODES = ["f32t", "f32x3"]  # exact f32 MFMA; GatedUpdate as bf16x9 emulation (round 3: wide_update_x3_kernel)
 
 
 def oracle_pooled(w, inp):
@@ -35,21 +39,25 @@ def oracle_pooled(w, inp):
                                               (128, 7, 30, 1, 1, 50, 5), (128, 40, 80, 5, 0, 30, 6),
                                               (64, 1, 0, 8, 2, 9, 7), (128, 100, 240, 8, 1, 16, 8),
                                               (64, 128, 512, 3, 1, 5, 9), (128, 256, 40, 2, 2, 3, 10)])
-def test_wide_encoder_random_shapes(D, N, E, K, S, B, seed):
+@pytest.mark.parametrize("mode", WIDE_MODES)
+def test_wide_encoder_random_shapes(D, N, E, K, S, B, seed, mode):
     Va, Vb = 30, 11
     inp = synthetic.make_batch(B, max_atoms=N, max_edges=E, atom_vocab_size=Va, bond_vocab_size=Vb,
                                min_atoms=min(3, N), seed=seed)
     w = weights.init_weights("viscosity", Va, Vb, atom_dim=D, bond_dim=K, num_steps=S, seed=seed + 100, perturb=True)
     m = make_model(w, Va, Vb, D, K)
-    assert m.resolve_encoder_mode(N, E) == "f32t"
+    assert m.resolve_encoder_mode(N, E) == "f32t"       # auto = exact f32
+    m.encoder_mode = mode
+    assert m.resolve_encoder_mode(N, E) == mode
     pc, pa = m.encode_pooled(to_dev(inp), fused=True)
     rc, ra = oracle_pooled(w, inp)
     assert_close(pc.cpu().numpy(), rc, what="cat pooled")
     assert_close(pa.cpu().numpy(), ra, what="an pooled")
 
 
+@pytest.mark.parametrize("mode", WIDE_MODES)
 @pytest.mark.parametrize("D", [64, 128])
-def test_wide_encoder_adversarial_graphs(D):
+def test_wide_encoder_adversarial_graphs(D, mode):
     """Edges that name padding atoms, self loops, 4x duplicated bonds (trainer expansion), id-0 holes, all-padding
     molecules, one atom with 64 in-edges, bond ids outside the vocabulary - the general contract."""
     rng = np.random.default_rng(42)
@@ -67,7 +75,7 @@ def test_wide_encoder_adversarial_graphs(D):
     inp = {"cat_atom": ids, "cat_bond": bond, "cat_connectivity": conn,
            "an_atom": ids[::-1].copy(), "an_bond": bond[::-1].copy(), "an_connectivity": conn[::-1].copy()}
     w = weights.init_weights("viscosity", Va, Vb, atom_dim=D, bond_dim=K, num_steps=S, seed=9, perturb=True)
-    m = make_model(w, Va, Vb, D, K)
+    m = make_model(w, Va, Vb, D, K, mode=mode)
     pc, pa = m.encode_pooled(to_dev(inp), fused=True)
     rc, ra = oracle_pooled(w, inp)
     assert_close(pc.cpu().numpy(), rc, what="cat pooled")
@@ -245,3 +253,32 @@ def test_wide_encoder_fuzz_against_the_oracle(seed):
     what = f"(D={D} N={N} E={E} K={K} S={S} B={B} Va={Va} Vb={Vb})"
     assert_close(pc.cpu().numpy(), rc, what="cat pooled " + what)
     assert_close(pa.cpu().numpy(), ra, what="an pooled " + what)
+
+
+def test_wide_f32x3_error_within_twice_f32t_and_bitwise_properties():
+    """Mode f32x3 at atom_dim 128, 6 steps (BASELINE configs[4]'s forward shape, batch 1024): error against the fp64
+    oracle within twice the exact-f32 mode's (max, rms, elementwise), run-to-run and shard-concatenation bitwise."""
+    Va, Vb, B = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, 1024
+    inp = synthetic.make_batch(B, seed=51)
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=128, bond_dim=8, num_steps=6, seed=52, perturb=True)
+    idx = np.random.default_rng(4).choice(B, size=24, replace=False)
+    sub = {k: v[idx] for k, v in inp.items()}
+    ref = np.concatenate(oracle_pooled(w, sub))
+    d, err = to_dev(inp), {}
+    for mode in WIDE_MODES:
+        m = make_model(w, Va, Vb, 128, mode=mode)
+        pc, pa = m.encode_pooled(d, fused=True)
+        got = np.concatenate([pc.cpu().numpy()[idx], pa.cpu().numpy()[idx]]).astype(np.float64)
+        dd = np.abs(got - ref)
+        err[mode] = (float(dd.max() / np.abs(ref).max()), float(np.sqrt(np.mean(dd * dd)) / np.sqrt(np.mean(ref * ref))),
+                     float(np.max(dd / np.maximum(np.abs(ref), 1e-3 * np.abs(ref).max()))))
+        if mode == "f32x3":
+            c2, a2 = m.encode_pooled(d, fused=True)
+            assert torch.equal(c2, pc) and torch.equal(a2, pa)
+            h = B // 2 + 5
+            c0, a0 = m.encode_pooled({k: v[:h].contiguous() for k, v in d.items()}, fused=True)
+            c1, a1 = m.encode_pooled({k: v[h:].contiguous() for k, v in d.items()}, fused=True)
+            assert torch.equal(torch.cat([c0, c1]), pc) and torch.equal(torch.cat([a0, a1]), pa)
+    for i in range(3):
+        assert err["f32x3"][i] <= 2.0 * err["f32t"][i] + 1e-7, err
+    assert err["f32x3"][0] <= 1e-5 and err["f32t"][0] <= 1e-5, err

@@ -15,8 +15,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/$R/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/$R/prof_wide -- python3 $ROOT/tools/wide_probe.py > $ROOT/gpurun_out/$R/prof_wide.log 2>&1
 cd $ROOT
 python tools/wide_probe.py > gpurun_out/$R/wide_probe.json 2>> gpurun_out/$R/bench.err
-if [ -f ionic_mpnn_amd/csrc/ab/lib_STAMPS.so ]; then
-  IMPNN_LIB=$ROOT/ionic_mpnn_amd/csrc/ab/lib_STAMPS.so python tools/wide_stamps.py > gpurun_out/$R/wide_stamps.txt 2>&1
+if [ -f ionic_mpnn_amd/csrc/ab/lib_STAMPS.so ]; then  # (a -DIMPNN_DIAG_WIDE_STAMPS build of the CURRENT sources)
+  IMPNN_LIB=$ROOT/ionic_mpnn_amd/csrc/ab/lib_STAMPS.so python tools/wide_stamps.py > gpurun_out/$R/wide_stamps.txt 2>&1 || true
 fi
 bash tools/pmc_profile.sh gpurun_out/$R/pmc > /dev/null 2>&1
 cat gpurun_out/$R/bench.json
