@@ -274,6 +274,21 @@ __global__ void typed_image_kernel(TImageParams p, int s) {
 // Every plan_chunks workgroup of a share recomputes this (a handful of L2 hits) instead of reading it
 // from a separate single-workgroup kernel: one launch and one dependent stage fewer.
 // -----------------------------------------------------------------------------------------
+// Workgroups are dealt to the 8 XCDs round robin (workgroup j runs on XCD j % 8; observed placement, used for speed only).
+// The shares are numbered so that the first half of them - ion 0's, when the ions hold about the same number of rows -
+// belongs to workgroups on XCDs 0-3 and the second half to XCDs 4-7: an XCD's L2 then holds the type matrices of ONE ion
+// (1.7 MB at Vb = 72, S = 3) instead of both (3.4 MB of a 4 MB L2 that also streams the chunk records).
+// A bijection on [0, nwg): no result depends on it.
+__device__ __forceinline__ int xcd_slot(int j, int nwg) {
+#ifdef IMPNN_DIAG_NO_XCD_MAP
+  return j;
+#else
+  const int lo = (nwg >> 3) * 4 + ((nwg & 7) < 4 ? (nwg & 7) : 4);  // workgroups with j % 8 < 4
+  const int r = j & 7, qd = j >> 3;
+  return r < 4 ? qd * 4 + r : lo + qd * 4 + (r - 4);
+#endif
+}
+
 __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int lane, int& g, int& k0, int& bp0,
                                               int& t_lo, int& t_hi, bool& bad) {
   const int nblk = p.nblk;
@@ -315,8 +330,9 @@ __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int la
       nwg0 = n0;
       nwg1 = p.nwg - n0;
     }
-    g = j < nwg0 ? 0 : 1;
-    const int jj = j - (g ? nwg0 : 0);
+    const int jp = xcd_slot(j, p.nwg);
+    g = jp < nwg0 ? 0 : 1;
+    const int jj = jp - (g ? nwg0 : 0);
     const int nwg_g = g ? nwg1 : nwg0;
     const long long tg = tot[g];
     t_lo = (int)(tg * jj / nwg_g);
@@ -361,8 +377,9 @@ __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int la
     nwg0 = n0;
     nwg1 = p.nwg - n0;
   }
-  g = j < nwg0 ? 0 : 1;
-  const int jj = j - (g ? nwg0 : 0);
+  const int jp = xcd_slot(j, p.nwg);
+  g = jp < nwg0 ? 0 : 1;
+  const int jj = jp - (g ? nwg0 : 0);
   const int nwg_g = g ? nwg1 : nwg0;
   const long long tg = tot[g];
   t_lo = (int)(tg * jj / nwg_g);

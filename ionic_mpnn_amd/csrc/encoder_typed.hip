@@ -539,6 +539,9 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
           }
         }
         if (mstamp && wave == 1 && lane == 0) stamp[8] = __builtin_amdgcn_s_memtime();
+        // (Mode 3, measured and dropped: a static priority for two of a SIMD's four waves, so that they run ahead and the
+        //  vector work of one pair overlaps the bf16 MFMAs of the other: +2 % kernel time - the waves that fall behind
+        //  then set the length of the phase.)
         __builtin_amdgcn_s_setprio(1);
         if (s + 1 < p.S) {  // in flight under the GEMMs (see above)
           if (kPfWhere == 1) fetch_pf(s + 1);
