@@ -659,7 +659,11 @@ int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
   pp.typed = typed ? 1 : 0;
   pp.ecap = tecap_of(a.E);
   pp.n_ions = a.n_ions; pp.B = a.B; pp.N = a.N; pp.E = a.E; pp.Va = a.Va; pp.Vb = a.Vb;
-  pp.grid_sub = w.max_sub < 5 ? w.max_sub : 5;  // 5 x 256 workgroups of 256 threads are resident at once on 256 CUs (<= 96 VGPRs)
+  // chunk workgroups resident at once on 256 CUs: 5 per CU (pull records, <= 96 VGPRs) or 4 (typed, <= 128 VGPRs)
+  {
+    const int per_cu = typed ? 4 : 5;
+    pp.grid_sub = w.max_sub < per_cu ? w.max_sub : per_cu;
+  }
   pp.nwg = w.nwg;
   pp.max_sub = w.max_sub;
   pp.nblk = w.nblk;

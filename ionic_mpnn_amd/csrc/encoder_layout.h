@@ -306,7 +306,7 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 
 __device__ __forceinline__ bool edge_valid(int s, int t, int bid, int N, int Vb) {
   // models/layers.py:114-115 (src>0 & tgt>0); out-of-range indices behave as padding (impnn.h)
-  return s > 0 && t > 0 && s < N && t < N && (unsigned)bid < (unsigned)Vb;
+  return (unsigned)s - 1u < (unsigned)(N - 1) && (unsigned)t - 1u < (unsigned)(N - 1) && (unsigned)bid < (unsigned)Vb;
 }
 
 // plan side (encoder_plan.hip)

@@ -40,24 +40,39 @@ __global__ __launch_bounds__(64 * kPB) void plan_stats_kernel(PlanParams p) {
   const int32_t* bd = p.bond_ids[g] + (int64_t)b * p.E;
   // wave-level reductions through ballots (scalar unit), no cross-lane data movement
   int rmax = 0, cnt = 0;
-  for (int n0 = 0; n0 < p.N; n0 += 64) {
-    const int n = n0 + lane;
-    const unsigned long long hit = __ballot(n < p.N && ids[n] > 0);
-    if (hit) rmax = n0 + 64 - __builtin_clzll(hit);  // 1 + highest n with ids[n] > 0
-  }
+  const int id_first = lane < p.N ? ids[lane] : 0;  // requested with the edge slots below, looked at behind them
   int emax = 0;  // largest atom index on a valid edge (lane-local)
-  for (int e0 = 0; e0 < p.E; e0 += 64) {
-    const int e = e0 + lane;
-    bool ok = false;
-    if (e < p.E) {
-      const int2 st = *reinterpret_cast<const int2*>(cn + 2 * e);
-      ok = edge_valid(st.x, st.y, bd[e], p.N, p.Vb);
-      if (ok) {
-        const int m = st.x > st.y ? st.x : st.y;
-        emax = emax > m ? emax : m;
+  for (int e0 = 0; e0 < p.E; e0 += 256) {  // four 64-slot groups per turn: their loads are in flight together
+    int2 st[4];
+    int bid[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + 64 * u + lane;
+      st[u] = make_int2(0, 0);
+      bid[u] = -1;
+      if (e < p.E) {
+        st[u] = *reinterpret_cast<const int2*>(cn + 2 * e);
+        bid[u] = bd[e];
       }
     }
-    cnt += __builtin_popcountll(__ballot(ok));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = edge_valid(st[u].x, st[u].y, bid[u], p.N, p.Vb);
+      if (ok) {
+        const int m = st[u].x > st[u].y ? st[u].x : st[u].y;
+        emax = emax > m ? emax : m;
+      }
+      cnt += __builtin_popcountll(__ballot(ok));
+    }
+  }
+  {
+    const unsigned long long hit = __ballot(id_first > 0);
+    if (hit) rmax = 64 - __builtin_clzll(hit);  // 1 + highest n with ids[n] > 0
+  }
+  for (int n0 = 64; n0 < p.N; n0 += 64) {
+    const int n = n0 + lane;
+    const unsigned long long hit = __ballot(n < p.N && ids[n] > 0);
+    if (hit) rmax = n0 + 64 - __builtin_clzll(hit);
   }
   if (cnt > 0) {  // wave max of emax, bit by bit from the top (indices < 65536)
     bool alive = true;
@@ -289,6 +304,23 @@ __device__ __forceinline__ int xcd_slot(int j, int nwg) {
 #endif
 }
 
+// Share boundaries.  Every workgroup evaluates the same expressions on the same totals, so neighbouring shares agree on
+// their common boundary whatever the rounding: the formulas have to be deterministic and monotone in the share index,
+// not exact - float arithmetic (a handful of instructions) instead of 64-bit integer divisions (a few hundred, on the
+// critical path of a single wave).
+__device__ __forceinline__ int share_bound(int tg, int jj, int nwg_g) {  // first virtual row of share jj of nwg_g (tg rows)
+  if (jj <= 0) return 0;
+  if (jj >= nwg_g) return tg;
+  const int t = (int)((float)tg * (float)jj * __frcp_rn((float)nwg_g));
+  return t < 0 ? 0 : (t > tg ? tg : t);
+}
+__device__ __forceinline__ int ion_split(long long t0, long long t1, int nwg) {  // workgroups of ion 0, in proportion to its rows
+  int n0 = (t0 + t1) > 0 ? (int)((float)nwg * (float)t0 * __frcp_rn((float)(t0 + t1)) + 0.5f) : nwg / 2;
+  if (nwg >= 2) n0 = n0 < 1 ? 1 : (n0 > nwg - 1 ? nwg - 1 : n0);
+  return n0;
+}
+
+#define CSTAMP(i) do { if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int lane, int& g, int& k0, int& bp0,
                                               int& t_lo, int& t_hi, bool& bad) {
   const int nblk = p.nblk;
@@ -299,34 +331,34 @@ __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int la
   constexpr int kPU = 4;
   const int npass = (nblk + 64 * kPU - 1) / (64 * kPU);
   if (npass == 1) {  // B <= 4096 molecules per ion: one pass, everything stays in registers
+    // lane l holds blocks 4l .. 4l+3 of either ion: a prefix inside the lane and ONE wave scan per ion (a single wave
+    // runs this code alone: its instruction count is its latency)
     int v[2][kPU];
+    int anybad = 0;
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi)
 #pragma unroll
       for (int i = 0; i < kPU; ++i) {
-        const int k = lane + 64 * i;
+        const int k = kPU * lane + i;
         const int kk = k < nblk ? k : nblk - 1;
         const int x = gi < p.n_ions ? p.partial[(int64_t)gi * nblk + kk] : 0;
-        if (__ballot(k < nblk && (x & kPlanBadBit))) bad = true;
+        anybad |= k < nblk ? x : 0;
         v[gi][i] = k < nblk ? (x & ~kPlanBadBit) : 0;
       }
+    if (__ballot((anybad & kPlanBadBit) != 0)) bad = true;
     if (bad) return false;
-    int incl[2][kPU], tot[2];
+    CSTAMP(10);
+    int ex[2], tot[2];  // blocks before the lane's first, per ion
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi) {
-      int carry = 0;
-#pragma unroll
-      for (int i = 0; i < kPU; ++i) {
-        incl[gi][i] = carry + wave_incl_scan(v[gi][i]);
-        carry = __builtin_amdgcn_readlane(incl[gi][i], 63);
-      }
-      tot[gi] = carry;
+      const int s4 = v[gi][0] + v[gi][1] + v[gi][2] + v[gi][3];
+      const int incl = wave_incl_scan(s4);
+      ex[gi] = incl - s4;
+      tot[gi] = __builtin_amdgcn_readlane(incl, 63);
     }
     int nwg0 = p.nwg, nwg1 = 0;
     if (p.n_ions == 2) {
-      const long long t0 = tot[0], t1 = tot[1];
-      int n0 = (t0 + t1) > 0 ? (int)((p.nwg * t0 + (t0 + t1) / 2) / (t0 + t1)) : p.nwg / 2;
-      if (p.nwg >= 2) n0 = n0 < 1 ? 1 : (n0 > p.nwg - 1 ? p.nwg - 1 : n0);
+      int n0 = ion_split(tot[0], tot[1], p.nwg);
       nwg0 = n0;
       nwg1 = p.nwg - n0;
     }
@@ -334,26 +366,23 @@ __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int la
     g = jp < nwg0 ? 0 : 1;
     const int jj = jp - (g ? nwg0 : 0);
     const int nwg_g = g ? nwg1 : nwg0;
-    const long long tg = tot[g];
-    t_lo = (int)(tg * jj / nwg_g);
-    t_hi = (jj + 1 == nwg_g) ? (int)tg : (int)(tg * (jj + 1) / nwg_g);
+    const int tg = tot[g];
+    t_lo = share_bound(tg, jj, nwg_g);
+    t_hi = share_bound(tg, jj + 1, nwg_g);
     k0 = 0;
     bp0 = 0;
     if (t_hi <= t_lo) return false;
-    bool found = false;
-#pragma unroll
-    for (int i = 0; i < kPU; ++i) {
-      const int vv = g ? v[1][i] : v[0][i];
-      const int st = (g ? incl[1][i] : incl[0][i]) - vv;
-      const unsigned long long hit = __ballot(st <= t_lo && t_lo < st + vv);
-      if (hit && !found) {
-        const int src = __builtin_ctzll(hit);
-        k0 = 64 * i + src;
-        bp0 = __shfl(st, src);
-        found = true;
-      }
-    }
-    return found;
+    // the block that holds virtual row t_lo: first the lane (its four blocks cover [ex, ex + s4)), then the block in it
+    const int e0 = g ? ex[1] : ex[0];
+    const int a0 = g ? v[1][0] : v[0][0], a1 = g ? v[1][1] : v[0][1], a2 = g ? v[1][2] : v[0][2], a3 = g ? v[1][3] : v[0][3];
+    const unsigned long long hit = __ballot(e0 <= t_lo && t_lo < e0 + a0 + a1 + a2 + a3);
+    if (hit == 0ull) return false;
+    const int src = __builtin_ctzll(hit);
+    const int i_in = t_lo < e0 + a0 ? 0 : (t_lo < e0 + a0 + a1 ? 1 : (t_lo < e0 + a0 + a1 + a2 ? 2 : 3));
+    const int st_in = e0 + (i_in > 0 ? a0 : 0) + (i_in > 1 ? a1 : 0) + (i_in > 2 ? a2 : 0);
+    k0 = kPU * src + __builtin_amdgcn_readlane(i_in, src);
+    bp0 = __builtin_amdgcn_readlane(st_in, src);
+    return true;
   }
   long long tot[2] = {0, 0};
   for (int gi = 0; gi < p.n_ions; ++gi) {
@@ -366,14 +395,12 @@ __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int la
     }
     if (__ballot(anybad != 0)) bad = true;
     tot[gi] = wave_incl_scan(acc);
-    tot[gi] = __shfl((int)tot[gi], 63);
+    tot[gi] = __builtin_amdgcn_readlane((int)tot[gi], 63);
   }
   if (bad) return false;
   int nwg0 = p.nwg, nwg1 = 0;
   if (p.n_ions == 2) {
-    const long long t0 = tot[0], t1 = tot[1];
-    int n0 = (t0 + t1) > 0 ? (int)((p.nwg * t0 + (t0 + t1) / 2) / (t0 + t1)) : p.nwg / 2;
-    if (p.nwg >= 2) n0 = n0 < 1 ? 1 : (n0 > p.nwg - 1 ? p.nwg - 1 : n0);
+    int n0 = ion_split(tot[0], tot[1], p.nwg);
     nwg0 = n0;
     nwg1 = p.nwg - n0;
   }
@@ -381,9 +408,9 @@ __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int la
   g = jp < nwg0 ? 0 : 1;
   const int jj = jp - (g ? nwg0 : 0);
   const int nwg_g = g ? nwg1 : nwg0;
-  const long long tg = tot[g];
-  t_lo = (int)(tg * jj / nwg_g);
-  t_hi = (jj + 1 == nwg_g) ? (int)tg : (int)(tg * (jj + 1) / nwg_g);
+  const int tg = (int)tot[g];
+  t_lo = share_bound(tg, jj, nwg_g);
+  t_hi = share_bound(tg, jj + 1, nwg_g);
   k0 = 0;
   bp0 = 0;
   if (t_hi <= t_lo) return false;
@@ -400,10 +427,10 @@ __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int la
     if (hit) {
       const int src = __builtin_ctzll(hit);
       k0 = kbase + src;
-      bp0 = __shfl(st, src);
+      bp0 = __builtin_amdgcn_readlane(st, src);
       found = true;
     }
-    carry += __shfl(incl, 63);
+    carry += __builtin_amdgcn_readlane(incl, 63);
   }
   return found;
 }
@@ -426,103 +453,158 @@ __device__ __forceinline__ int block_excl_scan(int v, int32_t* wsum /* [4] LDS *
   return off + incl - v;
 }
 
-// TYPED: records of the typed encoder (encoder_layout.h "typed"): rows placed by EXACT descending in-degree, message
-// slots in jagged-diagonal order, edges grouped by bond type.  Dynamic LDS: the group table (16 B x (128 + Vb)).
-template <bool TYPED>
-__global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  // <= 96 VGPRs: 5 workgroups per CU
+// Share tables of a plan_chunks workgroup (LDS): the virtual-row prefix of the share's molecules and its next-fit chain
+struct ShareTab {
+  int32_t shst[kShareCap + 1];  // virtual-row prefix of the share's molecules (+ end)
+  int32_t cb[kMaxHops + 1];     // next-fit chain: share-local first molecule of every chunk (+ end)
+  int32_t vwin[256];            // virtual rows of the molecules around the share's expected start (see resolve_chain)
+  int chunk_s[3];               // first molecule of the share, chunks of the share, ion
+};
 
+// quotient of two non-negative ints through the float unit (exact for x < 2^24 after the two corrections)
+__device__ __forceinline__ int fast_div(int x, int d, float rd) {
+  int q = (int)((float)x * rd);
+  if (q * d > x) --q;
+  if ((q + 1) * d <= x) ++q;
+  return q;
+}
+
+// Wave 0 of every plan_chunks workgroup: resolve share j (resolve_share), list the virtual-row prefix of its molecules
+// and chain them into chunks (next-fit: a chunk takes molecules while their virtual rows stay <= kRCap).
+// The share of workgroup j starts near molecule jj * B / nwg_g when the molecules are of similar size; the virtual rows
+// of the 256 molecules around that guess are requested together with the partial sums (one round trip to memory
+// instead of two dependent ones) and parked in LDS; a share that starts elsewhere reads them from memory as before.
+__device__ __forceinline__ void resolve_chain(const PlanParams& p, int j, int slot_i, int lane, ShareTab& T) {
+  int gg = 0, w_lo = 0;
+  {
+    const int half = p.n_ions == 2 ? (p.nwg >> 1 > 0 ? p.nwg >> 1 : 1) : p.nwg;
+    const int jp = xcd_slot(j, p.nwg);
+    gg = (p.n_ions == 2 && jp >= half) ? 1 : 0;
+    const int jj = jp - (gg ? half : 0);
+    const int nw = gg ? (p.nwg - half > 0 ? p.nwg - half : 1) : half;
+    w_lo = (int)((float)jj * (float)p.B / (float)nw) - 64;  // (a guess: need not be exact)
+    w_lo = w_lo < 0 ? 0 : w_lo;
+    w_lo &= ~15;
+  }
+  int vw[4];
+  {
+    const int32_t* vrg = p.vr + (int64_t)gg * p.B;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = w_lo + 64 * i + lane;
+      vw[i] = vrg[m < p.B ? m : p.B - 1];
+    }
+  }
+  int g = 0, k0 = 0, bp0 = 0, t_lo = 0, t_hi = 0;
+  bool bad = false;
+  const bool have = resolve_share(p, j, lane, g, k0, bp0, t_lo, t_hi, bad);  // (its loads are behind the window's)
+  CSTAMP(11);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) T.vwin[64 * i + lane] = vw[i];
+  if (!have) {
+    if (lane == 0) {
+      T.chunk_s[0] = -1; T.chunk_s[1] = 0; T.chunk_s[2] = 0;
+      if (slot_i == 0) p.nsub[j] = 0;
+      if (bad && blockIdx.x == 0) p.header->overflow = 1;  // a molecule larger than a chunk: every share is empty
+    }
+    return;
+  }
+  const int32_t* vrg = p.vr + (int64_t)g * p.B;
+  int run = bp0;  // prefix at molecule k0 * 16
+  int first = -1, nsh = 0;                          // first share molecule (global index), count
+  int end_row = -1;                                 // first virtual row after the share's last molecule
+  __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): vwin is read back by this wave
+  // 64 molecules from mbase on: out of the window when they all lie in it, else from memory (clamped addresses)
+  auto vr_at = [&](int mbase) {
+    const int rel = mbase - w_lo;
+    if (g == gg && rel >= 0 && rel + 64 <= 256) return T.vwin[rel + lane];
+    const int m = mbase + lane;
+    return vrg[m < p.B ? m : p.B - 1];
+  };
+  int v_n1 = vr_at(k0 * kPB);
+  for (int mbase = k0 * kPB; mbase < p.B && end_row < 0; mbase += 64) {
+    const int m = mbase + lane;
+    const int v = v_n1;
+    v_n1 = vr_at(mbase + 64);
+    const int vv = m < p.B ? v : 0;
+    const int incl = wave_incl_scan(vv);
+    const int st = run + incl - vv;  // first virtual row of molecule m
+    const bool in = m < p.B && st >= t_lo && st < t_hi;
+    const unsigned long long inb = __ballot(in);
+    if (inb) {
+      if (first < 0) first = mbase + __builtin_ctzll(inb);
+      const int pos = nsh + __builtin_popcountll(inb & ((1ull << lane) - 1));
+      if (in && pos < kShareCap) T.shst[pos] = st;
+      nsh += __builtin_popcountll(inb);
+    }
+    const unsigned long long ge = __ballot(m < p.B && st >= t_hi);
+    if (ge) end_row = __builtin_amdgcn_readlane(st, __builtin_ctzll(ge));  // the next share's first molecule starts here
+    run += __builtin_amdgcn_readlane(incl, 63);
+  }
+  if (end_row < 0) end_row = run;           // ran off the end of the ion
+  nsh = nsh < kShareCap ? nsh : kShareCap;  // a share holds ~B/nwg molecules; launch_plan checks the cap
+  if (lane == 0) T.shst[nsh] = end_row;
+  __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): shst is read back by this wave below
+  CSTAMP(12);
+  int mb = 0, hop = 0;
+  if (nsh < 64) {  // the usual share: every lane keeps one prefix value, a hop is a ballot
+    const int st_l = T.shst[lane <= nsh ? lane : nsh];
+    while (mb < nsh && hop < kMaxHops) {
+      const int lim = __builtin_amdgcn_readlane(st_l, mb) + kRCap;
+      const unsigned long long okb = __ballot(lane > mb && lane <= nsh && st_l <= lim);
+      if (lane == 0) T.cb[hop] = mb;
+      ++hop;
+      // highest e in (mb, nsh] whose prefix fits: the chunk is [mb, e), the next one starts at e (a molecule alone otherwise)
+      mb = okb ? 63 - __builtin_clzll(okb) : mb + 1;
+    }
+  }
+  while (mb < nsh && hop < kMaxHops) {  // next-fit: chunk [mb, e), e = largest index with shst[e] - shst[mb] <= 256
+    const int lim = T.shst[mb] + kRCap;
+    int e = mb + 1;
+    for (int c0 = mb + 1; c0 <= nsh; c0 += 64) {
+      const int cidx = c0 + lane;
+      const bool ok = cidx <= nsh && T.shst[cidx <= nsh ? cidx : nsh] <= lim;
+      const unsigned long long okb = __ballot(ok);
+      if (okb == 0) break;
+      e = c0 + 63 - __builtin_clzll(okb);
+      if (okb != ~0ull) break;
+    }
+    if (lane == 0) T.cb[hop] = mb;
+    ++hop;
+    mb = e;
+  }
+  if (lane == 0) {
+    T.cb[hop] = nsh;
+    T.chunk_s[0] = first;
+    T.chunk_s[1] = hop;
+    T.chunk_s[2] = g;
+    if (slot_i == 0) p.nsub[j] = hop;
+  }
+}
+
+
+// Records of the pull-form encoder (modes 0 / 1): rows placed by descending in-degree class, CSR of in-edges in edge-slot
+// order.
+__global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  // <= 96 VGPRs: 5 workgroups per CU
   __shared__ int32_t moloff[kRCap + 2], molrows[kRCap], cnt[kRCap], place[kRCap], cursor[kRCap], rowptr[kRCap + 2];
-  __shared__ int32_t bins[TYPED ? 2 * kRCap + 2 : 48], tilemax[16], scratch[8];
-  __shared__ int32_t jdp[TYPED ? kRCap + 2 : 1], thist[TYPED ? kTVbMax : 1], tgb[TYPED ? kTVbMax : 1];
-  extern __shared__ uint4 grp[];  // TYPED only
+  __shared__ int32_t bins[48], tilemax[16], scratch[8];
   __shared__ uint16_t atomof[kRCap];  // placed row -> atom id clamped to [0, Va] (Va = the zero row)
   __shared__ uint32_t ent2[kECap + 1];
-  __shared__ int32_t shst[kShareCap + 1];  // virtual-row prefix of the share's molecules (+ end)
-  __shared__ int32_t cb[kMaxHops + 1];     // next-fit chain: share-local first molecule of every chunk (+ end)
-  __shared__ int chunk_s[3];               // first molecule of the share, chunks of the share, ion
+  __shared__ ShareTab T;
   __builtin_amdgcn_s_setprio(3);
-#define CSTAMP(i) do { if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
   CSTAMP(0);
   // grid = nwg x grid_sub: workgroup (j, slot_i) builds chunks slot_i, slot_i + grid_sub, ... of share j.  grid_sub
   // covers the usual chunk count, so that every workgroup is resident at once (slots beyond a share's chunks only
   // resolve and leave); shares with more chunks take another turn of the loop below.
   const int j = blockIdx.x / p.grid_sub, slot_i = blockIdx.x - j * p.grid_sub;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // ---- resolve the share: molecules whose first virtual row lies in [t_lo, t_hi), their prefix, and
-  //      the next-fit chain of chunks; wave 0 does it, everybody else waits at the barrier.
-  if (wave == 0) {
-    int g = 0, k0 = 0, bp0 = 0, t_lo = 0, t_hi = 0;
-    bool bad = false;
-    const bool have = resolve_share(p, j, lane, g, k0, bp0, t_lo, t_hi, bad);
-    if (!have) {
-      if (lane == 0) {
-        chunk_s[0] = -1; chunk_s[1] = 0; chunk_s[2] = 0;
-        if (slot_i == 0) p.nsub[j] = 0;
-        if (bad && blockIdx.x == 0) p.header->overflow = 1;  // a molecule larger than a chunk: every share is empty
-      }
-    } else {
-    const int32_t* vrg = p.vr + (int64_t)g * p.B;
-    int run = bp0;  // prefix at molecule k0 * 16
-    int first = -1, nsh = 0;                          // first share molecule (global index), count
-    int end_row = -1;                                 // first virtual row after the share's last molecule
-    // clamped addresses, masked values; the loads of the next two 64-molecule groups are always in flight
-    auto vr_at = [&](int m) { return vrg[m < p.B ? m : p.B - 1]; };
-    int v_n1 = vr_at(k0 * kPB + lane), v_n2 = vr_at(k0 * kPB + 64 + lane);
-    for (int mbase = k0 * kPB; mbase < p.B && end_row < 0; mbase += 64) {
-      const int m = mbase + lane;
-      const int v = v_n1;
-      v_n1 = v_n2;
-      v_n2 = vr_at(mbase + 128 + lane);
-      const int vv = m < p.B ? v : 0;
-      const int incl = wave_incl_scan(vv);
-      const int st = run + incl - vv;  // first virtual row of molecule m
-      const bool in = m < p.B && st >= t_lo && st < t_hi;
-      const unsigned long long inb = __ballot(in);
-      if (inb) {
-        if (first < 0) first = mbase + __builtin_ctzll(inb);
-        const int pos = nsh + __builtin_popcountll(inb & ((1ull << lane) - 1));
-        if (in && pos < kShareCap) shst[pos] = st;
-        nsh += __builtin_popcountll(inb);
-      }
-      const unsigned long long ge = __ballot(m < p.B && st >= t_hi);
-      if (ge) end_row = __shfl(st, __builtin_ctzll(ge));  // the next share's first molecule starts here
-      run += __shfl(incl, 63);
-    }
-    if (end_row < 0) end_row = run;           // ran off the end of the ion
-    nsh = nsh < kShareCap ? nsh : kShareCap;  // a share holds ~B/nwg molecules; launch_plan checks the cap
-    if (lane == 0) shst[nsh] = end_row;
-    __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): sst is read back by this wave below
-    int mb = 0, hop = 0;
-    while (mb < nsh && hop < kMaxHops) {  // next-fit: chunk [mb, e), e = largest index with shst[e] - shst[mb] <= 256
-      const int lim = shst[mb] + kRCap;
-      int e = mb + 1;
-      for (int c0 = mb + 1; c0 <= nsh; c0 += 64) {
-        const int cidx = c0 + lane;
-        const bool ok = cidx <= nsh && shst[cidx <= nsh ? cidx : nsh] <= lim;
-        const unsigned long long okb = __ballot(ok);
-        if (okb == 0) break;
-        e = c0 + 63 - __builtin_clzll(okb);
-        if (okb != ~0ull) break;
-      }
-      if (lane == 0) cb[hop] = mb;
-      ++hop;
-      mb = e;
-    }
-    if (lane == 0) {
-      cb[hop] = nsh;
-      chunk_s[0] = first;
-      chunk_s[1] = hop;
-      chunk_s[2] = g;
-      if (slot_i == 0) p.nsub[j] = hop;
-    }
-    }
-  }
+  if (wave == 0) resolve_chain(p, j, slot_i, lane, T);
   lds_barrier();
   CSTAMP(1);
-  const int first_mol = chunk_s[0], nhop = chunk_s[1], g = chunk_s[2];
+  const int first_mol = T.chunk_s[0], nhop = T.chunk_s[1], g = T.chunk_s[2];
   for (int sl = slot_i; sl < nhop; sl += p.grid_sub) {
-  const int mb_local = cb[sl], M = cb[sl + 1] - mb_local, m0 = first_mol + mb_local;
-  const int R = shst[mb_local + M] - shst[mb_local];
+  const int mb_local = T.cb[sl], M = T.cb[sl + 1] - mb_local, m0 = first_mol + mb_local;
+  const int R = T.shst[mb_local + M] - T.shst[mb_local];
   const int idx = j * p.max_sub + sl;
   if (tid == 0) reinterpret_cast<int4*>(p.desc)[idx] = make_int4(m0, M, 0, R | (g << 16));
   const int N = p.N, E = p.E;
@@ -530,7 +612,7 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
   const int32_t* conn_g = p.conn[g];
   const int32_t* bond_g = p.bond_ids[g];
   const int32_t* rows_g = p.rows + (int64_t)g * p.B;
-  unsigned char* rec = p.rec + (size_t)idx * (TYPED ? kTRecBytes : kRecBytes);
+  unsigned char* rec = p.rec + (size_t)idx * kRecBytes;
   uint16_t* r_rowptr = reinterpret_cast<uint16_t*>(rec + kRecRowptr);
   unsigned char* r_tilemax = rec + kRecTilemax;
   uint16_t* r_moloff = reinterpret_cast<uint16_t*>(rec + kRecMoloff);
@@ -558,7 +640,7 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
     }
   }
   for (int m = tid; m <= M; m += kRCap) {
-    const int off = shst[mb_local + m] - shst[mb_local];
+    const int off = T.shst[mb_local + m] - T.shst[mb_local];
     moloff[m] = off;
     r_moloff[m] = (uint16_t)off;
     if (m < M) {
@@ -568,13 +650,7 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
     }
   }
   cnt[tid] = 0;
-  if constexpr (TYPED) {
-    bins[tid] = 0;          // [0, 256): rows per placement bin (bin = 255 - in-degree)
-    bins[kRCap + tid] = 0;  // [256, 512): fill cursors
-    thist[tid] = 0;
-  } else {
-    if (tid < 48) bins[tid] = 0;
-  }
+  if (tid < 48) bins[tid] = 0;
   if (tid < 16) tilemax[tid] = 0;
   lds_barrier();
   CSTAMP(2);
@@ -613,37 +689,7 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
   //     the gather and LayerNorm are per row; the pool walks logical rows in order).
   const int my_deg = cnt[tid];
   int pos;
-  if constexpr (TYPED) {
-    // exact bins: 255 - in-degree (in-degree <= E <= 255); rows beyond the chunk go last
-    const int dcl = my_deg > 255 ? 255 : my_deg;
-    if (tid < R && my_deg > 255) p.header->overflow = 1;  // in-degrees travel as 8 bits: the encoder refuses this plan
-    if (tid < R) atomicAdd(&bins[255 - dcl], 1);
-    lds_barrier();
-    CSTAMP(4);
-    int tot = 0;
-    const int start = block_excl_scan(bins[tid], scratch, tot);  // rows placed before bin `tid` = rows with a larger in-degree
-    cursor[tid] = start;  // (reused below for the placed in-degrees: read back first)
-    lds_barrier();
-    // jagged-diagonal pointers: rows with in-degree > d are exactly the first cursor[255 - d] placed rows
-    const int sd = cursor[255 - tid];  // S_d for d = tid
-    int nedge = 0;
-    const int jd = block_excl_scan(sd, scratch, nedge);
-    jdp[tid] = jd;
-    if (tid == 0) jdp[kRCap] = nedge;
-    const int my_start = tid < R ? cursor[255 - dcl] : 0;
-    lds_barrier();
-    CSTAMP(5);
-    pos = tid < R ? my_start + atomicAdd(&bins[kRCap + 255 - dcl], 1) : 0;
-    // rows beyond the chunk: after the R real rows, in thread order (ballot ranks: no atomics needed)
-    {
-      const unsigned long long beyond = __ballot(tid >= R);
-      if (lane == 0) scratch[4 + wave] = __builtin_popcountll(beyond);
-      lds_barrier();
-      int before = 0;
-      for (int w = 0; w < wave; ++w) before += scratch[4 + w];
-      if (tid >= R) pos = R + before + __builtin_popcountll(beyond & ((1ull << lane) - 1));
-    }
-  } else {
+  {
     const int my_bin = tid >= R ? 0 : (my_deg >= 16 ? 1 : 17 - my_deg);  // bin 0 = beyond chunk (placed last)
     atomicAdd(&bins[my_bin], 1);
     lds_barrier();
@@ -663,7 +709,7 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
     CSTAMP(5);
     pos = bins[24 + my_bin] + atomicAdd(&bins[my_bin], -1) - 1;
   }
-  lds_barrier();  // (typed: every thread has read its start before cursor is rewritten)
+  lds_barrier();
   place[tid] = pos;
   cursor[pos] = my_deg;  // in-degree per placed row (scanned below)
   if (my_deg > 0) atomicMax(&tilemax[pos >> 4], my_deg > 255 ? 255 : my_deg);
@@ -690,17 +736,10 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
     const int excl = off + incl - my_cnt;
     rowptr[tid] = excl;
     cursor[tid] = excl;
-    if constexpr (TYPED) {
-      r_rowptr[tid] = (uint16_t)my_cnt;  // kTRecRowdeg: the encoder needs the in-degree, not the CSR offset
-      reinterpret_cast<uint16_t*>(rec + kTRecJdptr)[tid] = (uint16_t)jdp[tid];
-      if (tid == kRCap - 1) rowptr[kRCap] = excl + my_cnt;
-      if (tid < 2) reinterpret_cast<uint16_t*>(rec + kTRecJdptr)[kRCap + tid] = (uint16_t)jdp[kRCap];
-    } else {
-      r_rowptr[tid] = (uint16_t)excl;
-      if (tid == kRCap - 1) {
-        rowptr[kRCap] = excl + my_cnt;
-        r_rowptr[kRCap] = (uint16_t)(excl + my_cnt);
-      }
+    r_rowptr[tid] = (uint16_t)excl;
+    if (tid == kRCap - 1) {
+      rowptr[kRCap] = excl + my_cnt;
+      r_rowptr[kRCap] = (uint16_t)(excl + my_cnt);
     }
     if (tid < 16) r_tilemax[tid] = (unsigned char)tilemax[tid];
   }
@@ -715,7 +754,6 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
       const int mo = moloff[sm[k]];
       const int at = atomicAdd(&cursor[place[mo + sst[k].y]], 1);
       ent2[at] = ((uint32_t)se[k] << 16) | ((uint32_t)sbid[k] << 8) | (uint32_t)place[mo + sst[k].x];
-      if constexpr (TYPED) atomicAdd(&thist[sbid[k]], 1);
     }
   for (int slot = tid + kSC * kRCap; slot < n_slots; slot += kRCap) {
     const int m = slot / E, e = slot - m * E;
@@ -726,77 +764,13 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
       const int mo = moloff[m];
       const int at = atomicAdd(&cursor[place[mo + st.y]], 1);
       ent2[at] = ((uint32_t)e << 16) | ((uint32_t)bid << 8) | (uint32_t)place[mo + st.x];
-      if constexpr (TYPED) atomicAdd(&thist[bid], 1);
     }
   }
   lds_barrier();
   CSTAMP(9);
 
   // P5: every row's in-edge list in edge-slot order: entry-parallel rank sort, straight into the record
-  if constexpr (TYPED) {
-    // Groups of <= 4 edges of one bond type, in type order: entry x = type | edges << 8 | groups of this type from
-    // this one on << 24.  All groups of a type form one "run", processed by one wave of the encoder (which fetches
-    // the type's matrix once per chunk-step).
-    const int n_t = thist[tid];
-    const int ng = (n_t + 3) >> 2;  // <= 128
-    int ngrp = 0;
-    const int gb = block_excl_scan(ng, scratch, ngrp);
-    tgb[tid] = gb;
-    thist[tid] = 0;  // becomes the fill cursor of the type
-    {
-      const uint32_t dump = (uint32_t)tmsg_key(p.ecap) * 0x10001u;  // unused edge lanes write to the dump slot
-      for (int i = tid; i < ngrp; i += kRCap) grp[i] = make_uint4(0u, 0u, dump, dump);
-    }
-    lds_barrier();
-    if (ng > 0) {
-      for (int jg = 0; jg < ng; ++jg) {
-        const int c = n_t - 4 * jg;
-        grp[gb + jg].x = (uint32_t)tid | ((uint32_t)(c < 4 ? c : 4) << 8) | ((uint32_t)(ng - jg) << 24);
-      }
-    }
-    // run table: first group of every type that has groups, in type order (+ end).  The encoder's waves take runs
-    // from it one at a time (an LDS counter), so the message phase is balanced dynamically.
-    {
-      int nrun = 0;
-      const int ridx = block_excl_scan(ng > 0 ? 1 : 0, scratch, nrun);
-      uint16_t* runs = reinterpret_cast<uint16_t*>(rec + trec_runs_off(p.Vb, p.ecap));
-      if (ng > 0) runs[ridx] = (uint16_t)gb;
-      if (tid == 0) {
-        runs[nrun] = (uint16_t)ngrp;
-        *reinterpret_cast<uint16_t*>(rec + kTRecNrun) = (uint16_t)nrun;
-      }
-    }
-    if (tid == 0) {
-      uint16_t* cw = reinterpret_cast<uint16_t*>(rec + kTRecCounts);
-      int md = 0;
-      for (int t = 0; t < 16; ++t) md = md > tilemax[t] ? md : tilemax[t];
-      cw[0] = (uint16_t)ngrp;
-      cw[1] = (uint16_t)rowptr[kRCap];
-      cw[2] = (uint16_t)md;
-    }
-    const int total = rowptr[kRCap];
-    for (int i = tid; i < total; i += kRCap) {
-      int lo = 0, hi = kRCap - 1;  // largest row with rowptr[row] <= i
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (rowptr[mid] <= i) lo = mid; else hi = mid - 1;
-      }
-      const int b0 = rowptr[lo], b1 = rowptr[lo + 1];
-      const uint32_t v = ent2[i];
-      int rank = 0;
-      for (int jx = b0; jx < b1; ++jx) rank += ent2[jx] < v;
-      const uint32_t srow = v & 0xffu, bid = (v >> 8) & 0xffu;
-      // jagged diagonal: d-th in-edge of placed row lo (rank > 255 only in a plan that is marked overflowed)
-      const uint32_t mslot = (uint32_t)(jdp[rank < 256 ? rank : 255] + lo);
-      const int idx = atomicAdd(&thist[bid], 1);
-      unsigned char* ge = reinterpret_cast<unsigned char*>(&grp[tgb[bid] + (idx >> 2)]);
-      ge[4 + (idx & 3)] = (unsigned char)srow;
-      reinterpret_cast<uint16_t*>(ge + 8)[idx & 3] = (uint16_t)tmsg_key((int)mslot);
-    }
-    lds_barrier();
-    uint4* r_grp = reinterpret_cast<uint4*>(rec + kTRecGrp);
-    for (int i = tid; i < ngrp; i += kRCap) r_grp[i] = grp[i];
-  } else {
+  {
     const int total = rowptr[kRCap];
     for (int i = tid; i < total; i += kRCap) {
       int lo = 0, hi = kRCap - 1;  // largest row with rowptr[row] <= i
@@ -820,8 +794,381 @@ __global__ __launch_bounds__(kRCap, 5) void plan_chunks_kernel(PlanParams p) {  
   CSTAMP(15);
   lds_barrier();  // the LDS tables are rebuilt by the next chunk of this workgroup (rare: see above)
   }
-#undef CSTAMP
 }
+
+// Records of the typed encoder (encoder_layout.h "typed"): rows placed by EXACT descending in-degree, message slots in
+// jagged-diagonal order, edges grouped by bond type.  Six barriers per chunk:
+//   P0  edge slots -> registers (the loads fly while the row -> molecule search and the table resets run); atom ids
+//   P1  per valid edge: a ticket from the target row's in-degree counter - the edge's slot number goes to the row's
+//       ticket list (<= kTick entries; rows with more take the slow path of P4) - and the type histogram
+//   P2  in-degree histogram of the rows
+//   P3  wave 0: rows placed before every in-degree bin (prefix over the histogram) and the jagged-diagonal pointers
+//       (prefix over the suffix counts); wave 1: groups per type, first group of every type, the run table
+//   P4  rows take their place; per-row tables of the record; the type's groups with their headers
+//   P5  per valid edge: its rank among the in-edges of its row in edge-slot order = the tickets with a smaller slot
+//       number -> message slot; a place in a group of its type
+//   P6  group table -> record
+// Dynamic LDS: the group table (16 B x tgrp_cap).
+constexpr int kTick = 16;
+__global__ __launch_bounds__(kRCap, 4) void plan_chunks_typed_kernel(PlanParams p) {  // <= 128 VGPRs: 4 workgroups per CU
+  __shared__ int32_t moloff[kRCap + 2], molrows[kRCap], cnt[kRCap + 64], place[kRCap];  // cnt, thist: + a spare word per lane
+  __shared__ int32_t idl[kRCap];  // atom id of the logical row (-1: a slack row)
+  __shared__ __attribute__((aligned(16))) int32_t dbins[kRCap], dstart[kRCap], dcur[kRCap];
+  __shared__ __attribute__((aligned(16))) int32_t thist[kTVbMax + 64], tgb[kTVbMax], tcur[kTVbMax + 64];
+  __shared__ __attribute__((aligned(16))) int32_t jdp[kRCap + 4];
+  __shared__ int32_t misc[4];  // groups of the chunk; valid edges listed so far
+  __shared__ __attribute__((aligned(16))) uint16_t tick[kRCap * kTick];
+  __shared__ uint2 elist[kTECapBig];  // the chunk's valid edges: x = target row | source row << 8 | type << 16 (logical rows), y = edge slot
+  extern __shared__ uint4 grp[];
+  __shared__ ShareTab T;
+  __builtin_amdgcn_s_setprio(3);
+  CSTAMP(0);
+  const int j = blockIdx.x / p.grid_sub, slot_i = blockIdx.x - j * p.grid_sub;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Wave w of a workgroup runs on SIMD w, and the workgroups that share a CU are 256 apart in the grid (round robin over
+  // 8 XCDs x 32 CUs; observed, used for speed only): the resolving wave rotates with the workgroup so that the four
+  // resolutions of a CU run on four SIMDs instead of queueing on SIMD 0.
+  if (wave == ((blockIdx.x >> 8) & 3)) resolve_chain(p, j, slot_i, lane, T);
+  lds_barrier();
+  CSTAMP(1);
+  const int first_mol = T.chunk_s[0], nhop = T.chunk_s[1], g = T.chunk_s[2];
+  const int N = p.N, E = p.E;
+  const float rE = 1.0f / (float)E;
+  for (int sl = slot_i; sl < nhop; sl += p.grid_sub) {
+  const int mb_local = T.cb[sl], M = T.cb[sl + 1] - mb_local, m0 = first_mol + mb_local;
+  const int base = T.shst[mb_local];
+  const int R = T.shst[mb_local + M] - base;
+  const int idx = j * p.max_sub + sl;
+  if (tid == 0) reinterpret_cast<int4*>(p.desc)[idx] = make_int4(m0, M, 0, R | (g << 16));
+  const int32_t* ids_g = p.atom_ids[g];
+  const int32_t* conn_g = p.conn[g];
+  const int32_t* bond_g = p.bond_ids[g];
+  const int32_t* rows_g = p.rows + (int64_t)g * p.B;
+  unsigned char* rec = p.rec + (size_t)idx * kTRecBytes;
+  uint16_t* r_rowdeg = reinterpret_cast<uint16_t*>(rec + kTRecRowdeg);
+  unsigned char* r_tilemax = rec + kTRecTilemax;
+  uint16_t* r_moloff = reinterpret_cast<uint16_t*>(rec + kTRecMoloff);
+  uint16_t* r_molrows = reinterpret_cast<uint16_t*>(rec + kTRecMolrows);
+  uint16_t* r_poolrow = reinterpret_cast<uint16_t*>(rec + kTRecPoolrow);
+  int32_t* r_rowatom = reinterpret_cast<int32_t*>(rec + kTRecRowatom);
+  uint16_t* r_jd = reinterpret_cast<uint16_t*>(rec + kTRecJdptr);
+  uint16_t* r_cw = reinterpret_cast<uint16_t*>(rec + kTRecCounts);
+
+  // P0: every edge slot of the chunk's molecules is requested now, kSC per thread (M * E <= 1536 slots; more: the loop
+  //     of P1), so the chain of dependent loads is descriptor -> {edges, ids, rows}
+  const int n_slots = M * E;  // <= 256 molecules x 65535 slots: fits 24 bits, fast_div is exact
+  constexpr int kSC = 6;
+  int sbid[kSC];
+  int2 sst[kSC];
+  const int32_t* conn_c = conn_g + (int64_t)m0 * E * 2;  // the chunk's molecules are contiguous: slot -> address
+  const int32_t* bond_c = bond_g + (int64_t)m0 * E;
+#pragma unroll
+  for (int k = 0; k < kSC; ++k) {
+    const int slot = tid + k * kRCap;
+    sbid[k] = -1; sst[k] = make_int2(0, 0);
+    if (slot < n_slots) {
+      sst[k] = *reinterpret_cast<const int2*>(conn_c + 2 * (int64_t)slot);
+      sbid[k] = bond_c[slot];
+    }
+  }
+  // atom ids of the chunk's molecules: kIC per thread (M * N <= 768; more: the loop of P1)
+  constexpr int kIC = 3;
+  const int n_ids = M * N;
+  const float rN = 1.0f / (float)N;
+  const int32_t* ids_c = ids_g + (int64_t)m0 * N;
+  int sid[kIC];
+#pragma unroll
+  for (int k = 0; k < kIC; ++k) {
+    const int slot = tid + k * kRCap;
+    sid[k] = slot < n_ids ? ids_c[slot] : 0;
+  }
+  for (int m = tid; m <= M; m += kRCap) {
+    const int off = T.shst[mb_local + m] - base;
+    moloff[m] = off;
+    r_moloff[m] = (uint16_t)off;
+    if (m < M) {
+      const int rr = rows_g[m0 + m];
+      molrows[m] = rr;
+      r_molrows[m] = (uint16_t)rr;
+    }
+  }
+  cnt[tid] = 0;
+  dbins[tid] = 0;
+  dcur[tid] = 0;
+  thist[tid] = 0;
+  tcur[tid] = 0;
+  idl[tid] = -1;
+  if (tid == 0) misc[1] = 0;
+  {
+    const uint4 ones = make_uint4(~0u, ~0u, ~0u, ~0u);  // empty ticket = slot number 65535 (no edge slot is above it)
+    reinterpret_cast<uint4*>(tick)[2 * tid] = ones;
+    reinterpret_cast<uint4*>(tick)[2 * tid + 1] = ones;
+  }
+  lds_barrier();
+  CSTAMP(2);
+
+  // P1: atom ids to their logical rows; valid edges -> ticket of the target row, type histogram, the chunk's edge list.
+  //     Stage by stage over the register-held slots, so that the LDS operations of all of them are in flight together.
+  auto put_id = [&](int slot, int id) {
+    const int m = fast_div(slot, N, rN), n = slot - m * N;
+    if (slot < n_ids && n < molrows[m]) idl[moloff[m] + n] = id;
+  };
+  {
+    const int dq = fast_div(kRCap, N, rN), dr = kRCap - dq * N;
+    int cm = fast_div(tid, N, rN), cn = tid - cm * N;
+    int mr[kIC], mo[kIC], nn[kIC];
+#pragma unroll
+    for (int k = 0; k < kIC; ++k) {  // (branch-free reads: all in flight together)
+      const int mm = tid + k * kRCap < n_ids ? cm : 0;
+      mr[k] = tid + k * kRCap < n_ids ? molrows[mm] : 0;
+      mo[k] = moloff[mm];
+      nn[k] = cn;
+      cn += dr; cm += dq;
+      if (cn >= N) { cn -= N; ++cm; }
+    }
+#pragma unroll
+    for (int k = 0; k < kIC; ++k)
+      if (nn[k] < mr[k]) idl[mo[k] + nn[k]] = sid[k];
+  }
+  for (int slot = tid + kIC * kRCap; slot < n_ids; slot += kRCap) put_id(slot, ids_c[slot]);
+  {
+    unsigned okm = 0u;
+#pragma unroll
+    for (int k = 0; k < kSC; ++k) okm |= edge_valid(sst[k].x, sst[k].y, sbid[k], N, p.Vb) ? 1u << k : 0u;
+    // places in the edge list: one atomic per wave
+    const int mine = __builtin_popcount(okm);
+    const int incl = wave_incl_scan(mine);
+    int pos = 0;
+    if (lane == 63) pos = atomicAdd(&misc[1], incl);
+    pos = __builtin_amdgcn_readlane(pos, 63) + incl - mine;
+    // slot tid + 256 k = molecule cm, edge slot ce: stepped, not divided
+    const int dq = fast_div(kRCap, E, rE), dr = kRCap - dq * E;
+    int cm = fast_div(tid, E, rE), ce = tid - cm * E;
+#pragma unroll
+    for (int k0 = 0; k0 < kSC; k0 += 3) {  // three slots at a time (all six would spill)
+      int row[3], srw[3], tk[3], es[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const bool ok = (okm >> (k0 + k)) & 1u;
+        const int m = cm;
+        es[k] = ce;
+        ce += dr; cm += dq;
+        if (ce >= E) { ce -= E; ++cm; }
+        const int mo = moloff[m < M ? m : 0];
+        row[k] = mo + (ok ? sst[k0 + k].y : 0);
+        srw[k] = mo + (ok ? sst[k0 + k].x : 0);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {  // unconditional atomics (slots without a valid edge hit a per-lane spare word): no branches, no waits in between
+        const bool ok = (okm >> (k0 + k)) & 1u;
+        tk[k] = atomicAdd(&cnt[ok ? row[k] : kRCap + lane], 1);
+        atomicAdd(&thist[ok ? sbid[k0 + k] : kTVbMax + lane], 1);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const bool ok = (okm >> (k0 + k)) & 1u;
+        if (ok && tk[k] < kTick) tick[row[k] * kTick + tk[k]] = (uint16_t)es[k];
+        if (ok) {
+          if (pos < kTECapBig)
+            elist[pos] = make_uint2((uint32_t)row[k] | ((uint32_t)srw[k] << 8) | ((uint32_t)sbid[k0 + k] << 16), (uint32_t)es[k]);
+          ++pos;
+        }
+      }
+    }
+  }
+  for (int s0 = kSC * kRCap; s0 < n_slots; s0 += kRCap) {  // (wave-uniform trip count: a ballot inside)
+    const int slot = s0 + tid;
+    int2 st = make_int2(0, 0);
+    int bid = -1;
+    if (slot < n_slots) {
+      st = *reinterpret_cast<const int2*>(conn_c + 2 * (int64_t)slot);
+      bid = bond_c[slot];
+    }
+    const bool ok = edge_valid(st.x, st.y, bid, N, p.Vb);
+    const int m = fast_div(slot, E, rE), e = slot - m * E;
+    const int mo = moloff[m < M ? m : 0];
+    const int row = mo + (ok ? st.y : 0);
+    int tk = kTick;
+    if (ok) {
+      tk = atomicAdd(&cnt[row], 1);
+      atomicAdd(&thist[bid], 1);
+    }
+    const unsigned long long okb = __ballot(ok);
+    int pos0 = 0;
+    if (okb != 0ull) {
+      if (lane == (int)__builtin_ctzll(okb)) pos0 = atomicAdd(&misc[1], (int)__builtin_popcountll(okb));
+      pos0 = __builtin_amdgcn_readlane(pos0, (int)__builtin_ctzll(okb));
+    }
+    if (tk < kTick) tick[row * kTick + tk] = (uint16_t)e;
+    const int pos = pos0 + (int)__builtin_popcountll(okb & ((1ull << lane) - 1));
+    if (ok && pos < kTECapBig)
+      elist[pos] = make_uint2((uint32_t)row | ((uint32_t)(mo + st.x) << 8) | ((uint32_t)bid << 16), (uint32_t)e);
+  }
+  lds_barrier();
+  CSTAMP(3);
+
+  // P2: bin = 255 - in-degree (in-degrees above 255 cannot travel: the plan is marked, the encoder refuses it)
+  const int my_deg = cnt[tid];
+  const int dcl = my_deg > 255 ? 255 : my_deg;
+  if (tid < R) {
+    if (my_deg > 255) p.header->overflow = 1;
+    atomicAdd(&dbins[255 - dcl], 1);
+  }
+  lds_barrier();
+  CSTAMP(4);
+
+  // P3
+  if (wave == 0) {
+    // rows placed before bin b = rows with a larger in-degree; lane l holds bins 4l .. 4l+3
+    const int4 h = reinterpret_cast<const int4*>(dbins)[lane];
+    const int s4 = h.x + h.y + h.z + h.w;
+    const int ex = wave_incl_scan(s4) - s4;
+    reinterpret_cast<int4*>(dstart)[lane] = make_int4(ex, ex + h.x, ex + h.x + h.y, ex + h.x + h.y + h.z);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // jagged-diagonal pointers: the rows with an in-edge of index d are the first S_d = dstart[255 - d] placed rows;
+    // lane l holds d = 4l .. 4l+3 = dstart[255 - 4l], [254 - 4l], [253 - 4l], [252 - 4l]
+    const int4 s = reinterpret_cast<const int4*>(dstart)[63 - lane];  // elements: dstart[252-4l], [253-4l], [254-4l], [255-4l]
+    const int t4 = s.x + s.y + s.z + s.w;
+    const int incl = wave_incl_scan(t4);
+    const int jx = incl - t4;
+    reinterpret_cast<int4*>(jdp)[lane] = make_int4(jx, jx + s.w, jx + s.w + s.z, jx + s.w + s.z + s.y);
+    if (lane == 63) { jdp[kRCap] = incl; jdp[kRCap + 1] = incl; }
+  } else if (wave == 1) {
+    // groups of <= 4 edges per type; lane l holds types 4l .. 4l+3
+    const int4 n = reinterpret_cast<const int4*>(thist)[lane];
+    const int4 ng = make_int4((n.x + 3) >> 2, (n.y + 3) >> 2, (n.z + 3) >> 2, (n.w + 3) >> 2);
+    const int s4 = ng.x + ng.y + ng.z + ng.w;
+    const int incl = wave_incl_scan(s4);
+    const int ex = incl - s4;
+    reinterpret_cast<int4*>(tgb)[lane] = make_int4(ex, ex + ng.x, ex + ng.x + ng.y, ex + ng.x + ng.y + ng.z);
+    // run table: first group of every type that has groups, in type order (+ end).  The encoder's waves take runs
+    // from it one at a time (an LDS counter), so the message phase is balanced dynamically.
+    const int r4 = (ng.x > 0) + (ng.y > 0) + (ng.z > 0) + (ng.w > 0);
+    const int rincl = wave_incl_scan(r4);
+    int ri = rincl - r4;
+    uint16_t* runs = reinterpret_cast<uint16_t*>(rec + trec_runs_off(p.Vb, p.ecap));
+    if (ng.x > 0) runs[ri++] = (uint16_t)ex;
+    if (ng.y > 0) runs[ri++] = (uint16_t)(ex + ng.x);
+    if (ng.z > 0) runs[ri++] = (uint16_t)(ex + ng.x + ng.y);
+    if (ng.w > 0) runs[ri++] = (uint16_t)(ex + ng.x + ng.y + ng.z);
+    if (lane == 63) {
+      runs[rincl] = (uint16_t)incl;
+      *reinterpret_cast<uint16_t*>(rec + kTRecNrun) = (uint16_t)rincl;
+      misc[0] = incl;
+    }
+  }
+  lds_barrier();
+  CSTAMP(5);
+
+  // P4
+  int pos = tid;  // rows beyond the chunk keep their thread order behind the R real rows
+  if (tid < R) pos = dstart[255 - dcl] + atomicAdd(&dcur[255 - dcl], 1);
+  place[tid] = pos;
+  {
+    const int my_id = idl[tid];  // -1: a slack row; out-of-range ids (incl. negative) read as a zero row in the encoder
+    r_rowatom[pos] = my_id;
+    r_poolrow[tid] = (uint16_t)(pos | (my_id > 0 ? 0x8000 : 0));
+    r_rowdeg[pos] = (uint16_t)my_deg;
+    if ((pos & 15) == 0) r_tilemax[pos >> 4] = (unsigned char)dcl;  // descending in-degrees: a tile's first row has its maximum
+    r_jd[tid] = (uint16_t)jdp[tid];
+    if (tid < 2) r_jd[kRCap + tid] = (uint16_t)jdp[kRCap];
+    if (pos == 0) {
+      r_cw[0] = (uint16_t)misc[0];
+      r_cw[1] = (uint16_t)jdp[kRCap];
+      r_cw[2] = (uint16_t)dcl;
+    }
+  }
+  {
+    // the groups of type `tid`: x = type | edges << 8 | groups of this type from this one on << 24; unused edge lanes
+    // write to the dump slot
+    const int n_t = thist[tid];
+    const int ng = (n_t + 3) >> 2, gb = tgb[tid];
+    const uint32_t dump = (uint32_t)tmsg_key(p.ecap) * 0x10001u;
+    for (int jg = 0; jg < ng; ++jg) {
+      const int c = n_t - 4 * jg;
+      grp[gb + jg] = make_uint4((uint32_t)tid | ((uint32_t)(c < 4 ? c : 4) << 8) | ((uint32_t)(ng - jg) << 24), 0u, dump, dump);
+    }
+  }
+  lds_barrier();
+  CSTAMP(6);
+
+  // P5: the listed edges, two per thread and turn, stage by stage (the LDS operations of both are in flight together)
+  {
+    auto below = [](uint4 a, uint32_t ue) {
+      return (int)(((a.x & 0xffffu) < ue) + ((a.x >> 16) < ue) + ((a.y & 0xffffu) < ue) + ((a.y >> 16) < ue) +
+                   ((a.z & 0xffffu) < ue) + ((a.z >> 16) < ue) + ((a.w & 0xffffu) < ue) + ((a.w >> 16) < ue));
+    };
+    const int nval = misc[1] < kTECapBig ? misc[1] : kTECapBig;
+    for (int i0 = 0; i0 < nval; i0 += 2 * kRCap) {
+      bool ok[2];
+      uint2 en[2];
+      int row[2], srow[2], deg[2], ix[2], gb[2], rank[2];
+      uint4 ta[2], tb[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int i = i0 + k * kRCap + tid;
+        ok[k] = i < nval;
+        en[k] = elist[ok[k] ? i : 0];
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int rt = (int)(en[k].x & 0xffu), bid = (int)(en[k].x >> 16);
+        deg[k] = cnt[rt];
+        ta[k] = reinterpret_cast<const uint4*>(tick)[2 * rt];
+        tb[k] = reinterpret_cast<const uint4*>(tick)[2 * rt + 1];
+        row[k] = place[rt];
+        srow[k] = place[(en[k].x >> 8) & 0xffu];
+        gb[k] = tgb[bid];
+        ix[k] = atomicAdd(&tcur[ok[k] ? bid : kTVbMax + lane], 1);  // (a spare word per lane where there is no edge: no branch)
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        rank[k] = below(ta[k], en[k].y) + below(tb[k], en[k].y);  // empty tickets (65535) never count
+        if (deg[k] > kTick) {
+          // a hub: the tickets beyond the list were not kept - count the earlier valid edge slots of the molecule with
+          // the same target (the molecule and the target atom come back out of the logical row)
+          const int rt = (int)(en[k].x & 0xffu);
+          int lo = 0, hi = M - 1;
+          while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (moloff[mid] <= rt) lo = mid; else hi = mid - 1;
+          }
+          const int t = rt - moloff[lo];
+          const int32_t* cm = conn_c + 2 * (int64_t)lo * E;
+          const int32_t* bm = bond_c + (int64_t)lo * E;
+          rank[k] = 0;
+          for (int e2 = 0; e2 < (int)en[k].y; ++e2) {
+            const int2 s2 = *reinterpret_cast<const int2*>(cm + 2 * e2);
+            rank[k] += (s2.y == t && edge_valid(s2.x, s2.y, bm[e2], N, p.Vb)) ? 1 : 0;
+          }
+        }
+        // jagged diagonal: rank-th in-edge of the placed row (rank > 255 only in a plan that is marked overflowed)
+        rank[k] = jdp[rank[k] < 256 ? rank[k] : 255];
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (ok[k]) {
+          unsigned char* ge = reinterpret_cast<unsigned char*>(&grp[gb[k] + (ix[k] >> 2)]);
+          ge[4 + (ix[k] & 3)] = (unsigned char)srow[k];
+          reinterpret_cast<uint16_t*>(ge + 8)[ix[k] & 3] = (uint16_t)tmsg_key(rank[k] + row[k]);
+        }
+      }
+    }
+  }
+  lds_barrier();
+  CSTAMP(9);
+
+  // P6
+  {
+    const int ngrp = misc[0];
+    uint4* r_grp = reinterpret_cast<uint4*>(rec + kTRecGrp);
+    for (int i = tid; i < ngrp; i += kRCap) r_grp[i] = grp[i];
+  }
+  CSTAMP(15);
+  lds_barrier();  // the LDS tables are rebuilt by the next chunk of this workgroup (rare)
+  }
+}
+#undef CSTAMP
 
 }  // namespace
 
@@ -853,9 +1200,9 @@ int launch_plan(const PlanParams& pp, hipStream_t s) {
   if (pp.max_sub > kMaxHops)
     return fail(IMPNN_E_UNSUPPORTED, "encoder plan: %d chunk slots per workgroup", pp.max_sub);
   if (pp.typed)
-    plan_chunks_kernel<true><<<pp.nwg * pp.grid_sub, kRCap, sizeof(uint4) * tgrp_cap(pp.Vb, pp.ecap), s>>>(pp);
+    plan_chunks_typed_kernel<<<pp.nwg * pp.grid_sub, kRCap, sizeof(uint4) * tgrp_cap(pp.Vb, pp.ecap), s>>>(pp);
   else
-    plan_chunks_kernel<false><<<pp.nwg * pp.grid_sub, kRCap, 0, s>>>(pp);
+    plan_chunks_kernel<<<pp.nwg * pp.grid_sub, kRCap, 0, s>>>(pp);
   return check_launch("plan_chunks");
 }
 

@@ -94,6 +94,35 @@ def test_fused_encoder_adversarial_graphs(mode):
     assert float(pc[0].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_fused_encoder_in_degrees_around_the_plan_ticket_list(mode):
+    """The typed plan ranks a row's in-edges through a 16-entry ticket list and takes a slower path beyond it:
+    in-degrees 15, 16, 17, 18 and 40 on atoms of one molecule, edge slots interleaved (the summation order is the
+    edge-slot order, models/layers.py:78-82), beside ordinary molecules."""
+    rng = np.random.default_rng(77)
+    B, N, E, Va, Vb, K, S = 24, 30, 120, 20, 7, 8, 3
+    ids = rng.integers(1, Va, size=(B, N)).astype(np.int32)
+    conn = np.zeros((B, E, 2), dtype=np.int32)
+    bond = np.zeros((B, E), dtype=np.int32)
+    for b in range(B):
+        tgt = np.concatenate([np.full(15, 3), np.full(16, 4), np.full(17, 5), np.full(18, 6), np.full(40, 7)])
+        tgt = np.concatenate([tgt, rng.integers(8, N, size=E - tgt.size - 6)])
+        rng.shuffle(tgt)                                              # interleave the slots of the five hubs
+        n = tgt.size
+        conn[b, :n, 1] = tgt
+        conn[b, :n, 0] = rng.integers(1, N, size=n)
+        bond[b, :n] = rng.integers(1, Vb, size=n)
+    inp = {"cat_atom": ids, "cat_bond": bond, "cat_connectivity": conn,
+           "an_atom": ids[::-1].copy(), "an_bond": bond[::-1].copy(), "an_connectivity": conn[::-1].copy()}
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=32, bond_dim=K, num_steps=S, seed=5, perturb=True)
+    m = make_model(w, Va, Vb, K=K, mode=mode)
+    pc, pa = m.encode_pooled(to_dev(inp), fused=True)
+    rc = O.encode(w, "cat", ids, bond, conn, pooled_only=True)
+    ra = O.encode(w, "an", inp["an_atom"], inp["an_bond"], inp["an_connectivity"], pooled_only=True)
+    assert_close(pc.cpu().numpy(), rc, what="cat pooled")
+    assert_close(pa.cpu().numpy(), ra, what="an pooled")
+
+
 def test_unsupported_shapes_fall_back_to_layered_hip():
     # melting-point model: K = D*D (train_melting_point.py:146) is outside the fused kernel
     _, inp, w, outs = load_case("tiny_melting_point")
