@@ -35,7 +35,8 @@
 namespace impnn {
 namespace wide {
 
-constexpr int kRT = 64;        // rows of a GatedUpdate tile; an ion's rows start at a multiple of it
+constexpr int kRT = 64;        // rows of a GatedUpdate tile (the exact-f32 kernel; mode 3's large-batch kernel: 128)
+constexpr int kRowAlign = 128; // an ion's rows start at a multiple of it (a tile never holds rows of two ions)
 constexpr int kMaxN = 256;     // atoms per molecule (LDS tables of wide_place)
 constexpr int kMaxE = 512;     // edge slots per molecule
 constexpr int kMaxVb = 512;    // bond vocabulary (types of both ions: one per thread of wide_scan)
@@ -107,7 +108,7 @@ inline Ws ws_layout(int n_ions, int B, int N, int E, int D, int S, int Vb, bool 
   Ws w{};
   const int64_t mols = (int64_t)n_ions * B;
   w.nT = n_ions * Vb;
-  w.rmax = mols * N + (int64_t)n_ions * kRT;
+  w.rmax = (mols * N + (int64_t)n_ions * kRowAlign + kRowAlign - 1) / kRowAlign * kRowAlign;  // whole tiles
   w.vmax = mols * E + (int64_t)(w.nT + 2) * tile_edges(D);  // a type's run is padded to whole tiles
   size_t o = 0;
   auto take = [&](size_t bytes) {
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void wide_count_kernel(Inputs in, int32_t* __r
     if (lh[t]) atomicAdd(&cnt[t], lh[t]);
 }
 
-// One workgroup of 1024 threads: (a) exclusive scan of the kept rows per ion (an ion's first row is a multiple of kRT),
+// One workgroup of 1024 threads: (a) exclusive scan of the kept rows per ion (an ion's first row is a multiple of kRowAlign),
 // (b) per-type runs and tiles.
 __global__ __launch_bounds__(1024) void wide_scan_kernel(const int32_t* __restrict__ kept, int32_t* __restrict__ rowbase,
                                                          const int32_t* __restrict__ cnt, int32_t* __restrict__ tstart,
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(1024) void wide_scan_kernel(const int32_t* __restri
       meta[kMetaBase + g] = base;
       meta[kMetaEnd] = base + rows;
     }
-    base = (base + rows + kRT - 1) / kRT * kRT;
+    base = (base + rows + kRowAlign - 1) / kRowAlign * kRowAlign;
     __syncthreads();
   }
   {  // types: nT <= 1024, one per thread
@@ -1214,6 +1215,322 @@ __global__ __launch_bounds__(kGuX3Threads, 2) void wide_update_x3_kernel(GuParam
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same update on 128-row tiles (batches that fill the chip): per 32-k slice the 48 KB of pre-split gate kernels are
+// shared by twice the rows, and a wave multiplies 64 rows x NL feature tiles of z and of r - 144 MFMAs per slice for 24
+// operand fetches (the 64-row form: 72 for 18), so the LDS traffic per MFMA is 0.67 of the 64-row kernel's and the L2 -> LDS
+// traffic of the kernels half.  One workgroup of 8 waves per CU, 256 VGPRs per lane.
+//   * kernel slices go global -> LDS directly (global_load_lds_dwordx4: 16 B per lane, a wave's 64 lanes fill 1 KB of
+//     consecutive LDS; no staging registers, no LDS store instructions); slice u + 1 lands in the other stage while
+//     slice u is multiplied;
+//   * row slices go global -> registers (one slice ahead) -> split -> the other stage, at the top of a slice;
+//   * the nine products of an output tile form a dependent chain: the MFMAs are issued product by product ACROSS the
+//     wave's four chains of a row tile (a chain's next link is four instructions away), and the operands of the next
+//     row tile are requested in front of them;
+//   * phase 2 keeps r * h as f32 in LDS (67 KB) beside ONE row stage and TWO kernel stages: multiply - barrier - park
+//     the next row slice - barrier.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kRT3 = 128;
+// LDS: phase 1 two stages of (rows 24 KB + [Wz|Wr] slice); phase 2 re-cuts the same memory into two row stages, two Wh
+// stages and the f32 copy of r * h (unpadded) - 160 KB at D = 128; the LayerNorm partials reuse the stages at the end
+constexpr size_t gu_x3b_lds_bytes(int D) {
+  const size_t p1 = 2 * (size_t)(3 * 4 * kRT3 * 16 + 12 * 2 * D * 16);
+  const size_t p2 = 2 * (size_t)(3 * 4 * kRT3 * 16 + 12 * D * 16) + (size_t)kRT3 * D * 4;
+  return p1 > p2 ? p1 : p2;
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int NT>
+__global__ __launch_bounds__(kGuX3Threads, 1) void wide_update_x3b_kernel(GuParams p) {
+  constexpr int D = 16 * NT, R = kRT3, LDR = D, T = kGuX3Threads;
+  constexpr int RG = 2, FG = 4, NL = NT / FG, RTW = R / (16 * RG);  // a wave: RTW = 4 row tiles x NL feature tiles
+  constexpr int NS = NT;                     // 32-k slices of a 2D-deep GEMM
+  constexpr int UA = 3 * 4 * R;              // 16-byte units of a row slice
+  constexpr int UB1 = 3 * 4 * 2 * D;         // ... of a [Wz|Wr] slice
+  constexpr int UB2 = 3 * 4 * D;             // ... of a Wh slice
+  constexpr int ST1 = UA + UB1;
+  constexpr int RP = R / 64;                 // row pieces a thread parks per slice
+  static_assert(NL >= 1 && NT % 2 == 0 && NS >= 4 && RTW == 4 && RP == 2, "tile shape");
+  static_assert(UB1 % 64 == 0 && UB2 % 64 == 0, "a kernel slice is whole 1 KB wave transfers");
+  constexpr int ST2 = UA + UB2;
+  static_assert((size_t)2 * ST2 * 16 + (size_t)R * LDR * 4 <= 160 * 1024, "phase 2 fits the LDS");
+  static_assert((size_t)8 * R * 4 <= (size_t)2 * ST2 * 16, "the LayerNorm partials fit the stages");
+  extern __shared__ __align__(16) unsigned char smem_b[];
+  uint4* const stage = reinterpret_cast<uint4*>(smem_b);                                  // phase 1: 2 x ST1 units
+  uint4* const stage2 = stage;                                                            // phase 2: 2 x ST2 units (rows | Wh slice)
+  float* const rhs = reinterpret_cast<float*>(smem_b + (size_t)2 * ST2 * 16);             // phase 2: R x LDR f32, r * h
+  float* const part = reinterpret_cast<float*>(smem_b);                                   // epilogue: 2 x FG x R LayerNorm partials
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, a = lane & 15, q = lane >> 4;
+  const int rg = wv % RG, fg = wv / RG;
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  const int end = p.meta[kMetaEnd];
+  if (row0 >= end) return;
+  const int g = (p.n_ions > 1 && row0 >= p.meta[kMetaBase + 1]) ? 1 : 0;
+  const int64_t ion_end = p.meta[kMetaBase + g] + p.meta[kMetaRows + g];
+  const int64_t row_end = row0 + R < ion_end ? row0 + R : ion_end;
+  if (row0 >= row_end) return;
+  WIDE_STAMP(p.stamps, 0);
+  WIDE_STAMP_REAL(p.stamps, 5);
+  const float* img = p.img[g] + p.gu_off;
+  const uint4* P1 = reinterpret_cast<const uint4*>(img);
+  const uint4* P2 = P1 + (size_t)NS * UB1;
+  const float* bias = reinterpret_cast<const float*>(P2 + (size_t)NS * UB2);  // bz br bh gamma beta
+  // a thread's pieces of a row slice: rows a_row and a_row + 64, k = 4 a_pc .. 4 a_pc + 3 of the slice's 32
+  const int a_row = tid >> 3, a_pc = tid & 7;
+  const float* hsrc = p.h + (row0 + a_row) * D + 4 * a_pc;
+  const float* gsrc = p.agg + (row0 + a_row) * D + 4 * a_pc;
+  const int a_unit = (a_pc >> 1) * R + a_row, a_half = a_pc & 1;  // unit (plane, k octet a_pc >> 1, row), 8-byte half
+  auto park_rows = [&](uint4* st, f32x4_t v, int piece) {  // 4 values -> three planes of 4 bf16
+    unsigned w0[2], w1[2], w2[2];
+    split_pair_w(v[0], v[1], w0[0], w1[0], w2[0]);
+    split_pair_w(v[2], v[3], w0[1], w1[1], w2[1]);
+    uint2* s2 = reinterpret_cast<uint2*>(st);
+    const int un = a_unit + 64 * piece;
+    s2[(0 * 4 * R + un) * 2 + a_half] = make_uint2(w0[0], w0[1]);
+    s2[(1 * 4 * R + un) * 2 + a_half] = make_uint2(w1[0], w1[1]);
+    s2[(2 * 4 * R + un) * 2 + a_half] = make_uint2(w2[0], w2[1]);
+  };
+  // `units` 16-byte units from global to LDS, verbatim: wave w moves units 64 (8 i + w) .. + 63 with its i-th instruction
+  auto dma = [&](const uint4* src, uint4* dst, int units) {
+#pragma unroll
+    for (int i = 0; i < (units + T - 1) / T; ++i) {
+      const int ub = 64 * (8 * i + wv);
+      if (ub < units)  // (wave-uniform)
+        __builtin_amdgcn_global_load_lds((const void*)(src + ub + lane), (lds_ptr_t)(dst + ub), 16, 0, 0);
+    }
+  };
+  // workgroup barrier behind everything this wave has in flight (kernel slices on their way into LDS included)
+  auto wg_barrier = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  f32x4_t pav[RP];
+  auto fetch_rows1 = [&](int u) {
+#pragma unroll
+    for (int i = 0; i < RP; ++i) pav[i] = ldv4((u < NS / 2 ? hsrc : gsrc - D) + 32 * u + (size_t)64 * i * D);
+  };
+  f32x4_t z[RTW][NL], rr[RTW][NL];
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL) {
+    const int f = 16 * (fg * NL + TL) + a;
+    const float b0 = bias[f], b1 = bias[D + f];
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt) {
+      z[rt][TL] = f32x4_t{b0, b0, b0, b0};
+      rr[rt][TL] = f32x4_t{b1, b1, b1, b1};
+    }
+  }
+  auto read_a = [&](const uint4* st, int rt, bf16x8_t (&av)[3]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+      av[pl] = __builtin_bit_cast(bf16x8_t, st[(pl * 4 + q) * R + 64 * rg + 16 * rt + a]);
+  };
+  auto read_b = [&](const uint4* bs, int ncols, int col, bf16x8_t (&bv)[3]) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) bv[pl] = __builtin_bit_cast(bf16x8_t, bs[(pl * 4 + q) * ncols + col]);
+  };
+  float hreg[RTW][NL][4];
+  auto load_hreg = [&]() {
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          hreg[rt][TL][gq] = p.h[(row0 + 64 * rg + 16 * rt + 4 * q + gq) * D + 16 * (fg * NL + TL) + a];
+  };
+  // the nine products, smallest first: (row plane, kernel plane)
+  constexpr int kPa[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}, kPb[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
+  auto slice1 = [&](const uint4* cur, uint4* oth, int u) {
+    bf16x8_t bz[NL][3], br[NL][3], av[2][3];
+    // slice u + 1 (rows in the staging registers since the last slice) to the other stage; u + 2 requested.  The two
+    // waves of a SIMD (w and w + 4) do it at opposite ends of the slice, so one of them always has MFMAs to issue.
+    if (u + 1 < NS) {  // slice u + 1 (rows in the staging registers since the last slice) to the other stage; u + 2 requested
+      park_rows(oth, pav[0], 0);
+      park_rows(oth, pav[1], 1);
+      __builtin_amdgcn_sched_barrier(0);  // (an LDS store behind a transfer in flight waits for the transfer)
+      if (u + 2 < NS) fetch_rows1(u + 2);
+      dma(P1 + (size_t)(u + 1) * UB1, oth + UA, UB1);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      load_hreg();
+    }
+    // operands in the order the products take them (plane 2 of both first): the first MFMA waits for 5 fetches, not 15
+#pragma unroll
+    for (int pl = 2; pl >= 0; --pl) {
+      av[0][pl] = __builtin_bit_cast(bf16x8_t, cur[(pl * 4 + q) * R + 64 * rg + a]);
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL) {
+        bz[TL][pl] = __builtin_bit_cast(bf16x8_t, cur[UA + (pl * 4 + q) * 2 * D + 16 * (fg * NL + TL) + a]);
+        br[TL][pl] = __builtin_bit_cast(bf16x8_t, cur[UA + (pl * 4 + q) * 2 * D + D + 16 * (fg * NL + TL) + a]);
+      }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt) {
+      if (rt + 1 < RTW) read_a(cur, rt + 1, av[(rt + 1) & 1]);
+      if (rt > 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pr = 0; pr < 9; ++pr)
+#pragma unroll
+        for (int TL = 0; TL < NL; ++TL) {
+          z[rt][TL] = mfma_bf16(av[rt & 1][kPa[pr]], bz[TL][kPb[pr]], z[rt][TL]);
+          rr[rt][TL] = mfma_bf16(av[rt & 1][kPa[pr]], br[TL][kPb[pr]], rr[rt][TL]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  fetch_rows1(0);
+  park_rows(stage, pav[0], 0);
+  park_rows(stage, pav[1], 1);
+  __builtin_amdgcn_sched_barrier(0);
+  fetch_rows1(1);
+  dma(P1, stage + UA, UB1);
+  wg_barrier();
+  WIDE_STAMP(p.stamps, 1);
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    slice1(stage + (u & 1) * ST1, stage + ((u + 1) & 1) * ST1, u);
+    wg_barrier();
+  }
+  WIDE_STAMP(p.stamps, 2);
+  // ---- gates; r * h (f32) into LDS: phase 2 parks its first NS / 2 row slices from there
+  auto fetch_rows2 = [&](int u) {    // (u >= NS / 2: the aggregated messages)
+#pragma unroll
+    for (int i = 0; i < RP; ++i) pav[i] = ldv4(gsrc + 32 * (u - NS / 2) + (size_t)64 * i * D);
+  };
+  auto park2 = [&](uint4* st, int u) {
+#pragma unroll
+    for (int i = 0; i < RP; ++i)
+      park_rows(st, u < NS / 2 ? ldv4(rhs + (a_row + 64 * i) * LDR + 32 * u + 4 * a_pc) : pav[i], i);
+  };
+  // (every wave is past the last barrier of phase 1: the stages are free)
+#pragma unroll
+  for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        z[rt][TL][gq] = fsig(z[rt][TL][gq]);
+        rhs[(64 * rg + 16 * rt + 4 * q + gq) * LDR + 16 * (fg * NL + TL) + a] = fsig(rr[rt][TL][gq]) * hreg[rt][TL][gq];
+      }
+  f32x4_t tt[RTW][NL];
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL) {
+    const float b2 = bias[2 * D + 16 * (fg * NL + TL) + a];
+#pragma unroll
+    for (int rt = 0; rt < RTW; ++rt) tt[rt][TL] = f32x4_t{b2, b2, b2, b2};
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  dma(P2, stage2 + UA, UB2);  // (behind the LDS stores above: a store behind a transfer in flight would wait for it)
+  wg_barrier();  // r * h complete
+  park2(stage2, 0);
+  wg_barrier();
+  auto slice2 = [&](const uint4* cur, uint4* oth, int u) {
+    if (u + 1 < NS) {  // slice u + 1: rows out of r * h or the staging registers, its Wh slice straight from global
+      park2(oth, u + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + 2 < NS && u + 2 >= NS / 2) fetch_rows2(u + 2);
+      dma(P2 + (size_t)(u + 1) * UB2, oth + UA, UB2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    bf16x8_t bv[NL][3], av[2][2][3];
+#pragma unroll
+    for (int pl = 2; pl >= 0; --pl) {  // (in the order the products take them)
+      av[0][0][pl] = __builtin_bit_cast(bf16x8_t, cur[(pl * 4 + q) * R + 64 * rg + a]);
+      av[0][1][pl] = __builtin_bit_cast(bf16x8_t, cur[(pl * 4 + q) * R + 64 * rg + 16 + a]);
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL) bv[TL][pl] = __builtin_bit_cast(bf16x8_t, cur[UA + (pl * 4 + q) * D + 16 * (fg * NL + TL) + a]);
+    }
+#pragma unroll
+    for (int rp = 0; rp < RTW / 2; ++rp) {  // two row tiles at a time: four chains
+      if (rp + 1 < RTW / 2) {
+        read_a(cur, 2 * rp + 2, av[(rp + 1) & 1][0]);
+        read_a(cur, 2 * rp + 3, av[(rp + 1) & 1][1]);
+      }
+      if (rp > 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pr = 0; pr < 9; ++pr)
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+          for (int TL = 0; TL < NL; ++TL)
+            tt[2 * rp + r2][TL] = mfma_bf16(av[rp & 1][r2][kPa[pr]], bv[TL][kPb[pr]], tt[2 * rp + r2][TL]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // (the first slice of aggregated messages, NS / 2, is requested inside slice NS / 2 - 2 and parked inside NS / 2 - 1)
+#pragma unroll
+  for (int u = 0; u < NS; ++u) {
+    slice2(stage2 + (u & 1) * ST2, stage2 + ((u + 1) & 1) * ST2, u);
+    wg_barrier();
+  }
+  WIDE_STAMP(p.stamps, 3);
+  // ---- blend, LayerNorm over the D features of a row, residual (models/layers.py:150-156): as wide_update_kernel
+  float sum[RTW][4];
+#pragma unroll
+  for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL) {
+        const float hv = hreg[rt][TL][gq];
+        const float nv = (1.0f - z[rt][TL][gq]) * hv + z[rt][TL][gq] * ftanh(tt[rt][TL][gq]);
+        tt[rt][TL][gq] = nv;
+        sacc += nv;
+      }
+      sum[rt][gq] = row16_sum_f(sacc);
+      if (a == 0) part[fg * R + 64 * rg + 16 * rt + 4 * q + gq] = sum[rt][gq];
+    }
+  __syncthreads();
+  float mean[RTW][4], inv[RTW][4];
+#pragma unroll
+  for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int rl = 64 * rg + 16 * rt + 4 * q + gq;
+      float ms = 0.f;
+#pragma unroll
+      for (int f2 = 0; f2 < FG; ++f2) ms += part[f2 * R + rl];
+      mean[rt][gq] = ms * (1.0f / D);
+      float vs = 0.f;
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL) {
+        const float dv = tt[rt][TL][gq] - mean[rt][gq];
+        vs = fmaf(dv, dv, vs);
+      }
+      vs = row16_sum_f(vs);
+      if (a == 0) part[FG * R + fg * R + rl] = vs;
+    }
+  __syncthreads();
+#pragma unroll
+  for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const int rl = FG * R + 64 * rg + 16 * rt + 4 * q + gq;
+      float vs = 0.f;
+#pragma unroll
+      for (int f2 = 0; f2 < FG; ++f2) vs += part[f2 * R + rl];
+      inv[rt][gq] = __builtin_amdgcn_rsqf(vs * (1.0f / D) + p.eps);  // (v_rsq_f32: 1 ulp)
+    }
+  WIDE_STAMP(p.stamps, 7);
+  // Every row of the tile is stored: the rows past row_end are padding of the row space (the gap behind an ion, the
+  // rows behind the last one) that nothing reads as a source, a target or a pooled row.
+  {
+    float* const out = p.h + (row0 + 64 * rg + 4 * q) * D + 16 * fg * NL + a;
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL) {
+      const int f = 16 * (fg * NL + TL) + a;
+      const float gm = bias[3 * D + f], bt = bias[4 * D + f];
+#pragma unroll
+      for (int rt = 0; rt < RTW; ++rt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+          out[(16 * rt + gq) * D + 16 * TL] = (tt[rt][TL][gq] - mean[rt][gq]) * inv[rt][gq] * gm + bt + hreg[rt][TL][gq];
+    }
+  }
+  WIDE_STAMP(p.stamps, 4);
+  WIDE_STAMP_REAL(p.stamps, 6);
+}
+
 // a8: one thread per 16-byte piece of a pooled row, 4 rows in flight, ascending n.
 __global__ __launch_bounds__(256) void wide_pool_kernel(Inputs in, const int32_t* __restrict__ kept,
                                                         const int32_t* __restrict__ rowbase,
@@ -1420,12 +1737,17 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   const int nt = a.D / 16;
   constexpr int R = kRT;
   const size_t gu_lds = x3 ? gu_x3_lds_bytes(a.D) : gu_lds_floats(a.D) * 4;
+  const size_t gu_lds_big = gu_x3b_lds_bytes(a.D);
   if (a.D == 128) {
     if (int rc = raise_lds<0>(wide_message_kernel<8, 64>, msg_lds)) return rc;
     if (int rc = x3 ? raise_lds<4>(wide_update_x3_kernel<8>, gu_lds) : raise_lds<1>(wide_update_kernel<8>, gu_lds)) return rc;
+    if (x3)
+      if (int rc = raise_lds<6>(wide_update_x3b_kernel<8>, gu_lds_big)) return rc;
   } else {
     if (int rc = raise_lds<2>(wide_message_kernel<4, 128>, msg_lds)) return rc;
     if (int rc = x3 ? raise_lds<5>(wide_update_x3_kernel<4>, gu_lds) : raise_lds<3>(wide_update_kernel<4>, gu_lds)) return rc;
+    if (x3)
+      if (int rc = raise_lds<7>(wide_update_x3b_kernel<4>, gu_lds_big)) return rc;
   }
   const int64_t red_threads = w.rmax * (a.D / 4);
   // update tiles: kRT rows, or 16 rows for batches of up to ~100 pairs (the kept rows are only known on the device: the
@@ -1442,6 +1764,15 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     if (env_rows) tile_rows = env_rows == 16 ? 16 : (env_rows == 32 ? 32 : R);
   }
   const int gu_grid = (int)(w.rmax / tile_rows);
+  // mode 3: 128-row tiles once they fill the chip at one workgroup per CU (two rounds and more)
+  bool big_tiles = x3 && tile_rows == R && (int64_t)mols * a.N >= (int64_t)2 * cus * kRT3;
+  {
+    static const int env_big = [] {
+      const char* e = getenv("IMPNN_WIDE_X3_BIG");
+      return e ? atoi(e) : -1;
+    }();
+    if (env_big >= 0) big_tiles = x3 && env_big != 0;
+  }
   unsigned long long* stamps = nullptr;  // [gu_grid x 8 | cus x 8] words, the last step's launches win
   {
     size_t sb = 0;
@@ -1469,7 +1800,11 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     gp.gu_off = step_off + (size_t)a.Vb * a.D * a.D;
     gp.meta = I(w.meta); gp.eps = a.ln_eps; gp.n_ions = a.n_ions; gp.tile_rows = tile_rows;
     gp.stamps = stamps;
-    if (x3) {
+    if (x3 && big_tiles) {  // batches that fill the chip: 128-row tiles
+      const int grid = (int)(w.rmax / kRT3);
+      if (nt == 8) wide_update_x3b_kernel<8><<<grid, kGuX3Threads, gu_lds_big, s>>>(gp);
+      else wide_update_x3b_kernel<4><<<grid, kGuX3Threads, gu_lds_big, s>>>(gp);
+    } else if (x3) {
       if (nt == 8) wide_update_x3_kernel<8><<<gu_grid, kGuX3Threads, gu_lds, s>>>(gp);
       else wide_update_x3_kernel<4><<<gu_grid, kGuX3Threads, gu_lds, s>>>(gp);
     } else if (nt == 8) {

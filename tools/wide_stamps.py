@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--dim", type=int, default=128)
 ap.add_argument("--steps", type=int, default=6)
+ap.add_argument("--mode", default="auto")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 Va, Vb = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB
@@ -24,10 +25,11 @@ inp = synthetic.make_batch(args.batch, seed=0)
 m = model.build_model(Va, Vb, atom_dim=args.dim, bond_dim=8, num_steps=args.steps, device=dev)
 m.load_weights(weights.init_weights("viscosity", Va, Vb, atom_dim=args.dim, bond_dim=8, num_steps=args.steps, seed=1))
 d = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+m.encoder_mode = args.mode
 for _ in range(20):
     m.encode_pooled(d, fused=True)
 torch.cuda.synchronize()
-gu_grid = (2 * args.batch * 40 + 2 * 64) // 64
+gu_grid = (2 * args.batch * 40 + 2 * 128 + 127) // 128 * 128 // 64  # the row space in 64-row tiles (ws_layout)
 cus = 256
 buf = torch.zeros((gu_grid + cus) * 8, dtype=torch.int64, device=dev)
 lib = _lib.load()
@@ -49,6 +51,8 @@ print(f"GatedUpdate tiles: {len(g)}; cycles per tile median {med(tot):.0f} (min 
       f"shader clock median {med(clk):.0f} MHz")
 print(f"  prologue {med(g[:, 1] - g[:, 0]):.0f}  phase 1 {med(g[:, 2] - g[:, 1]):.0f}  gates + phase 2 "
       f"{med(g[:, 3] - g[:, 2]):.0f}  epilogue {med(g[:, 4] - g[:, 3]):.0f}")
+if (g[:, 7] != 0).all():
+    print(f"  epilogue: blend + LayerNorm statistics {med(g[:, 7] - g[:, 3]):.0f}, normalise + store {med(g[:, 4] - g[:, 7]):.0f}")
 span = (g[:, 4].max() - g[:, 0].min())
 print(f"  launch span {span} cycles = {span / med(clk):.1f} us; sum of tiles / 256 CUs = {tot.sum() / 256:.0f} cycles")
 live = msg[:, 4] != 0
