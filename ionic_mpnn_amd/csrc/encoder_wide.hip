@@ -595,6 +595,7 @@ struct GuParams {
   float eps;
   int n_ions;
   int tile_rows;  // rows a workgroup updates: kRT, or 16 for launches too small to fill the chip with kRT-row tiles
+  int cus, tiles_max;  // wide_update_x3b_kernel: CUs of the device, 128-row tiles of the row space
   unsigned long long* stamps;  // diagnostics builds only (IMPNN_DIAG_WIDE_STAMPS)
 };
 
@@ -1198,7 +1199,7 @@ __global__ __launch_bounds__(kGuX3Threads, 2) void wide_update_x3_kernel(GuParam
       float vs = 0.f;
 #pragma unroll
       for (int f2 = 0; f2 < FG; ++f2) vs += part[f2 * R + rl];
-      inv[rt][gq] = 1.0f / sqrtf(vs * (1.0f / D) + p.eps);
+      inv[rt][gq] = __builtin_amdgcn_rsqf(vs * (1.0f / D) + p.eps);  // (v_rsq_f32, as the 128-row kernel: a batch and its shards may take different tile sizes and must agree bitwise)
     }
 #pragma unroll
   for (int TL = 0; TL < NL; ++TL) {
@@ -1241,8 +1242,8 @@ constexpr size_t gu_x3b_lds_bytes(int D) {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int NT>
-__global__ __launch_bounds__(kGuX3Threads, 1) void wide_update_x3b_kernel(GuParams p) {
+template <int NT, bool MINI>
+__device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, const int g, unsigned char* smem_b) {
   constexpr int D = 16 * NT, R = kRT3, LDR = D, T = kGuX3Threads;
   constexpr int RG = 2, FG = 4, NL = NT / FG, RTW = R / (16 * RG);  // a wave: RTW = 4 row tiles x NL feature tiles
   constexpr int NS = NT;                     // 32-k slices of a 2D-deep GEMM
@@ -1256,20 +1257,15 @@ __global__ __launch_bounds__(kGuX3Threads, 1) void wide_update_x3b_kernel(GuPara
   constexpr int ST2 = UA + UB2;
   static_assert((size_t)2 * ST2 * 16 + (size_t)R * LDR * 4 <= 160 * 1024, "phase 2 fits the LDS");
   static_assert((size_t)8 * R * 4 <= (size_t)2 * ST2 * 16, "the LayerNorm partials fit the stages");
-  extern __shared__ __align__(16) unsigned char smem_b[];
   uint4* const stage = reinterpret_cast<uint4*>(smem_b);                                  // phase 1: 2 x ST1 units
   uint4* const stage2 = stage;                                                            // phase 2: 2 x ST2 units (rows | Wh slice)
   float* const rhs = reinterpret_cast<float*>(smem_b + (size_t)2 * ST2 * 16);             // phase 2: R x LDR f32, r * h
   float* const part = reinterpret_cast<float*>(smem_b);                                   // epilogue: 2 x FG x R LayerNorm partials
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, a = lane & 15, q = lane >> 4;
   const int rg = wv % RG, fg = wv / RG;
-  const int64_t row0 = (int64_t)blockIdx.x * R;
-  const int end = p.meta[kMetaEnd];
-  if (row0 >= end) return;
-  const int g = (p.n_ions > 1 && row0 >= p.meta[kMetaBase + 1]) ? 1 : 0;
-  const int64_t ion_end = p.meta[kMetaBase + g] + p.meta[kMetaRows + g];
-  const int64_t row_end = row0 + R < ion_end ? row0 + R : ion_end;
-  if (row0 >= row_end) return;
+  // MINI: a 16-row piece of a tile of the last, partial round (wide_update_x3b_kernel): the same stages and slices, but
+  // only the waves of row group 0 multiply, and only their first row tile
+  auto active = [&](int rt) { return !MINI || (rg == 0 && rt == 0); };  // (wave-uniform)
   WIDE_STAMP(p.stamps, 0);
   WIDE_STAMP_REAL(p.stamps, 5);
   const float* img = p.img[g] + p.gu_off;
@@ -1331,28 +1327,18 @@ __global__ __launch_bounds__(kGuX3Threads, 1) void wide_update_x3b_kernel(GuPara
   auto load_hreg = [&]() {
 #pragma unroll
     for (int rt = 0; rt < RTW; ++rt)
+      if (active(rt)) {
 #pragma unroll
-      for (int TL = 0; TL < NL; ++TL)
+        for (int TL = 0; TL < NL; ++TL)
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq)
-          hreg[rt][TL][gq] = p.h[(row0 + 64 * rg + 16 * rt + 4 * q + gq) * D + 16 * (fg * NL + TL) + a];
+          for (int gq = 0; gq < 4; ++gq)
+            hreg[rt][TL][gq] = p.h[(row0 + 64 * rg + 16 * rt + 4 * q + gq) * D + 16 * (fg * NL + TL) + a];
+      }
   };
   // the nine products, smallest first: (row plane, kernel plane)
   constexpr int kPa[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}, kPb[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
   auto slice1 = [&](const uint4* cur, uint4* oth, int u) {
     bf16x8_t bz[NL][3], br[NL][3], av[2][3];
-    // slice u + 1 (rows in the staging registers since the last slice) to the other stage; u + 2 requested.  The two
-    // waves of a SIMD (w and w + 4) do it at opposite ends of the slice, so one of them always has MFMAs to issue.
-    if (u + 1 < NS) {  // slice u + 1 (rows in the staging registers since the last slice) to the other stage; u + 2 requested
-      park_rows(oth, pav[0], 0);
-      park_rows(oth, pav[1], 1);
-      __builtin_amdgcn_sched_barrier(0);  // (an LDS store behind a transfer in flight waits for the transfer)
-      if (u + 2 < NS) fetch_rows1(u + 2);
-      dma(P1 + (size_t)(u + 1) * UB1, oth + UA, UB1);
-      __builtin_amdgcn_sched_barrier(0);
-    } else {
-      load_hreg();
-    }
     // operands in the order the products take them (plane 2 of both first): the first MFMA waits for 5 fetches, not 15
 #pragma unroll
     for (int pl = 2; pl >= 0; --pl) {
@@ -1367,19 +1353,48 @@ __global__ __launch_bounds__(kGuX3Threads, 1) void wide_update_x3b_kernel(GuPara
     for (int rt = 0; rt < RTW; ++rt) {
       if (rt + 1 < RTW) read_a(cur, rt + 1, av[(rt + 1) & 1]);
       if (rt > 0) __builtin_amdgcn_sched_barrier(0);
+      // Row tile 0 shares its scheduling region with the split of slice u + 1's rows (in the staging registers since the
+      // last slice) and their LDS stores: vector instructions issue between the MFMAs of the bf16 pipe for free.
+      if (rt == 0 && u + 1 < NS) {
+        park_rows(oth, pav[0], 0);
+        if (!MINI) park_rows(oth, pav[1], 1);
+      }
+      if (active(rt)) {
 #pragma unroll
-      for (int pr = 0; pr < 9; ++pr)
+        for (int pr = 0; pr < 9; ++pr)
 #pragma unroll
-        for (int TL = 0; TL < NL; ++TL) {
-          z[rt][TL] = mfma_bf16(av[rt & 1][kPa[pr]], bz[TL][kPb[pr]], z[rt][TL]);
-          rr[rt][TL] = mfma_bf16(av[rt & 1][kPa[pr]], br[TL][kPb[pr]], rr[rt][TL]);
+          for (int TL = 0; TL < NL; ++TL) {
+            z[rt][TL] = mfma_bf16(av[rt & 1][kPa[pr]], bz[TL][kPb[pr]], z[rt][TL]);
+            rr[rt][TL] = mfma_bf16(av[rt & 1][kPa[pr]], br[TL][kPb[pr]], rr[rt][TL]);
+          }
+      }
+      if (!MINI && rt == 0 && u + 1 < NS) {
+#pragma unroll
+        for (int i = 0; i < 6 * NL; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
         }
+#pragma unroll
+        for (int i = 0; i < 3 * NL; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
+      if (rt == 0) {
+        if (u + 1 < NS) {  // slice u + 2's rows requested; slice u + 1's kernels on their way into the other stage
+          if (u + 2 < NS) fetch_rows1(u + 2);  // (behind the LDS stores: a store behind a transfer in flight waits for it)
+          dma(P1 + (size_t)(u + 1) * UB1, oth + UA, UB1);
+        } else {
+          load_hreg();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
   fetch_rows1(0);
   park_rows(stage, pav[0], 0);
-  park_rows(stage, pav[1], 1);
+  if (!MINI) park_rows(stage, pav[1], 1);
   __builtin_amdgcn_sched_barrier(0);
   fetch_rows1(1);
   dma(P1, stage + UA, UB1);
@@ -1398,19 +1413,21 @@ __global__ __launch_bounds__(kGuX3Threads, 1) void wide_update_x3b_kernel(GuPara
   };
   auto park2 = [&](uint4* st, int u) {
 #pragma unroll
-    for (int i = 0; i < RP; ++i)
+    for (int i = 0; i < (MINI ? 1 : RP); ++i)
       park_rows(st, u < NS / 2 ? ldv4(rhs + (a_row + 64 * i) * LDR + 32 * u + 4 * a_pc) : pav[i], i);
   };
   // (every wave is past the last barrier of phase 1: the stages are free)
 #pragma unroll
   for (int rt = 0; rt < RTW; ++rt)
+    if (active(rt)) {
 #pragma unroll
-    for (int TL = 0; TL < NL; ++TL)
+      for (int TL = 0; TL < NL; ++TL)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        z[rt][TL][gq] = fsig(z[rt][TL][gq]);
-        rhs[(64 * rg + 16 * rt + 4 * q + gq) * LDR + 16 * (fg * NL + TL) + a] = fsig(rr[rt][TL][gq]) * hreg[rt][TL][gq];
-      }
+        for (int gq = 0; gq < 4; ++gq) {
+          z[rt][TL][gq] = fsig(z[rt][TL][gq]);
+          rhs[(64 * rg + 16 * rt + 4 * q + gq) * LDR + 16 * (fg * NL + TL) + a] = fsig(rr[rt][TL][gq]) * hreg[rt][TL][gq];
+        }
+    }
   f32x4_t tt[RTW][NL];
 #pragma unroll
   for (int TL = 0; TL < NL; ++TL) {
@@ -1424,13 +1441,6 @@ __global__ __launch_bounds__(kGuX3Threads, 1) void wide_update_x3b_kernel(GuPara
   park2(stage2, 0);
   wg_barrier();
   auto slice2 = [&](const uint4* cur, uint4* oth, int u) {
-    if (u + 1 < NS) {  // slice u + 1: rows out of r * h or the staging registers, its Wh slice straight from global
-      park2(oth, u + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (u + 2 < NS && u + 2 >= NS / 2) fetch_rows2(u + 2);
-      dma(P2 + (size_t)(u + 1) * UB2, oth + UA, UB2);
-      __builtin_amdgcn_sched_barrier(0);
-    }
     bf16x8_t bv[NL][3], av[2][2][3];
 #pragma unroll
     for (int pl = 2; pl >= 0; --pl) {  // (in the order the products take them)
@@ -1446,14 +1456,34 @@ __global__ __launch_bounds__(kGuX3Threads, 1) void wide_update_x3b_kernel(GuPara
         read_a(cur, 2 * rp + 3, av[(rp + 1) & 1][1]);
       }
       if (rp > 0) __builtin_amdgcn_sched_barrier(0);
+      if (rp == 0 && u + 1 < NS) park2(oth, u + 1);  // (between the MFMAs, as in phase 1)
+      if (active(2 * rp)) {  // (MINI: row tile 1 rides along with row tile 0 - its rows are never stored)
 #pragma unroll
-      for (int pr = 0; pr < 9; ++pr)
+        for (int pr = 0; pr < 9; ++pr)
 #pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2)
+          for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
-          for (int TL = 0; TL < NL; ++TL)
-            tt[2 * rp + r2][TL] = mfma_bf16(av[rp & 1][r2][kPa[pr]], bv[TL][kPb[pr]], tt[2 * rp + r2][TL]);
+            for (int TL = 0; TL < NL; ++TL)
+              tt[2 * rp + r2][TL] = mfma_bf16(av[rp & 1][r2][kPa[pr]], bv[TL][kPb[pr]], tt[2 * rp + r2][TL]);
+      }
+      if (!MINI && rp == 0 && u + 1 < NS) {
+#pragma unroll
+        for (int i = 0; i < 6 * NL; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 3 * NL; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
+      if (rp == 0 && u + 1 < NS) {
+        if (u + 2 < NS && u + 2 >= NS / 2) fetch_rows2(u + 2);
+        dma(P2 + (size_t)(u + 1) * UB2, oth + UA, UB2);  // slice u + 1's Wh slice straight from global
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
   // (the first slice of aggregated messages, NS / 2, is requested inside slice NS / 2 - 2 and parked inside NS / 2 - 1)
@@ -1467,6 +1497,7 @@ __global__ __launch_bounds__(kGuX3Threads, 1) void wide_update_x3b_kernel(GuPara
   float sum[RTW][4];
 #pragma unroll
   for (int rt = 0; rt < RTW; ++rt)
+    if (active(rt))
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       float sacc = 0.f;
@@ -1484,6 +1515,7 @@ __global__ __launch_bounds__(kGuX3Threads, 1) void wide_update_x3b_kernel(GuPara
   float mean[RTW][4], inv[RTW][4];
 #pragma unroll
   for (int rt = 0; rt < RTW; ++rt)
+    if (active(rt))
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const int rl = 64 * rg + 16 * rt + 4 * q + gq;
@@ -1503,6 +1535,7 @@ __global__ __launch_bounds__(kGuX3Threads, 1) void wide_update_x3b_kernel(GuPara
   __syncthreads();
 #pragma unroll
   for (int rt = 0; rt < RTW; ++rt)
+    if (active(rt))
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const int rl = FG * R + 64 * rg + 16 * rt + 4 * q + gq;
@@ -1512,8 +1545,8 @@ __global__ __launch_bounds__(kGuX3Threads, 1) void wide_update_x3b_kernel(GuPara
       inv[rt][gq] = __builtin_amdgcn_rsqf(vs * (1.0f / D) + p.eps);  // (v_rsq_f32: 1 ulp)
     }
   WIDE_STAMP(p.stamps, 7);
-  // Every row of the tile is stored: the rows past row_end are padding of the row space (the gap behind an ion, the
-  // rows behind the last one) that nothing reads as a source, a target or a pooled row.
+  // Every row of the tile (MINI: of its 16-row piece) is stored: the rows past the ion's last are padding of the row
+  // space (the gap behind an ion, the rows behind the last one) that nothing reads as a source, a target or a pooled row.
   {
     float* const out = p.h + (row0 + 64 * rg + 4 * q) * D + 16 * fg * NL + a;
 #pragma unroll
@@ -1522,6 +1555,7 @@ __global__ __launch_bounds__(kGuX3Threads, 1) void wide_update_x3b_kernel(GuPara
       const float gm = bias[3 * D + f], bt = bias[4 * D + f];
 #pragma unroll
       for (int rt = 0; rt < RTW; ++rt)
+        if (active(rt))
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
           out[(16 * rt + gq) * D + 16 * TL] = (tt[rt][TL][gq] - mean[rt][gq]) * inv[rt][gq] * gm + bt + hreg[rt][TL][gq];
@@ -1529,6 +1563,38 @@ __global__ __launch_bounds__(kGuX3Threads, 1) void wide_update_x3b_kernel(GuPara
   }
   WIDE_STAMP(p.stamps, 4);
   WIDE_STAMP_REAL(p.stamps, 6);
+}
+
+// Grid: tiles_max workgroups, one per 128-row tile of the row space, then 8 x (cus - 1) "mini" workgroups.  The tiles of
+// the whole rounds (cus at a time) are updated by their own workgroup; the tiles of the last, partial round - a tile takes
+// ~50 us whatever the number of CUs at work - are cut into eight 16-row pieces, one mini workgroup each, so that the round
+// costs a third of a tile.  Workgroups are dispatched in grid order: the minis start as the CUs run out of whole tiles.
+template <int NT>
+__global__ __launch_bounds__(kGuX3Threads, 1) void wide_update_x3b_kernel(GuParams p) {
+  extern __shared__ __align__(16) unsigned char smem_b[];
+  constexpr int R = kRT3;
+  const int end = p.meta[kMetaEnd];
+  const int t_live = (end + R - 1) / R;
+  const int t_full = p.cus > 0 ? t_live / p.cus * p.cus : t_live;
+  const bool split = t_full > 0 && t_full < t_live;  // (a single partial round runs all at once: nothing to gain)
+  int tile, sub = -1;
+  if ((int)blockIdx.x < p.tiles_max) {
+    tile = blockIdx.x;
+    if (tile >= t_live || (split && tile >= t_full)) return;
+  } else {
+    if (!split) return;
+    const int m = (int)blockIdx.x - p.tiles_max;
+    tile = t_full + (m >> 3);
+    sub = m & 7;
+    if (tile >= t_live) return;
+  }
+  const int64_t tile0 = (int64_t)tile * R;
+  const int g = (p.n_ions > 1 && tile0 >= p.meta[kMetaBase + 1]) ? 1 : 0;
+  const int64_t ion_end = p.meta[kMetaBase + g] + p.meta[kMetaRows + g];
+  const int64_t row0 = tile0 + (sub >= 0 ? 16 * sub : 0);
+  if (row0 >= ion_end) return;
+  if (sub >= 0) x3b_tile<NT, true>(p, row0, g, smem_b);
+  else x3b_tile<NT, false>(p, row0, g, smem_b);
 }
 
 // a8: one thread per 16-byte piece of a pooled row, 4 rows in flight, ascending n.
@@ -1801,7 +1867,9 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     gp.meta = I(w.meta); gp.eps = a.ln_eps; gp.n_ions = a.n_ions; gp.tile_rows = tile_rows;
     gp.stamps = stamps;
     if (x3 && big_tiles) {  // batches that fill the chip: 128-row tiles
-      const int grid = (int)(w.rmax / kRT3);
+      gp.cus = cus;
+      gp.tiles_max = (int)(w.rmax / kRT3);
+      const int grid = gp.tiles_max + 8 * (cus - 1);
       if (nt == 8) wide_update_x3b_kernel<8><<<grid, kGuX3Threads, gu_lds_big, s>>>(gp);
       else wide_update_x3b_kernel<4><<<grid, kGuX3Threads, gu_lds_big, s>>>(gp);
     } else if (x3) {
