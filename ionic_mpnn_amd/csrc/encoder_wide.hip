@@ -65,6 +65,23 @@ __device__ __forceinline__ float row16_sum_f(float v) {
   return v;
 }
 
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4_t mfma_bf16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// two f32 -> their three packed bf16 pairs (low half <- x, high half <- y)
+__device__ __forceinline__ void split_pair_w(float x, float y, unsigned& w0, unsigned& w1, unsigned& w2) {
+  const unsigned xb = __builtin_bit_cast(unsigned, x), yb = __builtin_bit_cast(unsigned, y);
+  const float x1 = x - __builtin_bit_cast(float, xb & 0xffff0000u), y1 = y - __builtin_bit_cast(float, yb & 0xffff0000u);
+  const unsigned x1b = __builtin_bit_cast(unsigned, x1), y1b = __builtin_bit_cast(unsigned, y1);
+  const float x2 = x1 - __builtin_bit_cast(float, x1b & 0xffff0000u), y2 = y1 - __builtin_bit_cast(float, y1b & 0xffff0000u);
+  w0 = __builtin_amdgcn_perm(yb, xb, 0x07060302u);
+  w1 = __builtin_amdgcn_perm(y1b, x1b, 0x07060302u);
+  w2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, y2), __builtin_bit_cast(unsigned, x2), 0x07060302u);
+}
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;  // destination of global_load_lds (a wave-uniform LDS address)
+
 constexpr size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // In-kernel stamps (diagnostics builds only; tools/wide_stamps.py): thread 0 of a workgroup writes s_memtime into
@@ -96,9 +113,11 @@ inline int tile_edges(int D) { return D >= 128 ? 64 : 128; }
 
 // floats of one step of a prepared image: Vb type matrices (D x D, row-major [i][j]) | [Wz|Wr] slices | Wh slices |
 // bz br bh gamma beta
-// (mode 3: the gate kernels as three bf16 planes: 9 D^2 floats' worth of bytes instead of 6 D^2)
+// (mode 3: the gate kernels as three bf16 planes: 9 D^2 floats' worth of bytes instead of 6 D^2, and behind the vectors
+//  the type matrices once more as three bf16 planes in MFMA operand order: 1.5 Vb D^2 floats' worth - mat_planes_off)
+inline size_t mat_planes_off(int D, int Vb) { return (size_t)Vb * D * D + 9 * (size_t)D * D + 5 * (size_t)D; }
 inline size_t step_floats(int D, int Vb, bool x3 = false) {
-  return (size_t)Vb * D * D + (x3 ? 9 : 6) * (size_t)D * D + 5 * (size_t)D;
+  return x3 ? mat_planes_off(D, Vb) + (size_t)Vb * D * D / 2 * 3 : (size_t)Vb * D * D + 6 * (size_t)D * D + 5 * (size_t)D;
 }
 inline size_t prepared_bytes(int D, int S, int Vb, bool x3 = false) {
   return align_up((size_t)(S > 0 ? S : 1) * step_floats(D, Vb, x3) * 4, 256);
@@ -398,6 +417,7 @@ struct MsgParams {
   float* m;
   const float* img[2];      // prepared images; the type matrices of this step start at img[g] + mat_off
   size_t mat_off;
+  size_t planes_off;        // mode 3: the same matrices as bf16 planes (wide_mat_planes_kernel), img[g] + planes_off
   const int32_t* srcrow;
   const int32_t* tilebase;
   const int32_t* meta;
@@ -541,6 +561,187 @@ __global__ __launch_bounds__(1024) void wide_message_kernel(MsgParams p) {
     run_end = run_end2;
 #pragma unroll
     for (int i = 0; i < kX; ++i) sr1[i] = sr2[i];
+  }
+  WIDE_STAMP(p.stamps, 4);
+  WIDE_STAMP_REAL(p.stamps, 6);
+#ifdef IMPNN_DIAG_WIDE_STAMPS
+  if (p.stamps && threadIdx.x == 0) p.stamps[(size_t)blockIdx.x * 8 + 7] = (unsigned long long)(t1 - t0);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// a2 + a4 in mode IMPNN_ENCODER_F32X3_TYPED: the per-type GEMMs m = A[type] h[src] on the bf16 matrix pipe, every f32
+// operand carried exactly as three bf16 terms and all nine cross products accumulated in f32 (as the GatedUpdate of this
+// mode).  8 waves: a wave multiplies 32 edges x 32 features (2 x 2 MFMA tiles, 144 MFMAs per 64-edge tile).
+//   * a wave keeps ITS operands of the type's matrix - 32 feature rows, all k, three planes: 96 VGPRs - in registers
+//     for the whole run of the type (a type's run is ~40 tiles; the planes come pre-split and in operand order from
+//     the prepared image, wide_mat_planes_kernel), so a tile costs LDS traffic for the rows only;
+//   * the rows of the next tile are gathered under the MFMAs, split (three planes of bf16) and parked in the other of
+//     two LDS stages between the MFMAs of the second half of the tile: one barrier per tile.
+// Tiles, runs and the unconditional requests as in wide_message_kernel.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kMsgX3Threads = 512;
+constexpr size_t msg_x3_lds_bytes(int D, int TE, int nT) { return 2 * (size_t)3 * (D / 32) * 4 * (TE + 1) * 16 + (size_t)(nT + 1) * 4; }
+
+template <int NT, int TE>
+__global__ __launch_bounds__(kMsgX3Threads, 1) void wide_message_x3_kernel(MsgParams p) {
+  constexpr int D = 16 * NT, QD = D / 4, KB = D / 32, T = kMsgX3Threads;
+  constexpr int UM = 3 * KB * 4 * D;   // 16-byte units of a type's matrix (three planes): [plane][k block][k octet][feature]
+  constexpr int XS = TE + 1;           // units between the (k block, k octet) rows of a tile's planes: one unit of padding, so
+                                       // that the 16 k octets a wave parks at once fall into different LDS banks
+  constexpr int UX = 3 * KB * 4 * XS;  // ... of a tile of rows: [plane][k block][k octet][edge]
+  constexpr int kX = TE * QD / T;      // 16-byte pieces of f32 rows per thread
+  static_assert(TE == 64 && kX >= 1 && KB % 2 == 0, "tile shape");
+  extern __shared__ __align__(16) unsigned char smem_b[];
+  uint4* const Xb = reinterpret_cast<uint4*>(smem_b);             // 2 x UX units
+  int32_t* const tb_s = reinterpret_cast<int32_t*>(Xb + 2 * UX);  // tilebase[0 .. nT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = lane & 15, q = lane >> 4;
+  const int eg = wave & 1, fg = wave >> 1;  // 32 edges x 32 features
+  const int ntiles = p.meta[kMetaTiles];
+  const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t0 = blockIdx.x * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
+  if (t0 >= t1) return;
+  WIDE_STAMP(p.stamps, 0);
+  WIDE_STAMP_REAL(p.stamps, 5);
+  for (int t = tid; t <= p.nT; t += T) tb_s[t] = p.tilebase[t];
+  __syncthreads();
+  bf16x8_t am[KB][2][3];  // the wave's matrix operands: [k block][feature tile][plane]
+  auto load_mat = [&](int t) {
+    const int g = t >= p.Vb ? 1 : 0;
+    const uint4* src = reinterpret_cast<const uint4*>(p.img[g] + p.planes_off) + (size_t)(t - g * p.Vb) * UM;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int TL = 0; TL < 2; ++TL)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          am[kb][TL][pl] = __builtin_bit_cast(bf16x8_t, src[((pl * KB + kb) * 4 + q) * D + 16 * (fg * 2 + TL) + a]);
+  };
+  auto lds_barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // rows are requested TWO tiles ahead (two sets of staging registers, alternating), their source-row indices three
+  int srn[kX];
+  f32x4_t xa[kX], xb[kX];
+  auto fetch_sr = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < kX; ++i) srn[i] = p.srcrow[tile * TE + (tid + T * i) / QD];
+  };
+  auto fetch_x = [&](f32x4_t (&xr)[kX]) {  // the rows srn names
+#pragma unroll
+    for (int i = 0; i < kX; ++i) xr[i] = ldv4(p.h + (int64_t)srn[i] * D + 4 * ((tid + T * i) % QD));
+  };
+  auto park_piece = [&](uint4* X, const f32x4_t (&xr)[kX], int i) {  // 4 values of a row -> three planes of 4 bf16:
+    uint2* s2 = reinterpret_cast<uint2*>(X);                          // unit (plane, k block, k octet, edge), 8-byte half
+    const int idx = tid + T * i, e = idx / QD, c4 = idx - e * QD;
+    const int un = ((c4 >> 3) * 4 + ((c4 >> 1) & 3)) * XS + e, half = c4 & 1;
+    unsigned w0[2], w1[2], w2[2];
+    split_pair_w(xr[i][0], xr[i][1], w0[0], w1[0], w2[0]);
+    split_pair_w(xr[i][2], xr[i][3], w0[1], w1[1], w2[1]);
+    s2[(0 * KB * 4 * XS + un) * 2 + half] = make_uint2(w0[0], w0[1]);
+    s2[(1 * KB * 4 * XS + un) * 2 + half] = make_uint2(w1[0], w1[1]);
+    s2[(2 * KB * 4 * XS + un) * 2 + half] = make_uint2(w2[0], w2[1]);
+  };
+  int ty;
+  {  // type of the first tile: largest t with tilebase[t] <= t0 (empty types share a base with their successor)
+    int lo = 0, hi = p.nT - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (tb_s[mid] <= t0) lo = mid; else hi = mid - 1;
+    }
+    ty = lo;
+  }
+  int run_end = tb_s[ty + 1];  // first tile of the next type
+  const int tl = t1 - 1;  // (requests past the share's last tile name it again: no branch around them)
+  fetch_sr(t0);
+  load_mat(ty);
+  fetch_x(xa);                    // rows of t0
+  fetch_sr(min(t0 + 1, tl));
+#pragma unroll
+  for (int i = 0; i < kX; ++i) park_piece(Xb, xa, i);
+  fetch_x(xa);                    // rows of t0 + 1: parked inside tile t0
+  fetch_sr(min(t0 + 2, tl));      // (srn = the rows of t0 + 2: requested at the top of tile t0)
+  lds_barrier();
+  WIDE_STAMP(p.stamps, 1);
+  constexpr int kPa[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}, kPb[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};  // (matrix plane, row plane), smallest first
+  int cur = 0;
+  // tile `tile` out of stage cur; the rows of tile + 1 (in xpark since the tile before) go to the other stage, the rows
+  // of tile + 2 are requested into xfetch
+  auto do_tile = [&](int tile, f32x4_t (&xpark)[kX], f32x4_t (&xfetch)[kX]) {
+    const int nxt = min(tile + 1, tl);
+    int ty2 = ty, run_end2 = run_end;
+    if (nxt >= run_end) {  // (workgroup-uniform) a new type: step over empty ones
+      do {
+        ++ty2;
+        run_end2 = tb_s[ty2 + 1];
+      } while (run_end2 <= nxt);
+    }
+    fetch_x(xfetch);
+    fetch_sr(min(tile + 3, tl));
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const uint4* X = Xb + cur * UX;
+      f32x4_t acc[2][2];  // [feature tile][edge tile]
+#pragma unroll
+      for (int TL = 0; TL < 2; ++TL)
+#pragma unroll
+        for (int et = 0; et < 2; ++et) acc[TL][et] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      bf16x8_t xe[2][2][3];  // [buffer][edge tile][plane]
+#pragma unroll
+      for (int pl = 2; pl >= 0; --pl)  // (in the order the products take them)
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+          xe[0][et][pl] = __builtin_bit_cast(bf16x8_t, X[((pl * KB + 0) * 4 + q) * XS + 16 * (eg * 2 + et) + a]);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+        if (kb + 1 < KB) {
+#pragma unroll
+          for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+            for (int et = 0; et < 2; ++et)
+              xe[(kb + 1) & 1][et][pl] = __builtin_bit_cast(bf16x8_t, X[((pl * KB + kb + 1) * 4 + q) * XS + 16 * (eg * 2 + et) + a]);
+        }
+        // the next tile's rows (requested at the top of this one) are split and parked between the MFMAs of the last
+        // two k blocks: half of the thread's pieces each
+        if (kb >= KB - 2) {
+#pragma unroll
+          for (int i = (kb - (KB - 2)) * (kX / 2); i < (kb - (KB - 2) + 1) * (kX / 2); ++i) park_piece(Xb + (cur ^ 1) * UX, xpark, i);
+        }
+#pragma unroll
+        for (int pr = 0; pr < 9; ++pr)
+#pragma unroll
+          for (int TL = 0; TL < 2; ++TL)
+#pragma unroll
+            for (int et = 0; et < 2; ++et)
+              acc[TL][et] = mfma_bf16(am[kb][TL][kPa[pr]], xe[kb & 1][et][kPb[pr]], acc[TL][et]);
+        if (kb >= KB - 2) {
+#pragma unroll
+          for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);  // VALU
+          }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int et = 0; et < 2; ++et) {
+        float* dst = p.m + ((int64_t)tile * TE + 16 * (eg * 2 + et) + a) * D + 16 * (fg * 2) + 4 * q;
+#pragma unroll
+        for (int TL = 0; TL < 2; ++TL) stv4(dst + 16 * TL, acc[TL][et]);
+      }
+    }
+    if (ty2 != ty) load_mat(ty2);  // (workgroup-uniform; its latency is exposed once per type run)
+    lds_barrier();  // the other stage is complete, this one free: the stores above stay in flight
+    cur ^= 1;
+    ty = ty2;
+    run_end = run_end2;
+  };
+  for (int tile = t0; tile < t1; tile += 2) {
+    do_tile(tile, xa, xb);
+    if (tile + 1 < t1) do_tile(tile + 1, xb, xa);
   }
   WIDE_STAMP(p.stamps, 4);
   WIDE_STAMP_REAL(p.stamps, 6);
@@ -899,21 +1100,6 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
 //   * one workgroup of 8 waves per CU (a 32-k slice of [Wz|Wr] is 48 KB in three planes: two stages fill the LDS),
 //     wave = 32 rows x NL feature tiles of z and of r: 72 MFMAs per wave and slice between barriers.
 // ------------------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x4_t mfma_bf16(bf16x8_t a, bf16x8_t b, f32x4_t c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-}
-// two f32 -> their three packed bf16 pairs (low half <- x, high half <- y)
-__device__ __forceinline__ void split_pair_w(float x, float y, unsigned& w0, unsigned& w1, unsigned& w2) {
-  const unsigned xb = __builtin_bit_cast(unsigned, x), yb = __builtin_bit_cast(unsigned, y);
-  const float x1 = x - __builtin_bit_cast(float, xb & 0xffff0000u), y1 = y - __builtin_bit_cast(float, yb & 0xffff0000u);
-  const unsigned x1b = __builtin_bit_cast(unsigned, x1), y1b = __builtin_bit_cast(unsigned, y1);
-  const float x2 = x1 - __builtin_bit_cast(float, x1b & 0xffff0000u), y2 = y1 - __builtin_bit_cast(float, y1b & 0xffff0000u);
-  w0 = __builtin_amdgcn_perm(yb, xb, 0x07060302u);
-  w1 = __builtin_amdgcn_perm(y1b, x1b, 0x07060302u);
-  w2 = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, y2), __builtin_bit_cast(unsigned, x2), 0x07060302u);
-}
-
 constexpr int kGuX3Threads = 512;
 // LDS bytes: two stages of (rows 12 KB + [Wz|Wr] slice 3 x 4 x 2D x 16 B) - phase 2 re-cuts the same memory into two
 // stages of (rows + Wh slice) and the f32 copy of r*h - plus the LayerNorm partials
@@ -1240,7 +1426,6 @@ constexpr size_t gu_x3b_lds_bytes(int D) {
   return p1 > p2 ? p1 : p2;
 }
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int NT, bool MINI>
 __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, const int g, unsigned char* smem_b) {
@@ -1698,6 +1883,29 @@ __global__ void wide_gu_image_x3_kernel(const float* __restrict__ src, unsigned 
   }
 }
 
+// Mode 3: the step's type matrices A[v] (D x D, row-major [feature][k]) once more as three bf16 planes in the operand
+// order of wide_message_x3_kernel: per type 16-byte units [plane][k block][k octet][feature] of 8 consecutive k.
+__global__ void wide_mat_planes_kernel(const float* __restrict__ mats, unsigned short* __restrict__ dst, int Vb, int D) {
+  const int KB = D / 32;
+  const size_t per = (size_t)D * D, total = (size_t)Vb * per;
+  for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+    const size_t v = t / per;
+    const int e = (int)(t - v * per), f = e / D, k = e - f * D;
+    const float w = mats[t];
+    const unsigned u0 = __float_as_uint(w) & 0xffff0000u;
+    const float r1 = w - __uint_as_float(u0);
+    const unsigned u1 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(u1);
+    const unsigned u2 = __float_as_uint(r2);  // <= 8 significant bits left: its low half is zero
+    const int kb = k >> 5, q = (k >> 3) & 3, j = k & 7;
+    const size_t plane = (size_t)KB * 4 * D * 8;  // bf16 elements of one plane of a type
+    const size_t base = v * 3 * plane + (((size_t)kb * 4 + q) * D + f) * 8 + j;
+    dst[base] = (unsigned short)(u0 >> 16);
+    dst[base + plane] = (unsigned short)(u1 >> 16);
+    dst[base + 2 * plane] = (unsigned short)(u2 >> 16);
+  }
+}
+
 }  // namespace wide
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1724,9 +1932,11 @@ int launch_encoder_wide_prepare(const float* weights, const float* bond_table, i
     const float* w = weights + (size_t)st * canon;
     float* dst = img + (size_t)st * step_floats(D, Vb, x3);
     if (int rc = launch_bond_type_matrices(bond_table, w, dst, Vb, K, D, s)) return rc;
-    if (x3)
+    if (x3) {
       wide_gu_image_x3_kernel<<<128, 256, 0, s>>>(w + (size_t)K * D * D,
                                                   reinterpret_cast<unsigned short*>(dst + (size_t)Vb * D * D), D);
+      wide_mat_planes_kernel<<<512, 256, 0, s>>>(dst, reinterpret_cast<unsigned short*>(dst + mat_planes_off(D, Vb)), Vb, D);
+    }
     else
       wide_gu_image_kernel<<<64, 256, 0, s>>>(w + (size_t)K * D * D, dst + (size_t)Vb * D * D, D);
     if (int rc = check_launch("encoder_wide_prepare")) return rc;
@@ -1804,6 +2014,12 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   constexpr int R = kRT;
   const size_t gu_lds = x3 ? gu_x3_lds_bytes(a.D) : gu_lds_floats(a.D) * 4;
   const size_t gu_lds_big = gu_x3b_lds_bytes(a.D);
+  // mode 3 at atom_dim 128: the messages on the bf16 pipe too (64-edge tiles, as the plan cuts them for D = 128; the
+  // choice depends on the shape only, so a batch and its shards run the same kernels)
+  const bool x3_msg = x3 && nt == 8 && te == 64;
+  const size_t msg_x3_lds = msg_x3_lds_bytes(a.D, 64, w.nT);
+  if (x3_msg)
+    if (int rc = raise_lds<8>(wide_message_x3_kernel<8, 64>, msg_x3_lds)) return rc;
   if (a.D == 128) {
     if (int rc = raise_lds<0>(wide_message_kernel<8, 64>, msg_lds)) return rc;
     if (int rc = x3 ? raise_lds<4>(wide_update_x3_kernel<8>, gu_lds) : raise_lds<1>(wide_update_kernel<8>, gu_lds)) return rc;
@@ -1854,7 +2070,10 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     mp.srcrow = I(w.srcrow); mp.tilebase = I(w.tilebase); mp.meta = I(w.meta);
     mp.nT = w.nT; mp.Vb = a.Vb;
     mp.stamps = stamps ? stamps + (size_t)gu_grid * 8 : nullptr;
-    if (a.E > 0) {
+    mp.planes_off = step_off + mat_planes_off(a.D, a.Vb);
+    if (a.E > 0 && x3_msg) {
+      wide_message_x3_kernel<8, 64><<<cus, kMsgX3Threads, msg_x3_lds, s>>>(mp);
+    } else if (a.E > 0) {
       if (nt == 8) wide_message_kernel<8, 64><<<cus, 1024, msg_lds, s>>>(mp);
       else wide_message_kernel<4, 128><<<cus, 1024, msg_lds, s>>>(mp);
     }

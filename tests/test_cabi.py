@@ -84,7 +84,8 @@ def test_encoder_shape_coverage_is_reported():
     assert lib.impnn_encoder_workspace_bytes(2, 16, 40, 80, 32, 8, 3, 72, F32, -1, C.byref(need)) == -1
     assert lib.impnn_encoder_prepared_bytes(32, 3, 72, 3) > lib.impnn_encoder_prepared_bytes(32, 3, 72, TYPED) > lib.impnn_encoder_prepared_bytes(32, 3, 72, F32) > 0
     assert lib.impnn_encoder_prepared_bytes(128, 6, 72, TYPED) == 6 * (72 * 128 * 128 + 6 * 128 * 128 + 5 * 128) * 4
-    assert lib.impnn_encoder_prepared_bytes(128, 6, 72, 3) == 6 * (72 * 128 * 128 + 9 * 128 * 128 + 5 * 128) * 4   # bf16 planes
+    # mode 3, wide: f32 type matrices | gate kernels as three bf16 planes | vectors | the type matrices as three bf16 planes
+    assert lib.impnn_encoder_prepared_bytes(128, 6, 72, 3) == 6 * (72 * 128 * 128 + 9 * 128 * 128 + 5 * 128 + 72 * 128 * 128 * 3 // 2) * 4
     assert lib.impnn_encoder_prepared_bytes(128, 6, 72, F32) == 0 and lib.impnn_encoder_prepared_bytes(48, 6, 72, TYPED) == 0
 
 
