@@ -26,7 +26,7 @@ def make_model(w, Va, Vb, D, K=8, mode="auto"):
     return m
 
 
-WIDE_MODES = ["f32t", "f32x3"]  # exact f32 MFMA; GatedUpdate as bf16x9 emulation (round 3: wide_update_x3_kernel)
+WIDE_MODES = ["f32t", "f32x3"]  # exact f32 MFMA; the GEMMs of the message (atom_dim 128) and GatedUpdate layers as bf16x9 emulation
 
 
 def oracle_pooled(w, inp):
@@ -253,6 +253,30 @@ def test_wide_encoder_fuzz_against_the_oracle(seed):
     what = f"(D={D} N={N} E={E} K={K} S={S} B={B} Va={Va} Vb={Vb})"
     assert_close(pc.cpu().numpy(), rc, what="cat pooled " + what)
     assert_close(pa.cpu().numpy(), ra, what="an pooled " + what)
+
+
+def test_wide_f32x3_large_batch_kernels_at_atom_dim_64():
+    """atom_dim 64 at a batch that fills the chip (the 128-row GatedUpdate tiles and their 16-row pieces of the last
+    round; messages stay on the exact-f32 kernel at this width): against the fp64 oracle on a sample, against the
+    exact-f32 mode everywhere, shards bitwise (the halves take the 64-row kernel)."""
+    Va, Vb, B = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, 1024
+    inp = synthetic.make_batch(B, seed=61)
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=64, bond_dim=8, num_steps=3, seed=62, perturb=True)
+    idx = np.random.default_rng(5).choice(B, size=16, replace=False)
+    ref = np.concatenate(oracle_pooled(w, {k: v[idx] for k, v in inp.items()}))
+    d, out = to_dev(inp), {}
+    for mode in WIDE_MODES:
+        m = make_model(w, Va, Vb, 64, mode=mode)
+        pc, pa = m.encode_pooled(d, fused=True)
+        out[mode] = torch.cat([pc, pa]).double().cpu().numpy()
+        got = np.concatenate([pc.cpu().numpy()[idx], pa.cpu().numpy()[idx]]).astype(np.float64)
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), mode
+        if mode == "f32x3":
+            h = B // 2 + 3
+            c0, a0 = m.encode_pooled({k: v[:h].contiguous() for k, v in d.items()}, fused=True)
+            c1, a1 = m.encode_pooled({k: v[h:].contiguous() for k, v in d.items()}, fused=True)
+            assert torch.equal(torch.cat([c0, c1]), pc) and torch.equal(torch.cat([a0, a1]), pa)
+    assert np.abs(out["f32x3"] - out["f32t"]).max() <= 2e-5 * np.abs(out["f32t"]).max()
 
 
 def test_wide_f32x3_error_within_twice_f32t_and_bitwise_properties():

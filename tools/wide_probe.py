@@ -17,6 +17,7 @@ ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--dim", type=int, default=128)
 ap.add_argument("--steps", type=int, default=6)
 ap.add_argument("--iters", type=int, default=8)
+ap.add_argument("--mode", default="auto", help="auto (exact f32) | f32x3 (GEMMs as bf16x9 emulation)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 Va, Vb = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB
@@ -24,6 +25,7 @@ inp = synthetic.make_batch(args.batch, seed=0)
 m = model.build_model(Va, Vb, atom_dim=args.dim, bond_dim=8, num_steps=args.steps, device=dev)
 m.load_weights(weights.init_weights("viscosity", Va, Vb, atom_dim=args.dim, bond_dim=8, num_steps=args.steps, seed=1))
 d = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+m.encoder_mode = args.mode
 for _ in range(3):
     m.encode_pooled(d, fused=True)
 torch.cuda.synchronize()
@@ -32,4 +34,4 @@ for _ in range(args.iters):
     pc, pa = m.encode_pooled(d, fused=True)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / args.iters * 1e3
-print(json.dumps({"encode_ms": ms, "pairs_per_s": args.batch / ms * 1e3, "checksum": float(pc.sum() + pa.sum())}))
+print(json.dumps({"mode": args.mode, "encode_ms": ms, "pairs_per_s": args.batch / ms * 1e3, "checksum": float(pc.sum() + pa.sum())}))
