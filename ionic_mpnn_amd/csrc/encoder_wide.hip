@@ -603,8 +603,6 @@ __global__ __launch_bounds__(kMsgX3Threads, 1) void wide_message_x3_kernel(MsgPa
   if (t0 >= t1) return;
   WIDE_STAMP(p.stamps, 0);
   WIDE_STAMP_REAL(p.stamps, 5);
-  for (int t = tid; t <= p.nT; t += T) tb_s[t] = p.tilebase[t];
-  __syncthreads();
   bf16x8_t am[KB][2][3];  // the wave's matrix operands: [k block][feature tile][plane]
   auto load_mat = [&](int t) {
     const int g = t >= p.Vb ? 1 : 0;
@@ -640,6 +638,11 @@ __global__ __launch_bounds__(kMsgX3Threads, 1) void wide_message_x3_kernel(MsgPa
     s2[(1 * KB * 4 * XS + un) * 2 + half] = make_uint2(w1[0], w1[1]);
     s2[(2 * KB * 4 * XS + un) * 2 + half] = make_uint2(w2[0], w2[1]);
   };
+  // (the first source rows are requested together with the run table: one round trip to memory instead of two)
+  const int tl = t1 - 1;  // (requests past the share's last tile name it again: no branch around them)
+  fetch_sr(t0);
+  for (int t = tid; t <= p.nT; t += T) tb_s[t] = p.tilebase[t];
+  __syncthreads();
   int ty;
   {  // type of the first tile: largest t with tilebase[t] <= t0 (empty types share a base with their successor)
     int lo = 0, hi = p.nT - 1;
@@ -650,10 +653,8 @@ __global__ __launch_bounds__(kMsgX3Threads, 1) void wide_message_x3_kernel(MsgPa
     ty = lo;
   }
   int run_end = tb_s[ty + 1];  // first tile of the next type
-  const int tl = t1 - 1;  // (requests past the share's last tile name it again: no branch around them)
-  fetch_sr(t0);
-  load_mat(ty);
   fetch_x(xa);                    // rows of t0
+  load_mat(ty);
   fetch_sr(min(t0 + 1, tl));
 #pragma unroll
   for (int i = 0; i < kX; ++i) park_piece(Xb, xa, i);
@@ -1609,7 +1610,7 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
       for (int TL = 0; TL < NL; ++TL)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          z[rt][TL][gq] = fsig(z[rt][TL][gq]);
+          if (MINI) z[rt][TL][gq] = fsig(z[rt][TL][gq]);  // (whole tiles: between the MFMAs of phase 2, slice2)
           rhs[(64 * rg + 16 * rt + 4 * q + gq) * LDR + 16 * (fg * NL + TL) + a] = fsig(rr[rt][TL][gq]) * hreg[rt][TL][gq];
         }
     }
@@ -1642,6 +1643,16 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
       }
       if (rp > 0) __builtin_amdgcn_sched_barrier(0);
       if (rp == 0 && u + 1 < NS) park2(oth, u + 1);  // (between the MFMAs, as in phase 1)
+      // the update gate's sigmoids are not needed before the blend: they ride between the MFMAs of the second row-tile
+      // pair of slices 0 and 1 (two row tiles each) instead of standing in front of phase 2
+      if (!MINI && rp == 1 && u < 2) {
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2)
+#pragma unroll
+          for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) z[2 * u + r2][TL][gq] = fsig(z[2 * u + r2][TL][gq]);
+      }
       if (active(2 * rp)) {  // (MINI: row tile 1 rides along with row tile 0 - its rows are never stored)
 #pragma unroll
         for (int pr = 0; pr < 9; ++pr)
@@ -1663,6 +1674,13 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
           __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
         }
       }
+      if (!MINI && rp == 1 && u < 2) {
+#pragma unroll
+        for (int i = 0; i < 9 * NL; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // VALU (two of every four are quarter-rate)
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (rp == 0 && u + 1 < NS) {
         if (u + 2 < NS && u + 2 >= NS / 2) fetch_rows2(u + 2);
@@ -1679,6 +1697,24 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
   }
   WIDE_STAMP(p.stamps, 3);
   // ---- blend, LayerNorm over the D features of a row, residual (models/layers.py:150-156): as wide_update_kernel
+  // sum over the 16 lanes of a quarter wave, all of the wave's rows step by step (a row's next step is 16 instructions
+  // behind its last: no stall between dependent DPP operations)
+  auto row16_sum_all = [&](float (&v)[RTW][4]) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int rt = 0; rt < RTW; ++rt)
+        if (active(rt))
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int iv = __builtin_bit_cast(int, v[rt][gq]);
+            const int o = st == 0 ? __builtin_amdgcn_update_dpp(0, iv, 0x121, 0xf, 0xf, true)
+                          : st == 1 ? __builtin_amdgcn_update_dpp(0, iv, 0x122, 0xf, 0xf, true)
+                          : st == 2 ? __builtin_amdgcn_update_dpp(0, iv, 0x124, 0xf, 0xf, true)
+                                    : __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xf, 0xf, true);
+            v[rt][gq] += __builtin_bit_cast(float, o);
+          }
+  };
   float sum[RTW][4];
 #pragma unroll
   for (int rt = 0; rt < RTW; ++rt)
@@ -1693,11 +1729,17 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
         tt[rt][TL][gq] = nv;
         sacc += nv;
       }
-      sum[rt][gq] = row16_sum_f(sacc);
-      if (a == 0) part[fg * R + 64 * rg + 16 * rt + 4 * q + gq] = sum[rt][gq];
+      sum[rt][gq] = sacc;
     }
+  row16_sum_all(sum);
+#pragma unroll
+  for (int rt = 0; rt < RTW; ++rt)
+    if (active(rt))
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        if (a == 0) part[fg * R + 64 * rg + 16 * rt + 4 * q + gq] = sum[rt][gq];
   __syncthreads();
-  float mean[RTW][4], inv[RTW][4];
+  float mean[RTW][4], inv[RTW][4], var[RTW][4];
 #pragma unroll
   for (int rt = 0; rt < RTW; ++rt)
     if (active(rt))
@@ -1714,9 +1756,15 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
         const float dv = tt[rt][TL][gq] - mean[rt][gq];
         vs = fmaf(dv, dv, vs);
       }
-      vs = row16_sum_f(vs);
-      if (a == 0) part[FG * R + fg * R + rl] = vs;
+      var[rt][gq] = vs;
     }
+  row16_sum_all(var);
+#pragma unroll
+  for (int rt = 0; rt < RTW; ++rt)
+    if (active(rt))
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        if (a == 0) part[FG * R + fg * R + 64 * rg + 16 * rt + 4 * q + gq] = var[rt][gq];
   __syncthreads();
 #pragma unroll
   for (int rt = 0; rt < RTW; ++rt)
