@@ -1,4 +1,4 @@
-set -e
+# (no set -e: a failing diagnostics step must not cost the rest of the evidence)
 # One GPU-box run that regenerates the round's evidence under gpurun_out/rN (copy what is to be judged into profiles/).
 R=${1:-r3}
 mkdir -p gpurun_out/$R
