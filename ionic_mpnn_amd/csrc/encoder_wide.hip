@@ -10,7 +10,7 @@
 //   plan (graph only, once per batch)
 //     wide_count      one wave per molecule: kept rows r_b (rows that can send, receive or be pooled - the same rule as
 //                     the D = 32 encoders, encoder_plan.hip) and the histogram of valid edges by (ion, bond type)
-//     wide_scan       one workgroup: compact row base of every molecule (an ion starts at a multiple of 64 rows),
+//     wide_scan       one workgroup: compact row base of every molecule (an ion starts at a multiple of 128 rows),
 //                     per-type runs of the type-sorted edge list and their tiles
 //     wide_place      valid edges into their type's run (source row per sorted position) and, per kept row, the
 //                     positions of its in-edges IN EDGE-SLOT ORDER (the reference's sequential scatter_nd order,
@@ -19,9 +19,12 @@
 //     wide_embed      h[row] = atom_table[atom id]                               (a1)
 //     S x  wide_message   m[p] = A[type_p] h[src_p]: one GEMM per type run, 64-edge tiles, the type's matrix resident
 //                         in LDS, next tile's rows in flight under the MFMAs      (a2 + a4, models/layers.py:100-117)
+//                         (mode f32x3 at D = 128: wide_message_x3 - bf16x9, matrix operands in registers)
 //          wide_reduce    agg[row] = sum of its in-edge messages, slot order      (a5)
 //          wide_update    GatedUpdate on 64-row tiles (two workgroups per CU), [h|agg] and the gate kernels
 //                         streamed through LDS in 16-deep k slices, h updated in place (a7, models/layers.py:142-156)
+//                         (mode f32x3: wide_update_x3 on 64-row tiles, wide_update_x3b on 128-row tiles once a batch
+//                         fills the chip - bf16x9, kernel slices straight from global into LDS)
 //     wide_pool       pooled[b] = sum_n h[b,n] [atom_ids[b,n] > 0], ascending n   (a8)
 //
 // Every product is an exact f32 product on v_mfma_f32_16x16x4_f32; every sum has a fixed order that does not depend
@@ -1415,8 +1418,11 @@ __global__ __launch_bounds__(kGuX3Threads, 2) void wide_update_x3_kernel(GuParam
 //   * the nine products of an output tile form a dependent chain: the MFMAs are issued product by product ACROSS the
 //     wave's four chains of a row tile (a chain's next link is four instructions away), and the operands of the next
 //     row tile are requested in front of them;
-//   * phase 2 keeps r * h as f32 in LDS (67 KB) beside ONE row stage and TWO kernel stages: multiply - barrier - park
-//     the next row slice - barrier.
+//   * the split of slice u + 1's rows and their LDS stores sit between the MFMAs of slice u's first row tile
+//     (sched_group_barrier): the bf16 pipe co-executes with the vector ALU;
+//   * phase 2 re-cuts the LDS into two (rows + Wh slice) stages and an unpadded f32 copy of r * h - 160 KB at D = 128 -
+//     and runs like phase 1 (one barrier per slice); the LayerNorm partials reuse a stage at the end;
+//   * the tiles of the last, partial round are cut into 16-row pieces (wide_update_x3b_kernel below, MINI).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int kRT3 = 128;
 // LDS: phase 1 two stages of (rows 24 KB + [Wz|Wr] slice); phase 2 re-cuts the same memory into two row stages, two Wh
