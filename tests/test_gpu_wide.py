@@ -306,3 +306,71 @@ def test_wide_f32x3_error_within_twice_f32t_and_bitwise_properties():
     for i in range(3):
         assert err["f32x3"][i] <= 2.0 * err["f32t"][i] + 1e-7, err
     assert err["f32x3"][0] <= 1e-5 and err["f32t"][0] <= 1e-5, err
+
+
+def _wide_mode_outputs(w, inp, D):
+    Va, Vb = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB
+    d, out = to_dev(inp), {}
+    for mode in WIDE_MODES:
+        pc, pa = make_model(w, Va, Vb, D, mode=mode).encode_pooled(d, fused=True)
+        out[mode] = torch.cat([pc, pa]).double().cpu().numpy()
+    return out
+
+
+@pytest.mark.parametrize("what", ["embeddings", "bond_transform", "gate_kernels"])
+def test_wide_f32x3_magnitude_sweep_at_a_chip_filling_batch(what):
+    """The ruling's magnitude condition for the wide bf16x9 kernels (128-row GatedUpdate tiles, 16-row pieces, per-type
+    message GEMMs with register-resident matrix planes: batch 1024 at atom_dim 128): embeddings, message weights or gate
+    kernels scaled by 1e-12 ... 1e+12 - error against the fp64 oracle (a sample of molecules) within twice exact f32's
+    wherever exact f32 itself is within 1e-5, the same finiteness pattern everywhere."""
+    Va, Vb, B = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, 1024
+    inp = synthetic.make_batch(B, seed=91)
+    w0 = weights.init_weights("viscosity", Va, Vb, atom_dim=128, bond_dim=8, num_steps=2, seed=92, perturb=True)
+    idx = np.random.default_rng(6).choice(B, size=10, replace=False)
+    sub = {k: v[idx] for k, v in inp.items()}
+    sel = np.concatenate([idx, B + idx])
+    for sc in (1e-12, 1e-4, 1.0, 1e4, 1e12):
+        w = dict(w0)
+        for k in w0:
+            hit = (what == "embeddings" and k in ("atom_embedding", "bond_embedding")) or \
+                  (what == "bond_transform" and k.endswith("bond_transform")) or \
+                  (what == "gate_kernels" and "/dense_" in k and k.endswith("kernel") and "_gu_" in k)
+            if hit:
+                w[k] = (w0[k].astype(np.float64) * sc).astype(np.float32)
+        ref = np.concatenate(oracle_pooled(w, sub))
+        out = _wide_mode_outputs(w, inp, 128)
+        assert np.isfinite(ref).all(), (what, sc)
+        assert np.array_equal(np.isfinite(out["f32t"]), np.isfinite(out["f32x3"])), (what, sc)
+        if not np.isfinite(out["f32t"]).all():
+            continue
+        scale = np.abs(ref).max()
+        err = {m: float(np.abs(out[m][sel] - ref).max() / scale) for m in WIDE_MODES}
+        if err["f32t"] <= 1e-5:
+            assert err["f32x3"] <= 2.0 * err["f32t"] + 1e-7 and err["f32x3"] <= 1e-5, (what, sc, err)
+        else:  # ill-conditioned corner (saturated gates amplify any f32 rounding): the same order of magnitude
+            assert err["f32x3"] <= 4.0 * err["f32t"] + 1e-7, (what, sc, err)
+
+
+def test_wide_f32x3_propagates_nan_like_f32t():
+    """A NaN in an embedding row or a weight makes the same molecules' outputs NaN in both wide modes and leaves every
+    other molecule's output as it was; an infinity never yields a finite value where exact f32 reports none."""
+    Va, Vb, B = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, 1024
+    inp = synthetic.make_batch(B, seed=93)
+    w0 = weights.init_weights("viscosity", Va, Vb, atom_dim=128, bond_dim=8, num_steps=2, seed=94, perturb=True)
+    clean = _wide_mode_outputs(w0, inp, 128)
+    for bad in (np.nan, np.inf):
+        for key, where in (("atom_embedding", (17, 5)), ("bond_embedding", (9, 2)), ("cat_gu_1/dense_r/kernel", (40, 3)),
+                           ("an_bmm_0/bond_transform", (3, 7, 11))):
+            w = {k: v.copy() for k, v in w0.items()}
+            w[key][where] = bad
+            res = _wide_mode_outputs(w, inp, 128)
+            fin_t, fin_x = np.isfinite(res["f32t"]).all(axis=1), np.isfinite(res["f32x3"]).all(axis=1)
+            assert not (fin_x & ~fin_t).any(), (bad, key)   # never finite where exact f32 is not
+            if np.isnan(bad):
+                assert not fin_t.all(), (bad, key)          # the poison reached some molecule
+                assert np.array_equal(fin_t, fin_x), (bad, key, int(fin_t.sum()), int(fin_x.sum()))
+            # (an infinite gate kernel saturates the exact-f32 sigmoid to 0 / 1 - finite everywhere - while its three-term
+            #  split is (inf, nan, nan): the emulation is the more conservative of the two, encoder_typed.hip)
+            both = fin_t & fin_x
+            untouched = both & (np.abs(res["f32t"] - clean["f32t"]).max(axis=1) == 0)
+            assert np.array_equal(res["f32x3"][untouched], clean["f32x3"][untouched]), (bad, key)
