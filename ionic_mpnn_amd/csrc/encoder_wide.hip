@@ -1026,6 +1026,23 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
   }
   WIDE_STAMP(p.stamps, 3);
   // ---- blend, LayerNorm over the D features of a row, residual (models/layers.py:150-156)
+  // (row sums over the 16 lanes of a quarter wave, all of the wave's rows step by step: a row's next DPP step is eight
+  //  instructions behind its last, no stall between dependent DPP operations)
+  auto row16_sum_all = [&](float (&v)[2][4]) {
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int iv = __builtin_bit_cast(int, v[rt][gq]);
+          const int o = st == 0 ? __builtin_amdgcn_update_dpp(0, iv, 0x121, 0xf, 0xf, true)
+                        : st == 1 ? __builtin_amdgcn_update_dpp(0, iv, 0x122, 0xf, 0xf, true)
+                        : st == 2 ? __builtin_amdgcn_update_dpp(0, iv, 0x124, 0xf, 0xf, true)
+                                  : __builtin_amdgcn_update_dpp(0, iv, 0x128, 0xf, 0xf, true);
+          v[rt][gq] += __builtin_bit_cast(float, o);
+        }
+  };
   float sum[2][4];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
@@ -1039,11 +1056,16 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
         tt[rt][TL][gq] = nv;
         sacc += nv;
       }
-      sum[rt][gq] = row16_sum_f(sacc);
-      if (a == 0) part[fg * R + 32 * rg + 16 * rt + 4 * q + gq] = sum[rt][gq];
+      sum[rt][gq] = sacc;
     }
+  row16_sum_all(sum);
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+      if (a == 0) part[fg * R + 32 * rg + 16 * rt + 4 * q + gq] = sum[rt][gq];
   __syncthreads();
-  float mean[2][4], inv[2][4];
+  float mean[2][4], inv[2][4], var[2][4];
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -1059,9 +1081,14 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
         const float dv = tt[rt][TL][gq] - mean[rt][gq];
         vs = fmaf(dv, dv, vs);
       }
-      vs = row16_sum_f(vs);
-      if (a == 0) part[FG * R + fg * R + rl] = vs;
+      var[rt][gq] = vs;
     }
+  row16_sum_all(var);
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+      if (a == 0) part[FG * R + fg * R + 32 * rg + 16 * rt + 4 * q + gq] = var[rt][gq];
   __syncthreads();
 #pragma unroll
   for (int rt = 0; rt < 2; ++rt)
@@ -1071,20 +1098,25 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
       float vs = 0.f;
 #pragma unroll
       for (int f2 = 0; f2 < FG; ++f2) vs += part[f2 * R + rl];
-      inv[rt][gq] = 1.0f / sqrtf(vs * (1.0f / D) + p.eps);
+      inv[rt][gq] = __builtin_amdgcn_rsqf(vs * (1.0f / D) + p.eps);  // (v_rsq_f32: 1 ulp)
     }
+  {
+    float* const out = p.h + (row0 + 32 * rg + 4 * q) * D + 16 * fg * NL + a;
+    // a whole tile (tile_rows == R) stores every row: rows past row_end are padding of the row space, which nothing
+    // reads as a source, a target or a pooled row; a workgroup that owns only the first rows of its LDS tile checks
+    const bool all_rows = p.tile_rows == R;  // (workgroup-uniform)
 #pragma unroll
-  for (int TL = 0; TL < NL; ++TL) {
-    const int f = 16 * (fg * NL + TL) + a;
-    const float gm = bias[3 * D + f], bt = bias[4 * D + f];
+    for (int TL = 0; TL < NL; ++TL) {
+      const int f = 16 * (fg * NL + TL) + a;
+      const float gm = bias[3 * D + f], bt = bias[4 * D + f];
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+      for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int64_t row = row0 + 32 * rg + 16 * rt + 4 * q + gq;
-        if (row < row_end)
-          p.h[row * D + f] = (tt[rt][TL][gq] - mean[rt][gq]) * inv[rt][gq] * gm + bt + hreg[rt][TL][gq];
-      }
+        for (int gq = 0; gq < 4; ++gq) {
+          const float v = (tt[rt][TL][gq] - mean[rt][gq]) * inv[rt][gq] * gm + bt + hreg[rt][TL][gq];
+          if (all_rows || row0 + 32 * rg + 16 * rt + 4 * q + gq < row_end) out[(16 * rt + gq) * D + 16 * TL] = v;
+        }
+    }
   }
   WIDE_STAMP(p.stamps, 4);
   WIDE_STAMP_REAL(p.stamps, 6);
