@@ -107,7 +107,7 @@ constexpr size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // workspace
 // ------------------------------------------------------------------------------------------------------------
 struct Ws {
-  size_t meta, kept, rowbase, cnt, tstart, tilebase, cursor, srcrow, rowinfo, csr, h, agg, m, img, total;
+  size_t meta, kept, rowbase, cnt, tstart, tilebase, cursor, srcrow, rowinfo, csr, aggcode, h, agg, m, img, total;
   int64_t rmax, vmax;
   int nT;
 };
@@ -148,6 +148,7 @@ inline Ws ws_layout(int n_ions, int B, int N, int E, int D, int S, int Vb, bool 
   w.srcrow = take((size_t)w.vmax * 4);
   w.rowinfo = take((size_t)w.rmax * 8);
   w.csr = take((size_t)w.vmax * 4);
+  w.aggcode = take((size_t)w.rmax * 4);
   w.h = take((size_t)w.rmax * D * 4);
   w.agg = take((size_t)w.rmax * D * 4);
   w.m = take((size_t)w.vmax * D * 4);
@@ -174,6 +175,15 @@ __device__ __forceinline__ int valid_type(const int32_t* conn, const int32_t* bo
 // ------------------------------------------------------------------------------------------------------------
 // plan kernels
 // ------------------------------------------------------------------------------------------------------------
+// aggcode[row]: where the GatedUpdate finds the row's aggregated messages - the row itself (in `agg`, written by
+// wide_reduce) or, for a row with exactly ONE in-edge, ~position of that edge's message in `m` (the sum of one message is
+// the message: wide_reduce skips such rows - half of the atoms of a tree, every hydrogen of an explicit-hydrogen
+// molecule - and neither reads nor writes their 512 bytes).  Identity here, single in-edges from wide_place.
+__global__ void wide_iota_kernel(int32_t* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
 __global__ void wide_zero_kernel(int32_t* __restrict__ p, int n) {
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) p[t] = 0;
 }
@@ -306,7 +316,8 @@ __global__ __launch_bounds__(1024) void wide_scan_kernel(const int32_t* __restri
 __global__ __launch_bounds__(256) void wide_place_kernel(Inputs in, const int32_t* __restrict__ kept,
                                                          const int32_t* __restrict__ rowbase,
                                                          int32_t* __restrict__ cursor, int32_t* __restrict__ srcrow,
-                                                         int2* __restrict__ rowinfo, int32_t* __restrict__ csr) {
+                                                         int2* __restrict__ rowinfo, int32_t* __restrict__ csr,
+                                                         int32_t* __restrict__ aggcode) {
   __shared__ int32_t lh[2 * kMaxVb];
   __shared__ int16_t tg_s[4][kMaxE];   // target row of a slot, -1 = not a valid edge
   __shared__ int32_t pos_s[4][kMaxE];  // its sorted position
@@ -379,6 +390,7 @@ __global__ __launch_bounds__(256) void wide_place_kernel(Inputs in, const int32_
       int rank = 0;
       for (int e2 = 0; e2 < e; ++e2) rank += tg_s[wave][e2] == tg ? 1 : 0;
       csr[(int64_t)mol * in.E + off_s[wave][tg] + rank] = pos_s[wave][e];
+      if (deg_s[wave][tg] == 1) aggcode[rb + tg] = ~pos_s[wave][e];  // the row's only in-edge (wide_iota_kernel)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -765,6 +777,7 @@ __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restric
   if (row >= meta[kMetaEnd]) return;
   if (n_ions > 1 && row >= meta[kMetaRows] && row < meta[kMetaBase + 1]) return;  // the gap in front of ion 1
   const int2 ri = rowinfo[row];
+  if (ri.y == 1) return;  // a single in-edge: the update reads the message itself (aggcode)
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   int i = 0;
   for (; i + 4 <= ri.y; i += 4) {
@@ -791,9 +804,17 @@ __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restric
 //             Wh through the stages.
 //   epilogue  blend, LayerNorm (row sums across the four feature groups through LDS), residual.
 // h of the accumulator positions is read once into registers (for r*h, the blend and the residual).
+// first float of the aggregated messages of row `row` (aggcode, wide_iota_kernel)
+__device__ __forceinline__ const float* agg_row(const float* agg, const float* m, const int32_t* aggcode, int64_t row, int D) {
+  const int c = aggcode[row];
+  return c >= 0 ? agg + (int64_t)c * D : m + (int64_t)(~c) * D;
+}
+
 struct GuParams {
   float* h;
   const float* agg;
+  const float* m;            // messages: a row with a single in-edge reads its message instead of agg (aggcode)
+  const int32_t* aggcode;
   const float* img[2];  // the step's GatedUpdate image starts at img[g] + gu_off
   size_t gu_off;
   const int32_t* meta;
@@ -847,7 +868,7 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
   // (padding rows of the last tile of an ion lie inside the workspace; whatever they hold stays in their own rows)
   const int a_row = (tid % kAT) >> 2, a_c4 = tid & 3;
   const float* hsrc = p.h + (row0 + a_row) * D + 4 * a_c4;
-  const float* gsrc = p.agg + (row0 + a_row) * D + 4 * a_c4;
+  const float* gsrc = agg_row(p.agg, p.m, p.aggcode, row0 + a_row, D) + 4 * a_c4;
   struct Pre {
     f32x4_t av, bv[kQ1];
   };
@@ -1174,7 +1195,7 @@ __global__ __launch_bounds__(kGuX3Threads, 2) void wide_update_x3_kernel(GuParam
   // a thread's piece of a row slice: row a_row, k = 4 a_pc .. 4 a_pc + 3 of the slice's 32
   const int a_row = tid >> 3, a_pc = tid & 7;
   const float* hsrc = p.h + (row0 + a_row) * D + 4 * a_pc;
-  const float* gsrc = p.agg + (row0 + a_row) * D + 4 * a_pc;
+  const float* gsrc = agg_row(p.agg, p.m, p.aggcode, row0 + a_row, D) + 4 * a_pc;
   // unit (plane, k octet a_pc >> 1, row a_row), 8-byte half a_pc & 1
   const int a_unit = (a_pc >> 1) * R + a_row, a_half = a_pc & 1;
   auto park_rows = [&](uint4* st, f32x4_t v) {  // 4 values -> three planes of 4 bf16
@@ -1499,7 +1520,8 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
   // a thread's pieces of a row slice: rows a_row and a_row + 64, k = 4 a_pc .. 4 a_pc + 3 of the slice's 32
   const int a_row = tid >> 3, a_pc = tid & 7;
   const float* hsrc = p.h + (row0 + a_row) * D + 4 * a_pc;
-  const float* gsrc = p.agg + (row0 + a_row) * D + 4 * a_pc;
+  const float* gsrc = agg_row(p.agg, p.m, p.aggcode, row0 + a_row, D) + 4 * a_pc;
+  const float* gsrc1 = agg_row(p.agg, p.m, p.aggcode, row0 + a_row + 64, D) + 4 * a_pc;  // (the second piece's row)
   const int a_unit = (a_pc >> 1) * R + a_row, a_half = a_pc & 1;  // unit (plane, k octet a_pc >> 1, row), 8-byte half
   auto park_rows = [&](uint4* st, f32x4_t v, int piece) {  // 4 values -> three planes of 4 bf16
     unsigned w0[2], w1[2], w2[2];
@@ -1525,7 +1547,8 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
   f32x4_t pav[RP];
   auto fetch_rows1 = [&](int u) {
 #pragma unroll
-    for (int i = 0; i < RP; ++i) pav[i] = ldv4((u < NS / 2 ? hsrc : gsrc - D) + 32 * u + (size_t)64 * i * D);
+    for (int i = 0; i < RP; ++i)
+      pav[i] = u < NS / 2 ? ldv4(hsrc + 32 * u + (size_t)64 * i * D) : ldv4((i ? gsrc1 : gsrc) + 32 * (u - NS / 2));
   };
   f32x4_t z[RTW][NL], rr[RTW][NL];
 #pragma unroll
@@ -1633,7 +1656,7 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
   // ---- gates; r * h (f32) into LDS: phase 2 parks its first NS / 2 row slices from there
   auto fetch_rows2 = [&](int u) {    // (u >= NS / 2: the aggregated messages)
 #pragma unroll
-    for (int i = 0; i < RP; ++i) pav[i] = ldv4(gsrc + 32 * (u - NS / 2) + (size_t)64 * i * D);
+    for (int i = 0; i < RP; ++i) pav[i] = ldv4((i ? gsrc1 : gsrc) + 32 * (u - NS / 2));
   };
   auto park2 = [&](uint4* st, int u) {
 #pragma unroll
@@ -2074,8 +2097,9 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     wide_count_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.cnt));
     wide_scan_kernel<<<1, 1024, 0, s>>>(I(w.kept), I(w.rowbase), I(w.cnt), I(w.tstart), I(w.cursor), I(w.tilebase),
                                         I(w.srcrow), I(w.meta), a.n_ions, a.B, w.nT, te);
+    wide_iota_kernel<<<(unsigned)((w.rmax + 255) / 256), 256, 0, s>>>(I(w.aggcode), (int)w.rmax);
     wide_place_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.rowbase), I(w.cursor), I(w.srcrow),
-                                              reinterpret_cast<int2*>(base + w.rowinfo), I(w.csr));
+                                              reinterpret_cast<int2*>(base + w.rowinfo), I(w.csr), I(w.aggcode));
     if (int rc = check_launch("encoder_wide plan")) return rc;
   }
   if (!(a.phases & 2)) return IMPNN_OK;
@@ -2166,7 +2190,7 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     wide_reduce_kernel<<<(unsigned)((red_threads + 255) / 256), 256, 0, s>>>(
         F(w.m), reinterpret_cast<const int2*>(base + w.rowinfo), I(w.csr), F(w.agg), I(w.meta), a.n_ions, a.D);
     GuParams gp{};
-    gp.h = F(w.h); gp.agg = F(w.agg);
+    gp.h = F(w.h); gp.agg = F(w.agg); gp.m = F(w.m); gp.aggcode = I(w.aggcode);
     gp.img[0] = img[0]; gp.img[1] = img[1];
     gp.gu_off = step_off + (size_t)a.Vb * a.D * a.D;
     gp.meta = I(w.meta); gp.eps = a.ln_eps; gp.n_ions = a.n_ions; gp.tile_rows = tile_rows;
