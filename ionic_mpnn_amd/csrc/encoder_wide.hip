@@ -20,7 +20,8 @@
 //     S x  wide_message   m[p] = A[type_p] h[src_p]: one GEMM per type run, 64-edge tiles, the type's matrix resident
 //                         in LDS, next tile's rows in flight under the MFMAs      (a2 + a4, models/layers.py:100-117)
 //                         (mode f32x3 at D = 128: wide_message_x3 - bf16x9, matrix operands in registers)
-//          wide_reduce    agg[row] = sum of its in-edge messages, slot order      (a5)
+//          wide_reduce    agg[row] = sum of its in-edge messages, slot order      (a5); rows with ONE in-edge are
+//                         skipped: the update reads their message itself (aggcode: wide_iota + wide_place)
 //          wide_update    GatedUpdate on 64-row tiles (two workgroups per CU), [h|agg] and the gate kernels
 //                         streamed through LDS in 16-deep k slices, h updated in place (a7, models/layers.py:142-156)
 //                         (mode f32x3: wide_update_x3 on 64-row tiles, wide_update_x3b on 128-row tiles once a batch
