@@ -121,6 +121,61 @@ __global__ void bond_type_matrices_kernel(const float* __restrict__ tb, const fl
   }
 }
 
+// The same for GEMM-shaped bond_dim (K = D^2 = 1024 of train_melting_point.py:146): out (Vb x DD) = Tb (Vb x K) W (K x DD)
+// on v_mfma_f32_16x16x4_f32 (exact f32 products).  One 256-thread workgroup per 16 output columns; its four waves split
+// K and meet in LDS in wave order (a fixed summation order: bitwise reproducible); a lane's four k of a 16-k block are
+// consecutive (one 16-byte load of its Tb row), the MFMA step s takes component s of every lane - A and B agree on that
+// order, which is all a dot product asks.  VT = 16-row tiles of the vocabulary (Vb <= 16 VT).
+template <int VT>
+__global__ __launch_bounds__(256) void bond_type_matrices_mfma_kernel(const float* __restrict__ tb, const float* __restrict__ W,
+                                                                      float* __restrict__ out, int Vb, int K, int DD) {
+  __shared__ f32x4_t part[3][VT][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, a = lane & 15, q = lane >> 4;
+  const int j0 = blockIdx.x * 16;
+  const int kw = K >> 2, k_lo = wave * kw;  // this wave's quarter of K (a multiple of 16: launch_bond_type_matrices)
+  f32x4_t acc[VT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) acc[vt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const float* arow[VT];
+#pragma unroll
+  for (int vt = 0; vt < VT; ++vt) {
+    const int v = 16 * vt + a;
+    arow[vt] = tb + (int64_t)(v < Vb ? v : Vb - 1) * K + 4 * q;  // (rows past the vocabulary: multiplied, never stored)
+  }
+  const float* bcol = W + (int64_t)(4 * q) * DD + j0 + a;
+  for (int k0 = k_lo; k0 < k_lo + kw; k0 += 16) {
+    f32x4_t av[VT];
+    float bv[4];
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) av[vt] = *reinterpret_cast<const f32x4_t*>(arow[vt] + k0);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) bv[s4] = bcol[(int64_t)(k0 + s4) * DD];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int vt = 0; vt < VT; ++vt) acc[vt] = mfma_f32(av[vt][s4], bv[s4], acc[vt]);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) part[wave - 1][vt][lane] = acc[vt];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int vt = 0; vt < VT; ++vt) {
+      f32x4_t r = acc[vt];
+      r += part[0][vt][lane];
+      r += part[1][vt][lane];
+      r += part[2][vt][lane];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int v = 16 * vt + 4 * q + i;
+        if (v < Vb) out[(int64_t)v * DD + j0 + a] = r[i];
+      }
+    }
+  }
+}
+
 // a4 from bond ids: m[b,e,:] = A[bond_ids[b,e]] @ h[b,src,:], masked like models/layers.py:114-115
 __global__ void bmm_message_typed_kernel(const float* __restrict__ h, const int32_t* __restrict__ bond_ids,
                                          const int32_t* __restrict__ conn, const float* __restrict__ A,
@@ -1173,8 +1228,18 @@ int launch_bmm_message(const float* h, const float* bs, const int32_t* conn, con
 int launch_bond_type_matrices(const float* tb, const float* W, float* out, int Vb, int K, int D,
                               hipStream_t s) {
   const int DD = D * D;
-  if (K >= 64)  // K = D*D (train_melting_point.py:146): a real GEMM, out (Vb x DD) = Tb (Vb x K) W (K x DD)
+  if (K >= 64) {  // K = D*D (train_melting_point.py:146): a real GEMM, out (Vb x DD) = Tb (Vb x K) W (K x DD)
+    const bool al = (reinterpret_cast<uintptr_t>(tb) & 15u) == 0;
+    if (K % 64 == 0 && DD % 16 == 0 && Vb >= 1 && Vb <= 128 && al) {  // 79 -> ~10 us at Vb = 72, K = DD = 1024
+      const int vt = (Vb + 15) / 16;
+      const dim3 grid(DD / 16);
+      if (vt <= 2) bond_type_matrices_mfma_kernel<2><<<grid, 256, 0, s>>>(tb, W, out, Vb, K, DD);
+      else if (vt <= 5) bond_type_matrices_mfma_kernel<5><<<grid, 256, 0, s>>>(tb, W, out, Vb, K, DD);
+      else bond_type_matrices_mfma_kernel<8><<<grid, 256, 0, s>>>(tb, W, out, Vb, K, DD);
+      return check_launch("bond_type_matrices_mfma");
+    }
     return launch_strided_gemm(tb, W, out, K, Vb, DD, 1, K, DD, 1, s);
+  }
   dim3 grid((DD + kBlock - 1) / kBlock, Vb);
   bond_type_matrices_kernel<<<grid, kBlock, 0, s>>>(tb, W, out, Vb, K, DD);
   return check_launch("bond_type_matrices");
