@@ -89,12 +89,17 @@ constexpr int kTRecGrp = 3712;       // uint4[tgrp_cap(Vb)]: x = type | edges <<
                                      //   y = 4 x u8 placed source row, z/w = 4 x u16 message key (tmsg_key of the edge's
                                      //   slot; the dump slot for unused lanes); in type order
 // A chunk holds <= ecap edges of <= Vb types: at most ecap/4 full groups plus one partial group per type.  The run
-// table (u16[Vb + 2]: first group of every type run, + end) follows the group table, so a record's used bytes - and the
-// LDS the encoder spends on it - depend on the bond vocabulary: 7.1 KB at Vb = 72, 12 KB at Vb = 256.
+// table (u16: first group of every run, + end) follows the group table, so a record's used bytes - and the LDS the
+// encoder spends on it - depend on the bond vocabulary: 7.2 KB at Vb = 72, 12 KB at Vb = 256.
+// A run is what one wave of the encoder multiplies with one fetch of the type's matrix: the groups of a type, cut into
+// pieces of <= gmax = max(2, ceil(groups of the chunk / kTRunTarget)) groups, so that a chunk of FEW bond types - real
+// molecules have a handful - still gives every wave its share (uncut, a chunk of 6 types kept 6 of 16 waves busy:
+// 2.46 M pairs/s at the explicit-hydrogen shape against 3.79 M with 71 uniformly drawn types).  Runs <= types + kTRunTarget.
+constexpr int kTRunTarget = 32;
 __host__ __device__ constexpr int tgrp_cap(int Vb, int ecap) { return ecap / 4 + (Vb < kTVbMax ? Vb : kTVbMax); }
 __host__ __device__ constexpr int trec_runs_off(int Vb, int ecap) { return kTRecGrp + 16 * tgrp_cap(Vb, ecap); }
 __host__ __device__ constexpr int trec_used_bytes(int Vb, int ecap) {
-  return (trec_runs_off(Vb, ecap) + 2 * (Vb + 2) + 15) & ~15;
+  return (trec_runs_off(Vb, ecap) + 2 * (Vb + 2 + kTRunTarget) + 15) & ~15;
 }
 constexpr int kTRecBytes = 12288;    // stride of the records in the workspace
 constexpr int kTRecPart1 = 8192;     // the encoder copies a record as 8 B per thread (+ 4 B per thread beyond 8 KB)

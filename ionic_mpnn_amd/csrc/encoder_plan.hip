@@ -1041,16 +1041,23 @@ __global__ __launch_bounds__(kRCap, 4) void plan_chunks_typed_kernel(PlanParams 
     const int incl = wave_incl_scan(s4);
     const int ex = incl - s4;
     reinterpret_cast<int4*>(tgb)[lane] = make_int4(ex, ex + ng.x, ex + ng.x + ng.y, ex + ng.x + ng.y + ng.z);
-    // run table: first group of every type that has groups, in type order (+ end).  The encoder's waves take runs
-    // from it one at a time (an LDS counter), so the message phase is balanced dynamically.
-    const int r4 = (ng.x > 0) + (ng.y > 0) + (ng.z > 0) + (ng.w > 0);
+    // run table: the groups of every type that has groups, in type order, cut into runs of <= gmax groups (+ end;
+    // encoder_layout.h).  The encoder's waves take runs from it one at a time (an LDS counter), so the message phase is
+    // balanced dynamically - given enough runs.
+    const int ngrp_all = __builtin_amdgcn_readlane(incl, 63);
+    int gmax = (ngrp_all + kTRunTarget - 1) / kTRunTarget;
+    gmax = gmax < 2 ? 2 : gmax;
+    const float rgm = 1.0f / (float)gmax;
+    const int4 nr = make_int4(fast_div(ng.x + gmax - 1, gmax, rgm), fast_div(ng.y + gmax - 1, gmax, rgm),
+                              fast_div(ng.z + gmax - 1, gmax, rgm), fast_div(ng.w + gmax - 1, gmax, rgm));
+    const int r4 = nr.x + nr.y + nr.z + nr.w;
     const int rincl = wave_incl_scan(r4);
     int ri = rincl - r4;
     uint16_t* runs = reinterpret_cast<uint16_t*>(rec + trec_runs_off(p.Vb, p.ecap));
-    if (ng.x > 0) runs[ri++] = (uint16_t)ex;
-    if (ng.y > 0) runs[ri++] = (uint16_t)(ex + ng.x);
-    if (ng.z > 0) runs[ri++] = (uint16_t)(ex + ng.x + ng.y);
-    if (ng.w > 0) runs[ri++] = (uint16_t)(ex + ng.x + ng.y + ng.z);
+    for (int i = 0; i < nr.x; ++i) runs[ri++] = (uint16_t)(ex + i * gmax);
+    for (int i = 0; i < nr.y; ++i) runs[ri++] = (uint16_t)(ex + ng.x + i * gmax);
+    for (int i = 0; i < nr.z; ++i) runs[ri++] = (uint16_t)(ex + ng.x + ng.y + i * gmax);
+    for (int i = 0; i < nr.w; ++i) runs[ri++] = (uint16_t)(ex + ng.x + ng.y + ng.z + i * gmax);
     if (lane == 63) {
       runs[rincl] = (uint16_t)incl;
       *reinterpret_cast<uint16_t*>(rec + kTRecNrun) = (uint16_t)rincl;

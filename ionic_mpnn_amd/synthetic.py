@@ -81,7 +81,7 @@ def make_batch(batch, max_atoms=40, max_edges=80, atom_vocab_size=DEFAULT_VA,
     return out
 
 
-def _one_ion_explicit_h(rng, B, N, E, Va, Vb, min_atoms, max_atoms, max_degree=4):
+def _one_ion_explicit_h(rng, B, N, E, Va, Vb, min_atoms, max_atoms, max_degree=4, bond_type_probs=None):
     """Explicit-hydrogen-like molecules as the reference's trainers hand them to the model: featurize.py:45,54-63
     adds hydrogens and lists every bond in both directions; preprocess_edges_and_bonds (utils/mp_utils.py:18-45,
     train_viscosity.py:76-110) then follows every listed (src, tgt) with its reverse and repeats the bond id - FOUR
@@ -130,7 +130,12 @@ def _one_ion_explicit_h(rng, B, N, E, Va, Vb, min_atoms, max_atoms, max_degree=4
         bvalid[rows[ok], slot[ok]] = True
         deg[rows[ok], cu[ok]] += 1
         deg[rows[ok], cv[ok]] += 1
-    bid = np.where(bvalid, rng.integers(1, Vb, size=(B, nb_slots)), 0)
+    if bond_type_probs is None:
+        draw = rng.integers(1, Vb, size=(B, nb_slots))
+    else:  # a few bond types with skewed frequencies, as real molecules have (ids 1 .. len(probs))
+        pr = np.asarray(bond_type_probs, dtype=np.float64)
+        draw = 1 + rng.choice(len(pr), size=(B, nb_slots), p=pr / pr.sum())
+    bid = np.where(bvalid, draw, 0)
     bu = np.where(bvalid, bu, 0)
     bv = np.where(bvalid, bv, 0)
     # the ring slot may sit beyond a gap-free prefix only when a ring was refused: compact nothing, the reference's
@@ -145,14 +150,15 @@ def _one_ion_explicit_h(rng, B, N, E, Va, Vb, min_atoms, max_atoms, max_degree=4
 
 
 def make_explicit_h_batch(batch, max_atoms=160, max_edges=640, atom_vocab_size=DEFAULT_VA, bond_vocab_size=DEFAULT_VB,
-                          min_atoms=20, seed=0, with_temperature=True):
+                          min_atoms=20, seed=0, with_temperature=True, bond_type_probs=None):
     """As make_batch, for the padded shapes of the reference's real (explicit-hydrogen) data sets: up to `max_atoms`
-    atoms of degree <= 4, every bond in four edge slots, E = 4 * max_bonds (see _one_ion_explicit_h)."""
+    atoms of degree <= 4, every bond in four edge slots, E = 4 * max_bonds (see _one_ion_explicit_h).  Bond ids are
+    uniform over the vocabulary unless `bond_type_probs` gives the frequencies of a few types (ids 1, 2, ...)."""
     rng = np.random.default_rng(seed)
     out = {}
     for p in ("cat", "an"):
         a, b, c = _one_ion_explicit_h(rng, batch, max_atoms, max_edges, atom_vocab_size, bond_vocab_size, min_atoms,
-                                      max_atoms)
+                                      max_atoms, bond_type_probs=bond_type_probs)
         out[f"{p}_atom"], out[f"{p}_bond"], out[f"{p}_connectivity"] = a, b, c
     if with_temperature:
         out["temperature"] = rng.uniform(253.0, 393.0, size=(batch, 1)).astype(np.float32)
