@@ -658,6 +658,7 @@ int launch_encoder_phase(const EncoderArgs& a, hipStream_t s, bool plan_phase) {
   pp.header = reinterpret_cast<PlanHeader*>(base);
   pp.typed = typed ? 1 : 0;
   pp.ecap = tecap_of(a.E);
+  pp.vmin = plan_vmin(a.n_ions, a.B, vr_max_of(a.N, a.E, typed), w.nwg);
   pp.n_ions = a.n_ions; pp.B = a.B; pp.N = a.N; pp.E = a.E; pp.Va = a.Va; pp.Vb = a.Vb;
   // chunk workgroups resident at once on 256 CUs: 5 per CU (pull records, <= 96 VGPRs) or 4 (typed, <= 128 VGPRs)
   {

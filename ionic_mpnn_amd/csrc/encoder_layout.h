@@ -148,6 +148,15 @@ inline size_t typed_prepared_floats(int S, int Vb, bool x3 = false) {
 }
 
 constexpr int kShareCap = kECap;  // molecules of one share that plan_chunks resolves in LDS
+// Shares are equal in virtual rows, per ion and in proportion to the ion's rows - so where molecules are tiny (halide
+// anions: one atom, no bond) a share would hold as many molecules as rows.  Every molecule therefore counts at least
+// plan_vmin virtual rows: a share spans < 2 (all rows) / nwg + vrmax virtual rows (the ion split rounds to whole
+// workgroups), hence at most that many / vmin molecules.  Placement only: no result depends on it.
+inline int plan_vmin(int n_ions, int B, int vrmax, int nwg) {
+  const int64_t span = 2 * (int64_t)n_ions * B * vrmax / (nwg > 0 ? nwg : 1) + vrmax;
+  const int64_t v = (span + kShareCap - 2) / (kShareCap - 1);
+  return (int)(v < 1 ? 1 : (v > kRCap ? kRCap : v));
+}
 constexpr int kMaxHops = 128;     // chunks of one share (Ws::max_sub <= kMaxHops: encoder_workgroups sees to it)
 
 // chunk descriptor (int4): {first molecule, molecules, 0, rows | ion << 16}
@@ -236,6 +245,7 @@ struct PlanParams {
   int grid_sub;  // plan_chunks workgroups launched per share (<= max_sub)
   int typed;     // 1: typed records (kTRecBytes), ecap / kRCap valid edges per virtual row
   int ecap;      // typed: valid edges per chunk, tecap_of(E)
+  int vmin;      // every molecule counts at least this many virtual rows (plan_vmin): a share then holds <= kShareCap molecules
   PlanHeader* header;          // written by plan_stats block 0
   unsigned long long* stamps;  // diagnostics only: 16 words written by plan_chunks workgroup 0
 };

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * kPB) void plan_stats_kernel(PlanParams p) {
     // edges per virtual row: 4 (pull records) or ecap / 256 = 2, 2.5 (typed)
     int vr = p.typed ? tvr_of_edges(cnt < 0x100000 ? cnt : 0x100000, p.ecap) : (cnt + 3) >> 2;
     vr = vr > rmax ? vr : rmax;
-    my_vr = vr < 1 ? 1 : vr;
+    my_vr = vr < p.vmin ? p.vmin : vr;  // (>= 1; encoder_layout.h: plan_vmin)
     // a molecule that does not fit one chunk (kRCap rows / kRCap virtual rows of edges): the plan is marked as
     // overflowed (kPlanBadBit of the block's partial sum -> plan_chunks -> PlanHeader::overflow), nothing is built
     if (my_vr > kRCap) {
@@ -542,7 +542,10 @@ __device__ __forceinline__ void resolve_chain(const PlanParams& p, int j, int sl
     run += __builtin_amdgcn_readlane(incl, 63);
   }
   if (end_row < 0) end_row = run;           // ran off the end of the ion
-  nsh = nsh < kShareCap ? nsh : kShareCap;  // a share holds ~B/nwg molecules; launch_plan checks the cap
+  if (nsh > kShareCap) {  // cannot happen while every molecule counts plan_vmin virtual rows; never truncate silently
+    if (lane == 0) p.header->overflow = 1;
+    nsh = kShareCap;
+  }
   if (lane == 0) T.shst[nsh] = end_row;
   __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): shst is read back by this wave below
   CSTAMP(12);

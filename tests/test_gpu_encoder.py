@@ -123,6 +123,32 @@ def test_fused_encoder_in_degrees_around_the_plan_ticket_list(mode):
     assert_close(pa.cpu().numpy(), ra, what="an pooled")
 
 
+@pytest.mark.parametrize("B", [4096, 20000])
+@pytest.mark.parametrize("mode", ["f32t", "f32x3", "f32"])
+def test_fused_encoder_single_atom_anions(mode, B):
+    """Halide-like anions (one atom, no bond) against ordinary cations: the ions' row counts differ 25-fold, so the
+    anion's few persistent workgroups take shares of several thousand molecules each and chunks of 256 molecules."""
+    Va, Vb = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB
+    inp = synthetic.make_batch(B, seed=5)
+    inp["an_atom"][:, 1:] = 0
+    inp["an_bond"][:] = 0
+    inp["an_connectivity"][:] = 0
+    w = weights.init_weights("viscosity", Va, Vb, num_steps=3, seed=6, perturb=True)
+    idx = np.concatenate([np.arange(8), np.random.default_rng(1).choice(B, size=16, replace=False), np.arange(B - 8, B)])
+    ra = O.encode(w, "an", inp["an_atom"][idx], inp["an_bond"][idx], inp["an_connectivity"][idx], pooled_only=True)
+    rc = O.encode(w, "cat", inp["cat_atom"][idx], inp["cat_bond"][idx], inp["cat_connectivity"][idx], pooled_only=True)
+    m = make_model(w, Va, Vb, mode=mode)
+    pc, pa = m.encode_pooled(to_dev(inp), fused=True)
+    assert bool(torch.isfinite(pc).all()) and bool(torch.isfinite(pa).all())
+    assert_close(pa.cpu().numpy()[idx], ra, what="an pooled")
+    assert_close(pc.cpu().numpy()[idx], rc, what="cat pooled")
+    # every anion is the same computation on its one embedding row: equal atom ids, equal rows - everywhere in the batch
+    ids = inp["an_atom"][:, 0]
+    first = {int(v): int(np.argmax(ids == v)) for v in np.unique(ids)}
+    ref_rows = pa[torch.as_tensor([first[int(v)] for v in ids], device=pa.device)]
+    assert torch.equal(pa, ref_rows)
+
+
 def test_unsupported_shapes_fall_back_to_layered_hip():
     # melting-point model: K = D*D (train_melting_point.py:146) is outside the fused kernel
     _, inp, w, outs = load_case("tiny_melting_point")
