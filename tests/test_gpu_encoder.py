@@ -149,6 +149,25 @@ def test_fused_encoder_single_atom_anions(mode, B):
     assert torch.equal(pa, ref_rows)
 
 
+@pytest.mark.parametrize("mode", ["f32t"])
+def test_fused_encoder_explicit_hydrogen_cations_with_single_atom_anions(mode):
+    """The real data sets' padded shape (N = 160, E = 640) with few bond types and halide-like anions, batch 2048."""
+    Va, Vb, B = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, 2048
+    inp = synthetic.make_explicit_h_batch(B, seed=25, bond_type_probs=(0.6, 0.25, 0.1, 0.05))
+    inp["an_atom"][:, 1:] = 0
+    inp["an_bond"][:] = 0
+    inp["an_connectivity"][:] = 0
+    w = weights.init_weights("viscosity", Va, Vb, num_steps=3, seed=26, perturb=True)
+    idx = np.concatenate([np.arange(3), np.random.default_rng(3).choice(B, size=6, replace=False), np.arange(B - 3, B)])
+    ra = O.encode(w, "an", inp["an_atom"][idx], inp["an_bond"][idx], inp["an_connectivity"][idx], pooled_only=True)
+    rc = O.encode(w, "cat", inp["cat_atom"][idx], inp["cat_bond"][idx], inp["cat_connectivity"][idx], pooled_only=True)
+    m = make_model(w, Va, Vb, mode=mode)
+    pc, pa = m.encode_pooled(to_dev(inp), fused=True)
+    assert int(getattr(m, "overflow_fallbacks", 0)) == 0
+    assert_close(pa.cpu().numpy()[idx], ra, what="an pooled")
+    assert_close(pc.cpu().numpy()[idx], rc, what="cat pooled")
+
+
 def test_unsupported_shapes_fall_back_to_layered_hip():
     # melting-point model: K = D*D (train_melting_point.py:146) is outside the fused kernel
     _, inp, w, outs = load_case("tiny_melting_point")

@@ -374,3 +374,24 @@ def test_wide_f32x3_propagates_nan_like_f32t():
             both = fin_t & fin_x
             untouched = both & (np.abs(res["f32t"] - clean["f32t"]).max(axis=1) == 0)
             assert np.array_equal(res["f32x3"][untouched], clean["f32x3"][untouched]), (bad, key)
+
+
+@pytest.mark.parametrize("mode", WIDE_MODES)
+def test_wide_encoder_single_atom_anions(mode):
+    """Halide-like anions (one atom, no bond) beside ordinary cations at a chip-filling batch: the anion's rows are a
+    sliver of the row space (partial tiles, 16-row pieces), every anion with the same atom id must come out the same."""
+    Va, Vb, B = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, 2048
+    inp = synthetic.make_batch(B, seed=15)
+    inp["an_atom"][:, 1:] = 0
+    inp["an_bond"][:] = 0
+    inp["an_connectivity"][:] = 0
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=128, bond_dim=8, num_steps=2, seed=16, perturb=True)
+    idx = np.concatenate([np.arange(4), np.random.default_rng(2).choice(B, size=8, replace=False), np.arange(B - 4, B)])
+    rc, ra = oracle_pooled(w, {k: v[idx] for k, v in inp.items()})
+    pc, pa = make_model(w, Va, Vb, 128, mode=mode).encode_pooled(to_dev(inp), fused=True)
+    assert_close(pa.cpu().numpy()[idx], ra, what="an pooled")
+    assert_close(pc.cpu().numpy()[idx], rc, what="cat pooled")
+    ids = inp["an_atom"][:, 0]
+    first = {int(v): int(np.argmax(ids == v)) for v in np.unique(ids)}
+    ref_rows = pa[torch.as_tensor([first[int(v)] for v in ids], device=pa.device)]
+    assert torch.equal(pa, ref_rows)
