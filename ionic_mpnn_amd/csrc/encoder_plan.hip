@@ -1,16 +1,17 @@
 // Plan kernels of the fused encoder (gfx950): everything that depends on the graph batch only
 // (not on the weights) and is cheap, latency-bound, index arithmetic:
 //
-//   plan_stats   one wave per molecule: kept rows r_b, valid edges v_b -> virtual rows; one partial
-//                sum per 16 molecules
-//   plan_chunks  one 256-thread workgroup per (share, chunk slot) (8+ resident per CU, so its
-//                dependent loads overlap).  The rows of the batch are dealt to `nwg` persistent
-//                encoder workgroups in equal contiguous shares (per ion, proportional to its rows);
-//                the workgroup resolves its share from the partial sums, the share's molecules and
-//                its next-fit chain of chunks (<= 256 rows / <= 1024 edges), then builds its chunk: in-degrees,
-//                placement of rows by descending in-degree, CSR of in-edges in edge-slot order,
-//                pool map -> one 8 KB chunk record in HBM
-//   weight_image canonical weights -> the encoder's LDS image (weights only; run when they change)
+//   plan_stats          one wave per molecule: kept rows r_b, valid edges v_b -> virtual rows (>= plan_vmin); one
+//                       partial sum per 16 molecules
+//   plan_chunks[_typed] one 256-thread workgroup per (share, chunk slot) (4-5 resident per CU, so their dependent loads
+//                       overlap).  The rows of the batch are dealt to `nwg` persistent encoder workgroups in equal
+//                       contiguous shares (per ion, proportional to its rows); one wave resolves the share from the
+//                       partial sums, the share's molecules and its next-fit chain of chunks (resolve_chain), then the
+//                       workgroup builds its chunk's record in HBM:
+//                         pull form (modes 0 / 1): rows placed by in-degree class, CSR of in-edges in edge-slot order
+//                         typed (modes 2 / 3): rows placed by exact in-degree, jagged-diagonal message slots, edges
+//                         grouped by bond type in groups of 4 and runs of a few groups (the comment at the kernel)
+//   weight_image / typed_image   canonical weights -> the encoder's LDS images (weights only; run when they change)
 #include "encoder_layout.h"
 
 namespace impnn {
