@@ -108,7 +108,7 @@ constexpr size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // workspace
 // ------------------------------------------------------------------------------------------------------------
 struct Ws {
-  size_t meta, kept, rowbase, cnt, tstart, tilebase, cursor, srcrow, rowinfo, csr, aggcode, h, agg, m, img, total;
+  size_t meta, kept, rowbase, cnt, tstart, tilebase, cursor, srcrow, rowinfo, csr, aggcode, aggc2, h, agg, m, img, total;
   int64_t rmax, vmax;
   int nT;
 };
@@ -150,8 +150,9 @@ inline Ws ws_layout(int n_ions, int B, int N, int E, int D, int S, int Vb, bool 
   w.rowinfo = take((size_t)w.rmax * 8);
   w.csr = take((size_t)w.vmax * 4);
   w.aggcode = take((size_t)w.rmax * 4);
+  w.aggc2 = take((size_t)w.rmax * 8);  // two sources per row (wide_iota_kernel)
   w.h = take((size_t)w.rmax * D * 4);
-  w.agg = take((size_t)w.rmax * D * 4);
+  w.agg = take((size_t)(w.rmax + 1) * D * 4);  // + a row of zeros at index rmax
   w.m = take((size_t)w.vmax * D * 4);
   w.img = take((size_t)n_ions * prepared_bytes(D, S, Vb, x3));
   w.total = o;
@@ -180,9 +181,18 @@ __device__ __forceinline__ int valid_type(const int32_t* conn, const int32_t* bo
 // wide_reduce) or, for a row with exactly ONE in-edge, ~position of that edge's message in `m` (the sum of one message is
 // the message: wide_reduce skips such rows - half of the atoms of a tree, every hydrogen of an explicit-hydrogen
 // molecule - and neither reads nor writes their 512 bytes).  Identity here, single in-edges from wide_place.
-__global__ void wide_iota_kernel(int32_t* __restrict__ p, int n) {
+// The 128-row update (wide_update_x3b) adds TWO sources per row, c2a + c2b: a row with two in-edges names both messages
+// (first slot first: the Reduce's order), a row with none names the row of zeros at index n of `agg` twice, every other
+// row its single source and the zeros - wide_reduce then only sums rows with three in-edges and more.
+__global__ void wide_iota_kernel(int32_t* __restrict__ aggcode, int32_t* __restrict__ c2a, int32_t* __restrict__ c2b,
+                                 float* __restrict__ agg, int n, int D) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = i;
+  if (i < n) {
+    aggcode[i] = i;
+    c2a[i] = i;
+    c2b[i] = n;
+  }
+  if (i < D) agg[(int64_t)n * D + i] = 0.f;
 }
 
 __global__ void wide_zero_kernel(int32_t* __restrict__ p, int n) {
@@ -318,7 +328,8 @@ __global__ __launch_bounds__(256) void wide_place_kernel(Inputs in, const int32_
                                                          const int32_t* __restrict__ rowbase,
                                                          int32_t* __restrict__ cursor, int32_t* __restrict__ srcrow,
                                                          int2* __restrict__ rowinfo, int32_t* __restrict__ csr,
-                                                         int32_t* __restrict__ aggcode) {
+                                                         int32_t* __restrict__ aggcode, int32_t* __restrict__ c2a,
+                                                         int32_t* __restrict__ c2b, int zero_row) {
   __shared__ int32_t lh[2 * kMaxVb];
   __shared__ int16_t tg_s[4][kMaxE];   // target row of a slot, -1 = not a valid edge
   __shared__ int32_t pos_s[4][kMaxE];  // its sorted position
@@ -379,6 +390,7 @@ __global__ __launch_bounds__(256) void wide_place_kernel(Inputs in, const int32_
       if (n < r) {
         off_s[wave][n] = run + inc - d;
         rowinfo[rb + n] = make_int2((int)((int64_t)mol * in.E) + run + inc - d, d);
+        if (d == 0) c2a[rb + n] = zero_row;  // nothing to add
       }
       run += __shfl(inc, 63);
     }
@@ -391,7 +403,9 @@ __global__ __launch_bounds__(256) void wide_place_kernel(Inputs in, const int32_
       int rank = 0;
       for (int e2 = 0; e2 < e; ++e2) rank += tg_s[wave][e2] == tg ? 1 : 0;
       csr[(int64_t)mol * in.E + off_s[wave][tg] + rank] = pos_s[wave][e];
-      if (deg_s[wave][tg] == 1) aggcode[rb + tg] = ~pos_s[wave][e];  // the row's only in-edge (wide_iota_kernel)
+      const int dg = deg_s[wave][tg];  // (wide_iota_kernel: the sources of rows with one or two in-edges)
+      if (dg == 1) aggcode[rb + tg] = ~pos_s[wave][e];
+      if (dg <= 2) (rank == 0 ? c2a : c2b)[rb + tg] = ~pos_s[wave][e];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -770,7 +784,7 @@ __global__ __launch_bounds__(kMsgX3Threads, 1) void wide_message_x3_kernel(MsgPa
 // a5 on the compact rows: D/4 lanes per row, the in-edge messages added in edge-slot order with 4 rows in flight.
 __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restrict__ m, const int2* __restrict__ rowinfo,
                                                           const int32_t* __restrict__ csr, float* __restrict__ agg,
-                                                          const int32_t* __restrict__ meta, int n_ions, int D) {
+                                                          const int32_t* __restrict__ meta, int n_ions, int D, int two_src) {
   const int qd = D >> 2;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = t / qd;
@@ -779,6 +793,7 @@ __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restric
   if (n_ions > 1 && row >= meta[kMetaRows] && row < meta[kMetaBase + 1]) return;  // the gap in front of ion 1
   const int2 ri = rowinfo[row];
   if (ri.y == 1) return;  // a single in-edge: the update reads the message itself (aggcode)
+  if (two_src && ri.y <= 2) return;  // the 128-row update adds two messages itself, and zeros for a row without in-edges
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   int i = 0;
   for (; i + 4 <= ri.y; i += 4) {
@@ -816,6 +831,9 @@ struct GuParams {
   const float* agg;
   const float* m;            // messages: a row with a single in-edge reads its message instead of agg (aggcode)
   const int32_t* aggcode;
+  const int32_t* c2a;        // wide_update_x3b: two sources per row (wide_iota_kernel)
+  const int32_t* c2b;
+  int m_off;                 // floats from agg to m (both in one workspace; the launch checks the range)
   const float* img[2];  // the step's GatedUpdate image starts at img[g] + gu_off
   size_t gu_off;
   const int32_t* meta;
@@ -1521,8 +1539,15 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
   // a thread's pieces of a row slice: rows a_row and a_row + 64, k = 4 a_pc .. 4 a_pc + 3 of the slice's 32
   const int a_row = tid >> 3, a_pc = tid & 7;
   const float* hsrc = p.h + (row0 + a_row) * D + 4 * a_pc;
-  const float* gsrc = agg_row(p.agg, p.m, p.aggcode, row0 + a_row, D) + 4 * a_pc;
-  const float* gsrc1 = agg_row(p.agg, p.m, p.aggcode, row0 + a_row + 64, D) + 4 * a_pc;  // (the second piece's row)
+  // the aggregated messages of the thread's two rows: two sources each (wide_iota_kernel), as float offsets from p.agg
+  int goff[RP][2];
+#pragma unroll
+  for (int i = 0; i < RP; ++i) {
+    const int ca = p.c2a[row0 + a_row + 64 * i], cb = p.c2b[row0 + a_row + 64 * i];
+    goff[i][0] = (ca >= 0 ? ca * D : p.m_off + (~ca) * D) + 4 * a_pc;
+    goff[i][1] = (cb >= 0 ? cb * D : p.m_off + (~cb) * D) + 4 * a_pc;
+  }
+  f32x4_t pavb[RP];  // the second source's piece (added when the slice is parked)
   const int a_unit = (a_pc >> 1) * R + a_row, a_half = a_pc & 1;  // unit (plane, k octet a_pc >> 1, row), 8-byte half
   auto park_rows = [&](uint4* st, f32x4_t v, int piece) {  // 4 values -> three planes of 4 bf16
     unsigned w0[2], w1[2], w2[2];
@@ -1548,8 +1573,14 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
   f32x4_t pav[RP];
   auto fetch_rows1 = [&](int u) {
 #pragma unroll
-    for (int i = 0; i < RP; ++i)
-      pav[i] = u < NS / 2 ? ldv4(hsrc + 32 * u + (size_t)64 * i * D) : ldv4((i ? gsrc1 : gsrc) + 32 * (u - NS / 2));
+    for (int i = 0; i < RP; ++i) {
+      if (u < NS / 2) {
+        pav[i] = ldv4(hsrc + 32 * u + (size_t)64 * i * D);
+      } else {
+        pav[i] = ldv4(p.agg + goff[i][0] + 32 * (u - NS / 2));
+        pavb[i] = ldv4(p.agg + goff[i][1] + 32 * (u - NS / 2));
+      }
+    }
   };
   f32x4_t z[RTW][NL], rr[RTW][NL];
 #pragma unroll
@@ -1604,8 +1635,9 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
       // Row tile 0 shares its scheduling region with the split of slice u + 1's rows (in the staging registers since the
       // last slice) and their LDS stores: vector instructions issue between the MFMAs of the bf16 pipe for free.
       if (rt == 0 && u + 1 < NS) {
-        park_rows(oth, pav[0], 0);
-        if (!MINI) park_rows(oth, pav[1], 1);
+        // (the slices of the aggregated messages: the row's two sources are added here - first slot first)
+        park_rows(oth, u + 1 >= NS / 2 ? pav[0] + pavb[0] : pav[0], 0);
+        if (!MINI) park_rows(oth, u + 1 >= NS / 2 ? pav[1] + pavb[1] : pav[1], 1);
       }
       if (active(rt)) {
 #pragma unroll
@@ -1657,12 +1689,15 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
   // ---- gates; r * h (f32) into LDS: phase 2 parks its first NS / 2 row slices from there
   auto fetch_rows2 = [&](int u) {    // (u >= NS / 2: the aggregated messages)
 #pragma unroll
-    for (int i = 0; i < RP; ++i) pav[i] = ldv4((i ? gsrc1 : gsrc) + 32 * (u - NS / 2));
+    for (int i = 0; i < RP; ++i) {
+      pav[i] = ldv4(p.agg + goff[i][0] + 32 * (u - NS / 2));
+      pavb[i] = ldv4(p.agg + goff[i][1] + 32 * (u - NS / 2));
+    }
   };
   auto park2 = [&](uint4* st, int u) {
 #pragma unroll
     for (int i = 0; i < (MINI ? 1 : RP); ++i)
-      park_rows(st, u < NS / 2 ? ldv4(rhs + (a_row + 64 * i) * LDR + 32 * u + 4 * a_pc) : pav[i], i);
+      park_rows(st, u < NS / 2 ? ldv4(rhs + (a_row + 64 * i) * LDR + 32 * u + 4 * a_pc) : pav[i] + pavb[i], i);
   };
   // (every wave is past the last barrier of phase 1: the stages are free)
 #pragma unroll
@@ -2098,9 +2133,11 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     wide_count_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.cnt));
     wide_scan_kernel<<<1, 1024, 0, s>>>(I(w.kept), I(w.rowbase), I(w.cnt), I(w.tstart), I(w.cursor), I(w.tilebase),
                                         I(w.srcrow), I(w.meta), a.n_ions, a.B, w.nT, te);
-    wide_iota_kernel<<<(unsigned)((w.rmax + 255) / 256), 256, 0, s>>>(I(w.aggcode), (int)w.rmax);
+    wide_iota_kernel<<<(unsigned)((w.rmax + 255) / 256), 256, 0, s>>>(I(w.aggcode), I(w.aggc2), I(w.aggc2) + w.rmax,
+                                                                      F(w.agg), (int)w.rmax, a.D);
     wide_place_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.rowbase), I(w.cursor), I(w.srcrow),
-                                              reinterpret_cast<int2*>(base + w.rowinfo), I(w.csr), I(w.aggcode));
+                                              reinterpret_cast<int2*>(base + w.rowinfo), I(w.csr), I(w.aggcode),
+                                              I(w.aggc2), I(w.aggc2) + w.rmax, (int)w.rmax);
     if (int rc = check_launch("encoder_wide plan")) return rc;
   }
   if (!(a.phases & 2)) return IMPNN_OK;
@@ -2159,6 +2196,7 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   const int gu_grid = (int)(w.rmax / tile_rows);
   // mode 3: 128-row tiles once they fill the chip at one workgroup per CU (two rounds and more)
   bool big_tiles = x3 && tile_rows == R && (int64_t)mols * a.N >= (int64_t)2 * cus * kRT3;
+  const int64_t m_off = (int64_t)((w.m - w.agg) / 4);
   {
     static const int env_big = [] {
       const char* e = getenv("IMPNN_WIDE_X3_BIG");
@@ -2166,6 +2204,9 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     }();
     if (env_big >= 0) big_tiles = x3 && env_big != 0;
   }
+  // (the 128-row kernel addresses a row's two message sources as 32-bit float offsets from `agg`)
+  if (m_off + (int64_t)w.vmax * a.D >= ((int64_t)1 << 31)) big_tiles = false;
+  const bool two_src = big_tiles;  // wide_reduce leaves rows with <= 2 in-edges to wide_update_x3b
   unsigned long long* stamps = nullptr;  // [gu_grid x 8 | cus x 8] words, the last step's launches win
   {
     size_t sb = 0;
@@ -2189,9 +2230,11 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
       else wide_message_kernel<4, 128><<<cus, 1024, msg_lds, s>>>(mp);
     }
     wide_reduce_kernel<<<(unsigned)((red_threads + 255) / 256), 256, 0, s>>>(
-        F(w.m), reinterpret_cast<const int2*>(base + w.rowinfo), I(w.csr), F(w.agg), I(w.meta), a.n_ions, a.D);
+        F(w.m), reinterpret_cast<const int2*>(base + w.rowinfo), I(w.csr), F(w.agg), I(w.meta), a.n_ions, a.D,
+        two_src ? 1 : 0);
     GuParams gp{};
     gp.h = F(w.h); gp.agg = F(w.agg); gp.m = F(w.m); gp.aggcode = I(w.aggcode);
+    gp.c2a = I(w.aggc2); gp.c2b = I(w.aggc2) + w.rmax; gp.m_off = (int)m_off;
     gp.img[0] = img[0]; gp.img[1] = img[1];
     gp.gu_off = step_off + (size_t)a.Vb * a.D * a.D;
     gp.meta = I(w.meta); gp.eps = a.ln_eps; gp.n_ions = a.n_ions; gp.tile_rows = tile_rows;
