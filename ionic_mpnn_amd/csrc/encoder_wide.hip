@@ -20,8 +20,8 @@
 //     S x  wide_message   m[p] = A[type_p] h[src_p]: one GEMM per type run, 64-edge tiles, the type's matrix resident
 //                         in LDS, next tile's rows in flight under the MFMAs      (a2 + a4, models/layers.py:100-117)
 //                         (mode f32x3 at D = 128: wide_message_x3 - bf16x9, matrix operands in registers)
-//          wide_reduce    agg[row] = sum of its in-edge messages, slot order      (a5); rows with ONE in-edge are
-//                         skipped: the update reads their message itself (aggcode: wide_iota + wide_place)
+//          wide_reduce    agg[row] = sum of its in-edge messages, slot order      (a5); rows with <= 2 in-edges are
+//                         left to the update, which adds up to two messages itself (wide_iota + wide_place)
 //          wide_update    GatedUpdate on 64-row tiles (two workgroups per CU), [h|agg] and the gate kernels
 //                         streamed through LDS in 16-deep k slices, h updated in place (a7, models/layers.py:142-156)
 //                         (mode f32x3: wide_update_x3 on 64-row tiles, wide_update_x3b on 128-row tiles once a batch
@@ -108,7 +108,7 @@ constexpr size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // workspace
 // ------------------------------------------------------------------------------------------------------------
 struct Ws {
-  size_t meta, kept, rowbase, cnt, tstart, tilebase, cursor, srcrow, rowinfo, csr, aggcode, aggc2, h, agg, m, img, total;
+  size_t meta, kept, rowbase, cnt, tstart, tilebase, cursor, srcrow, rowinfo, csr, aggc2, h, agg, m, img, total;
   int64_t rmax, vmax;
   int nT;
 };
@@ -149,7 +149,6 @@ inline Ws ws_layout(int n_ions, int B, int N, int E, int D, int S, int Vb, bool 
   w.srcrow = take((size_t)w.vmax * 4);
   w.rowinfo = take((size_t)w.rmax * 8);
   w.csr = take((size_t)w.vmax * 4);
-  w.aggcode = take((size_t)w.rmax * 4);
   w.aggc2 = take((size_t)w.rmax * 8);  // two sources per row (wide_iota_kernel)
   w.h = take((size_t)w.rmax * D * 4);
   w.agg = take((size_t)(w.rmax + 1) * D * 4);  // + a row of zeros at index rmax
@@ -177,18 +176,17 @@ __device__ __forceinline__ int valid_type(const int32_t* conn, const int32_t* bo
 // ------------------------------------------------------------------------------------------------------------
 // plan kernels
 // ------------------------------------------------------------------------------------------------------------
-// aggcode[row]: where the GatedUpdate finds the row's aggregated messages - the row itself (in `agg`, written by
-// wide_reduce) or, for a row with exactly ONE in-edge, ~position of that edge's message in `m` (the sum of one message is
-// the message: wide_reduce skips such rows - half of the atoms of a tree, every hydrogen of an explicit-hydrogen
-// molecule - and neither reads nor writes their 512 bytes).  Identity here, single in-edges from wide_place.
-// The 128-row update (wide_update_x3b) adds TWO sources per row, c2a + c2b: a row with two in-edges names both messages
-// (first slot first: the Reduce's order), a row with none names the row of zeros at index n of `agg` twice, every other
-// row its single source and the zeros - wide_reduce then only sums rows with three in-edges and more.
-__global__ void wide_iota_kernel(int32_t* __restrict__ aggcode, int32_t* __restrict__ c2a, int32_t* __restrict__ c2b,
-                                 float* __restrict__ agg, int n, int D) {
+// Where the GatedUpdate finds a row's aggregated messages: TWO sources per row, c2a[row] + c2b[row] (added where the
+// update parks the slice, first slot first: the Reduce's order).  A source is a row of `agg` (code >= 0) or ~position of
+// a message in `m`.  A row with one in-edge names that message and the row of zeros at index n of `agg`; a row with two
+// names both messages; a row with none the zeros twice; every other row itself (written by wide_reduce) and the zeros.
+// wide_reduce then only sums rows with three in-edges and more - the leaves of a tree, every hydrogen of an
+// explicit-hydrogen molecule, every chain atom cost neither a read nor a write of an aggregated copy.
+// Defaults here, rows with <= 2 in-edges from wide_place.
+__global__ void wide_iota_kernel(int32_t* __restrict__ c2a, int32_t* __restrict__ c2b, float* __restrict__ agg, int n,
+                                 int D) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    aggcode[i] = i;
     c2a[i] = i;
     c2b[i] = n;
   }
@@ -328,8 +326,8 @@ __global__ __launch_bounds__(256) void wide_place_kernel(Inputs in, const int32_
                                                          const int32_t* __restrict__ rowbase,
                                                          int32_t* __restrict__ cursor, int32_t* __restrict__ srcrow,
                                                          int2* __restrict__ rowinfo, int32_t* __restrict__ csr,
-                                                         int32_t* __restrict__ aggcode, int32_t* __restrict__ c2a,
-                                                         int32_t* __restrict__ c2b, int zero_row) {
+                                                         int32_t* __restrict__ c2a,
+                                                         int32_t* __restrict__ c2b, int zero_row, int direct_ok) {
   __shared__ int32_t lh[2 * kMaxVb];
   __shared__ int16_t tg_s[4][kMaxE];   // target row of a slot, -1 = not a valid edge
   __shared__ int32_t pos_s[4][kMaxE];  // its sorted position
@@ -404,8 +402,7 @@ __global__ __launch_bounds__(256) void wide_place_kernel(Inputs in, const int32_
       for (int e2 = 0; e2 < e; ++e2) rank += tg_s[wave][e2] == tg ? 1 : 0;
       csr[(int64_t)mol * in.E + off_s[wave][tg] + rank] = pos_s[wave][e];
       const int dg = deg_s[wave][tg];  // (wide_iota_kernel: the sources of rows with one or two in-edges)
-      if (dg == 1) aggcode[rb + tg] = ~pos_s[wave][e];
-      if (dg <= 2) (rank == 0 ? c2a : c2b)[rb + tg] = ~pos_s[wave][e];
+      if (dg <= 2 && direct_ok) (rank == 0 ? c2a : c2b)[rb + tg] = ~pos_s[wave][e];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -784,7 +781,7 @@ __global__ __launch_bounds__(kMsgX3Threads, 1) void wide_message_x3_kernel(MsgPa
 // a5 on the compact rows: D/4 lanes per row, the in-edge messages added in edge-slot order with 4 rows in flight.
 __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restrict__ m, const int2* __restrict__ rowinfo,
                                                           const int32_t* __restrict__ csr, float* __restrict__ agg,
-                                                          const int32_t* __restrict__ meta, int n_ions, int D, int two_src) {
+                                                          const int32_t* __restrict__ meta, int n_ions, int D, int skip_upto) {
   const int qd = D >> 2;
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t row = t / qd;
@@ -792,8 +789,7 @@ __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restric
   if (row >= meta[kMetaEnd]) return;
   if (n_ions > 1 && row >= meta[kMetaRows] && row < meta[kMetaBase + 1]) return;  // the gap in front of ion 1
   const int2 ri = rowinfo[row];
-  if (ri.y == 1) return;  // a single in-edge: the update reads the message itself (aggcode)
-  if (two_src && ri.y <= 2) return;  // the 128-row update adds two messages itself, and zeros for a row without in-edges
+  if (ri.y <= skip_upto) return;  // the update adds up to two messages itself, and zeros for a row without in-edges (wide_iota_kernel)
   f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   int i = 0;
   for (; i + 4 <= ri.y; i += 4) {
@@ -820,18 +816,13 @@ __global__ __launch_bounds__(256) void wide_reduce_kernel(const float* __restric
 //             Wh through the stages.
 //   epilogue  blend, LayerNorm (row sums across the four feature groups through LDS), residual.
 // h of the accumulator positions is read once into registers (for r*h, the blend and the residual).
-// first float of the aggregated messages of row `row` (aggcode, wide_iota_kernel)
-__device__ __forceinline__ const float* agg_row(const float* agg, const float* m, const int32_t* aggcode, int64_t row, int D) {
-  const int c = aggcode[row];
-  return c >= 0 ? agg + (int64_t)c * D : m + (int64_t)(~c) * D;
-}
+// float offset from `agg` of a source of aggregated messages (wide_iota_kernel): a row of agg, or ~position of a message
+__device__ __forceinline__ int agg_off(int code, int m_off, int D) { return code >= 0 ? code * D : m_off + (~code) * D; }
 
 struct GuParams {
   float* h;
   const float* agg;
-  const float* m;            // messages: a row with a single in-edge reads its message instead of agg (aggcode)
-  const int32_t* aggcode;
-  const int32_t* c2a;        // wide_update_x3b: two sources per row (wide_iota_kernel)
+  const int32_t* c2a;        // two sources of aggregated messages per row (wide_iota_kernel)
   const int32_t* c2b;
   int m_off;                 // floats from agg to m (both in one workspace; the launch checks the range)
   const float* img[2];  // the step's GatedUpdate image starts at img[g] + gu_off
@@ -887,9 +878,11 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
   // (padding rows of the last tile of an ion lie inside the workspace; whatever they hold stays in their own rows)
   const int a_row = (tid % kAT) >> 2, a_c4 = tid & 3;
   const float* hsrc = p.h + (row0 + a_row) * D + 4 * a_c4;
-  const float* gsrc = agg_row(p.agg, p.m, p.aggcode, row0 + a_row, D) + 4 * a_c4;
+  // the row's aggregated messages: two sources (wide_iota_kernel), as float offsets from p.agg
+  const int goff0 = agg_off(p.c2a[row0 + a_row], p.m_off, D) + 4 * a_c4, goff1 = agg_off(p.c2b[row0 + a_row], p.m_off, D) + 4 * a_c4;
+  const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
   struct Pre {
-    f32x4_t av, bv[kQ1];
+    f32x4_t av, aw, bv[kQ1];  // aw: the second source of a slice of aggregated messages (zeros for a slice of h)
   };
   Pre preA, preB;
   auto fetch1 = [&](int u, Pre& pre) {
@@ -897,16 +890,24 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
     for (int i = 0; i < kQ1; ++i)
       if (tid + kGuThreads * i < B1 / 4) pre.bv[i] = ldv4(P1 + (size_t)u * B1 + (tid + kGuThreads * i) * 4);
 #ifdef IMPNN_DIAG_WIDE_NOFETCH
-    if (tid < kAT) pre.av = f32x4_t{0.25f, 0.5f, -0.25f, 0.125f};
+    if (tid < kAT) { pre.av = f32x4_t{0.25f, 0.5f, -0.25f, 0.125f}; pre.aw = zero4; }
 #else
-    if (tid < kAT) pre.av = ldv4((u < NT ? hsrc : gsrc - D) + 16 * u);
+    if (tid < kAT) {
+      if (u < NT) {  // (workgroup-uniform)
+        pre.av = ldv4(hsrc + 16 * u);
+        pre.aw = zero4;
+      } else {
+        pre.av = ldv4(p.agg + goff0 + 16 * (u - NT));
+        pre.aw = ldv4(p.agg + goff1 + 16 * (u - NT));
+      }
+    }
 #endif
   };
   auto park1 = [&](float* st, const Pre& pre) {
 #pragma unroll
     for (int i = 0; i < kQ1; ++i)
       if (tid + kGuThreads * i < B1 / 4) stv4(st + A1 + (tid + kGuThreads * i) * 4, pre.bv[i]);
-    if (tid < kAT) stv4(st + (a_c4 * R + a_row) * 4, pre.av);
+    if (tid < kAT) stv4(st + (a_c4 * R + a_row) * 4, pre.av + pre.aw);  // (first slot first: the Reduce's order)
   };
   f32x4_t z[2][NL], rr[2][NL];
 #pragma unroll
@@ -986,7 +987,7 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
   WIDE_STAMP(p.stamps, 2);
   // ---- phase 2
   struct Pre2 {
-    f32x4_t av, bv[kQ2];
+    f32x4_t av, aw, bv[kQ2];
   };
   Pre2 qA, qB;
   auto fetch2 = [&](int u, Pre2& pre) {
@@ -994,16 +995,19 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
     for (int i = 0; i < kQ2; ++i)
       if (tid + kGuThreads * i < B2 / 4) pre.bv[i] = ldv4(P2 + (size_t)u * B2 + (tid + kGuThreads * i) * 4);
 #ifdef IMPNN_DIAG_WIDE_NOFETCH
-    if (u >= NT && tid < kAT) pre.av = f32x4_t{0.25f, 0.5f, -0.25f, 0.125f};
+    if (u >= NT && tid < kAT) { pre.av = f32x4_t{0.25f, 0.5f, -0.25f, 0.125f}; pre.aw = zero4; }
 #else
-    if (u >= NT && tid < kAT) pre.av = ldv4(gsrc + 16 * (u - NT));
+    if (u >= NT && tid < kAT) {
+      pre.av = ldv4(p.agg + goff0 + 16 * (u - NT));
+      pre.aw = ldv4(p.agg + goff1 + 16 * (u - NT));
+    }
 #endif
   };
   auto park2 = [&](int u, float* st, const Pre2& pre) {
 #pragma unroll
     for (int i = 0; i < kQ2; ++i)
       if (tid + kGuThreads * i < B2 / 4) stv4(st + A1 + (tid + kGuThreads * i) * 4, pre.bv[i]);
-    if (u >= NT && tid < kAT) stv4(st + (a_c4 * R + a_row) * 4, pre.av);
+    if (u >= NT && tid < kAT) stv4(st + (a_c4 * R + a_row) * 4, pre.av + pre.aw);
   };
   fetch2(0, qA);
   fetch2(1, qB);
@@ -1214,7 +1218,8 @@ __global__ __launch_bounds__(kGuX3Threads, 2) void wide_update_x3_kernel(GuParam
   // a thread's piece of a row slice: row a_row, k = 4 a_pc .. 4 a_pc + 3 of the slice's 32
   const int a_row = tid >> 3, a_pc = tid & 7;
   const float* hsrc = p.h + (row0 + a_row) * D + 4 * a_pc;
-  const float* gsrc = agg_row(p.agg, p.m, p.aggcode, row0 + a_row, D) + 4 * a_pc;
+  // the row's aggregated messages: two sources (wide_iota_kernel), as float offsets from p.agg
+  const int goff0 = agg_off(p.c2a[row0 + a_row], p.m_off, D) + 4 * a_pc, goff1 = agg_off(p.c2b[row0 + a_row], p.m_off, D) + 4 * a_pc;
   // unit (plane, k octet a_pc >> 1, row a_row), 8-byte half a_pc & 1
   const int a_unit = (a_pc >> 1) * R + a_row, a_half = a_pc & 1;
   auto park_rows = [&](uint4* st, f32x4_t v) {  // 4 values -> three planes of 4 bf16
@@ -1235,7 +1240,8 @@ __global__ __launch_bounds__(kGuX3Threads, 2) void wide_update_x3_kernel(GuParam
 #pragma unroll
     for (int i = 0; i < kQ1; ++i)
       if (tid + kGuX3Threads * i < UB1) pre.bv[i] = P1[(size_t)u * UB1 + tid + kGuX3Threads * i];
-    pre.av = ldv4((u < NS / 2 ? hsrc : gsrc - D) + 32 * u);
+    // (a slice of aggregated messages: the row's two sources, first slot first - the Reduce's order)
+    pre.av = u < NS / 2 ? ldv4(hsrc + 32 * u) : ldv4(p.agg + goff0 + 32 * (u - NS / 2)) + ldv4(p.agg + goff1 + 32 * (u - NS / 2));
   };
   auto park1 = [&](uint4* st, const Pre& pre) {
 #pragma unroll
@@ -1350,7 +1356,7 @@ __global__ __launch_bounds__(kGuX3Threads, 2) void wide_update_x3_kernel(GuParam
 #pragma unroll
     for (int i = 0; i < kQ2; ++i)
       if (tid + kGuX3Threads * i < UB2) pre.bv[i] = P2[(size_t)u * UB2 + tid + kGuX3Threads * i];
-    if (u >= NS / 2) pre.av = ldv4(gsrc + 32 * (u - NS / 2));
+    if (u >= NS / 2) pre.av = ldv4(p.agg + goff0 + 32 * (u - NS / 2)) + ldv4(p.agg + goff1 + 32 * (u - NS / 2));
   };
   auto park2 = [&](int u, uint4* st, const Pre2& pre) {
 #pragma unroll
@@ -1544,8 +1550,8 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
 #pragma unroll
   for (int i = 0; i < RP; ++i) {
     const int ca = p.c2a[row0 + a_row + 64 * i], cb = p.c2b[row0 + a_row + 64 * i];
-    goff[i][0] = (ca >= 0 ? ca * D : p.m_off + (~ca) * D) + 4 * a_pc;
-    goff[i][1] = (cb >= 0 ? cb * D : p.m_off + (~cb) * D) + 4 * a_pc;
+    goff[i][0] = agg_off(ca, p.m_off, D) + 4 * a_pc;
+    goff[i][1] = agg_off(cb, p.m_off, D) + 4 * a_pc;
   }
   f32x4_t pavb[RP];  // the second source's piece (added when the slice is parked)
   const int a_unit = (a_pc >> 1) * R + a_row, a_half = a_pc & 1;  // unit (plane, k octet a_pc >> 1, row), 8-byte half
@@ -2133,11 +2139,12 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     wide_count_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.cnt));
     wide_scan_kernel<<<1, 1024, 0, s>>>(I(w.kept), I(w.rowbase), I(w.cnt), I(w.tstart), I(w.cursor), I(w.tilebase),
                                         I(w.srcrow), I(w.meta), a.n_ions, a.B, w.nT, te);
-    wide_iota_kernel<<<(unsigned)((w.rmax + 255) / 256), 256, 0, s>>>(I(w.aggcode), I(w.aggc2), I(w.aggc2) + w.rmax,
-                                                                      F(w.agg), (int)w.rmax, a.D);
+    const bool direct_ok = (int64_t)((w.m - w.agg) / 4) + (int64_t)w.vmax * a.D < ((int64_t)1 << 31);
+    wide_iota_kernel<<<(unsigned)((w.rmax + 255) / 256), 256, 0, s>>>(I(w.aggc2), I(w.aggc2) + w.rmax, F(w.agg),
+                                                                      (int)w.rmax, a.D);
     wide_place_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.rowbase), I(w.cursor), I(w.srcrow),
-                                              reinterpret_cast<int2*>(base + w.rowinfo), I(w.csr), I(w.aggcode),
-                                              I(w.aggc2), I(w.aggc2) + w.rmax, (int)w.rmax);
+                                              reinterpret_cast<int2*>(base + w.rowinfo), I(w.csr), I(w.aggc2),
+                                              I(w.aggc2) + w.rmax, (int)w.rmax, direct_ok ? 1 : 0);
     if (int rc = check_launch("encoder_wide plan")) return rc;
   }
   if (!(a.phases & 2)) return IMPNN_OK;
@@ -2204,9 +2211,8 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     }();
     if (env_big >= 0) big_tiles = x3 && env_big != 0;
   }
-  // (the 128-row kernel addresses a row's two message sources as 32-bit float offsets from `agg`)
-  if (m_off + (int64_t)w.vmax * a.D >= ((int64_t)1 << 31)) big_tiles = false;
-  const bool two_src = big_tiles;  // wide_reduce leaves rows with <= 2 in-edges to wide_update_x3b
+  // (the update kernels address a row's two sources as 32-bit float offsets from `agg`: batches whose message buffer
+  //  lies beyond that range - ~70 000 pairs at D = 128 - keep every row's sum in agg)
   unsigned long long* stamps = nullptr;  // [gu_grid x 8 | cus x 8] words, the last step's launches win
   {
     size_t sb = 0;
@@ -2231,9 +2237,9 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     }
     wide_reduce_kernel<<<(unsigned)((red_threads + 255) / 256), 256, 0, s>>>(
         F(w.m), reinterpret_cast<const int2*>(base + w.rowinfo), I(w.csr), F(w.agg), I(w.meta), a.n_ions, a.D,
-        two_src ? 1 : 0);
+        m_off + (int64_t)w.vmax * a.D < ((int64_t)1 << 31) ? 2 : 0);
     GuParams gp{};
-    gp.h = F(w.h); gp.agg = F(w.agg); gp.m = F(w.m); gp.aggcode = I(w.aggcode);
+    gp.h = F(w.h); gp.agg = F(w.agg);
     gp.c2a = I(w.aggc2); gp.c2b = I(w.aggc2) + w.rmax; gp.m_off = (int)m_off;
     gp.img[0] = img[0]; gp.img[1] = img[1];
     gp.gu_off = step_off + (size_t)a.Vb * a.D * a.D;
