@@ -154,13 +154,15 @@ int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, i
  *                                 time entries for that batch, as ionic_mpnn_amd.model does).  atom_dim 64 / 128 (train_viscosity.py with atom_dim=128,
  *                                 num_steps=6), N <= 256, E <= 512, Vb <= 512: the same arithmetic as a short sequence
  *                                 of launches per call on compact kept rows (per type-run GEMMs for the messages,
- *                                 slot-order sums, GatedUpdate on 128-row tiles; csrc/encoder_wide.hip); `workgroups`
+ *                                 slot-order sums, GatedUpdate on 64-row tiles; csrc/encoder_wide.hip); `workgroups`
  *                                 is ignored there.
  *    IMPNN_ENCODER_F32X3_TYPED (3): mode 2 with the GatedUpdate GEMMs on the bf16 matrix pipe: every f32 operand is carried
  *                                 EXACTLY as three bf16 terms (3 x 8 significant bits, fp32's exponent range) and all nine
  *                                 cross products are accumulated in f32 (9 x v_mfma_f32_16x16x32_bf16 per 8 f32 MFMAs):
- *                                 the products are the f32 products, only their summation order differs.  Messages
- *                                 stay on the f32 4x4x1 MFMA.  Same records, prepared buffer of its own.  Opt-in.
+ *                                 the products are the f32 products, only their summation order differs.  atom_dim 32:
+ *                                 messages stay on the f32 4x4x1 MFMA; atom_dim 128: the per-type message GEMMs run
+ *                                 the same way (atom_dim 64: exact f32 messages).  Same records, prepared buffer of
+ *                                 its own (impnn_encoder_prepared_bytes with this mode).  Opt-in.
  *  `workgroups` - persistent workgroups of the launch: 0 = default (environment IMPNN_ENCODER_WORKGROUPS if set - a
  *  process-wide diagnostics override, read ONCE at the first call - else one per compute unit), n = min(max(n, 16), CUs);
  *  a multiple of that for very large batches or padded shapes (the size query, plan and run agree on it by themselves).  It fixes the workspace layout, so the size query, the plan and
