@@ -184,18 +184,16 @@ __device__ __forceinline__ int valid_type(const int32_t* conn, const int32_t* bo
 // explicit-hydrogen molecule, every chain atom cost neither a read nor a write of an aggregated copy.
 // Defaults here, rows with <= 2 in-edges from wide_place.
 __global__ void wide_iota_kernel(int32_t* __restrict__ c2a, int32_t* __restrict__ c2b, float* __restrict__ agg, int n,
-                                 int D) {
+                                 int D, int32_t* __restrict__ zero, int nz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     c2a[i] = i;
     c2b[i] = n;
   }
   if (i < D) agg[(int64_t)n * D + i] = 0.f;
+  if (i < nz) zero[i] = 0;  // meta and the type counters (what wide_zero_kernel did in a launch of its own)
 }
 
-__global__ void wide_zero_kernel(int32_t* __restrict__ p, int n) {
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) p[t] = 0;
-}
 
 // One wave per molecule (4 in turn): kept rows, and the workgroup's histogram of valid edges by (ion, type) - counted
 // in LDS, one global atomic per type the workgroup saw.
@@ -2135,13 +2133,12 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   const int te = tile_edges(a.D);
   if (a.phases & 1) {
     const int nz = (int)((w.kept - w.meta) / 4);  // meta and the type counters
-    wide_zero_kernel<<<(nz + 255) / 256, 256, 0, s>>>(I(w.meta), nz);
+    const bool direct_ok = (int64_t)((w.m - w.agg) / 4) + (int64_t)w.vmax * a.D < ((int64_t)1 << 31);
+    wide_iota_kernel<<<(unsigned)(((w.rmax > nz ? w.rmax : nz) + 255) / 256), 256, 0, s>>>(I(w.aggc2), I(w.aggc2) + w.rmax, F(w.agg),
+        (int)w.rmax, a.D, I(w.meta), nz);
     wide_count_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.cnt));
     wide_scan_kernel<<<1, 1024, 0, s>>>(I(w.kept), I(w.rowbase), I(w.cnt), I(w.tstart), I(w.cursor), I(w.tilebase),
                                         I(w.srcrow), I(w.meta), a.n_ions, a.B, w.nT, te);
-    const bool direct_ok = (int64_t)((w.m - w.agg) / 4) + (int64_t)w.vmax * a.D < ((int64_t)1 << 31);
-    wide_iota_kernel<<<(unsigned)((w.rmax + 255) / 256), 256, 0, s>>>(I(w.aggc2), I(w.aggc2) + w.rmax, F(w.agg),
-                                                                      (int)w.rmax, a.D);
     wide_place_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.rowbase), I(w.cursor), I(w.srcrow),
                                               reinterpret_cast<int2*>(base + w.rowinfo), I(w.csr), I(w.aggc2),
                                               I(w.aggc2) + w.rmax, (int)w.rmax, direct_ok ? 1 : 0);
