@@ -59,7 +59,27 @@ __device__ __forceinline__ float fsig(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896f * x));
 }
 __device__ __forceinline__ float ftanh(float x) {
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177793f * x));
+  return fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177793f * x)), 1.0f);
+}
+// The elementwise arithmetic of the GatedUpdate, shared by every update kernel of this file with the fusion of multiply
+// and add spelled out: a batch and its shards may run different kernels (tile sizes) and must agree bit for bit, which
+// they do not if the compiler is left to contract `a * b + c` one way in one kernel and another way in the next.
+__device__ __forceinline__ float gu_rh(float r_pre, float h) {  // sigmoid(r) * h (models/layers.py:147-148)
+#pragma clang fp contract(off)
+  return fsig(r_pre) * h;
+}
+__device__ __forceinline__ float gu_blend(float z, float h, float t_pre) {  // (1 - z) h + z tanh(t) (models/layers.py:150)
+#pragma clang fp contract(off)
+  const float keep = (1.0f - z) * h;
+  return fmaf(z, ftanh(t_pre), keep);
+}
+__device__ __forceinline__ float gu_inv_std(float sq_dev_sum, float inv_d, float eps) {  // 1 / sqrt(var + eps): v_rsq_f32, 1 ulp
+  return __builtin_amdgcn_rsqf(fmaf(sq_dev_sum, inv_d, eps));
+}
+__device__ __forceinline__ float gu_out(float x, float mean, float inv, float gamma, float beta, float h) {  // LayerNorm + residual
+#pragma clang fp contract(off)
+  const float n = (x - mean) * inv;
+  return fmaf(n, gamma, beta) + h;
 }
 __device__ __forceinline__ float row16_sum_f(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, true));
@@ -414,21 +434,19 @@ __global__ __launch_bounds__(256) void wide_place_kernel(Inputs in, const int32_
 __global__ __launch_bounds__(256) void wide_embed_kernel(Inputs in, const int32_t* __restrict__ kept,
                                                          const int32_t* __restrict__ rowbase,
                                                          const float* __restrict__ table, float* __restrict__ h, int D) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int mols = in.n_ions * in.B, qd = D >> 2, rpw = 64 / qd;
-  const int sub = lane / qd, c4 = lane - sub * qd;
-  for (int i = 0; i < kMolPerWg / 4; ++i) {
-    const int mol = blockIdx.x * kMolPerWg + wave * (kMolPerWg / 4) + i;
-    if (mol >= mols) break;
-    const int g = mol >= in.B ? 1 : 0, b = mol - g * in.B;
-    const int r = kept[mol], rb = rowbase[mol];
-    const int32_t* ids = in.atom_ids[g] + (int64_t)b * in.N;
-    for (int n = sub; n < r; n += rpw) {
-      const int id = ids[n];
-      f32x4_t v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)id < (unsigned)in.Va) v = ldv4(table + (int64_t)id * D + 4 * c4);
-      stv4(h + (int64_t)(rb + n) * D + 4 * c4, v);
-    }
+  // one workgroup per molecule, D / 4 threads per row (a wave per molecule and four molecules per wave, as the plan
+  // kernels have it, left a batch of 32 pairs with 4 workgroups walking 24 rows each in turn: 23 us)
+  const int mol = blockIdx.x;
+  const int qd = D >> 2, rpw = 256 / qd;
+  const int sub = threadIdx.x / qd, c4 = threadIdx.x - sub * qd;
+  const int g = mol >= in.B ? 1 : 0, b = mol - g * in.B;
+  const int r = kept[mol], rb = rowbase[mol];
+  const int32_t* ids = in.atom_ids[g] + (int64_t)b * in.N;
+  for (int n = sub; n < r; n += rpw) {
+    const int id = ids[n];
+    f32x4_t v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)id < (unsigned)in.Va) v = ldv4(table + (int64_t)id * D + 4 * c4);
+    stv4(h + (int64_t)(rb + n) * D + 4 * c4, v);
   }
 }
 
@@ -1017,7 +1035,7 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         z[rt][TL][gq] = fsig(z[rt][TL][gq]);
-        rhs[(32 * rg + 16 * rt + 4 * q + gq) * LDR + 16 * (fg * NL + TL) + a] = fsig(rr[rt][TL][gq]) * hreg[rt][TL][gq];
+        rhs[(32 * rg + 16 * rt + 4 * q + gq) * LDR + 16 * (fg * NL + TL) + a] = gu_rh(rr[rt][TL][gq], hreg[rt][TL][gq]);
       }
   f32x4_t tt[2][NL];
 #pragma unroll
@@ -1094,7 +1112,7 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
 #pragma unroll
       for (int TL = 0; TL < NL; ++TL) {
         const float hv = hreg[rt][TL][gq];
-        const float nv = (1.0f - z[rt][TL][gq]) * hv + z[rt][TL][gq] * ftanh(tt[rt][TL][gq]);
+        const float nv = gu_blend(z[rt][TL][gq], hv, tt[rt][TL][gq]);
         tt[rt][TL][gq] = nv;
         sacc += nv;
       }
@@ -1140,7 +1158,7 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
       float vs = 0.f;
 #pragma unroll
       for (int f2 = 0; f2 < FG; ++f2) vs += part[f2 * R + rl];
-      inv[rt][gq] = __builtin_amdgcn_rsqf(vs * (1.0f / D) + p.eps);  // (v_rsq_f32: 1 ulp)
+      inv[rt][gq] = gu_inv_std(vs, 1.0f / D, p.eps);
     }
   {
     float* const out = p.h + (row0 + 32 * rg + 4 * q) * D + 16 * fg * NL + a;
@@ -1155,13 +1173,183 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
-          const float v = (tt[rt][TL][gq] - mean[rt][gq]) * inv[rt][gq] * gm + bt + hreg[rt][TL][gq];
+          const float v = gu_out(tt[rt][TL][gq], mean[rt][gq], inv[rt][gq], gm, bt, hreg[rt][TL][gq]);
           if (all_rows || row0 + 32 * rg + 16 * rt + 4 * q + gq < row_end) out[(16 * rt + gq) * D + 16 * TL] = v;
         }
     }
   }
   WIDE_STAMP(p.stamps, 4);
   WIDE_STAMP_REAL(p.stamps, 6);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// a7 for launches too small to fill the chip (16-row tiles: batches of up to ~100 pairs - model.predict at the
+// reference's batch 32).  There wide_update_kernel is a chain of 32 weight slices through LDS with a barrier each:
+// 29 us per launch whatever the rows, half of the forward's latency.  Here a 4-wave workgroup owns 16 rows, wave w the
+// features [w D/4, (w + 1) D/4) of z, r and the candidate, and every operand comes straight from global memory / L2 in
+// 16-byte pieces - the kernels in the prepared image's own order ([16-k slice][k quad][column][4 k]: a lane's four k of
+// a slice are one load, MFMA step r takes component r of both operands), the rows' h from an LDS copy, the
+// aggregated messages from their two sources - three slices ahead of the MFMAs: no staging, four barriers per tile.
+// Exact f32 (v_mfma_f32_16x16x4_f32), the products and their order per output as wide_update_kernel's.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kGuSmallThreads = 256;
+template <int NT>
+__global__ __launch_bounds__(kGuSmallThreads) void wide_update_small_kernel(GuParams p) {
+  constexpr int D = 16 * NT, NL = NT / 4, LDH = D + 4, R = 16, NS = NT;  // NS 16-k slices per D of contraction
+  static_assert(NL >= 1, "tile shape");
+  __shared__ __align__(16) float hs[R * LDH];   // h of the tile's rows
+  __shared__ __align__(16) float rhs[R * LDH];  // r * h
+  __shared__ float part[2][4][R];               // LayerNorm partials: [sum | squared deviations][wave][row]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, a = lane & 15, q = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * R;
+  const int end = p.meta[kMetaEnd];
+  if (row0 >= end) return;
+  const int g = (p.n_ions > 1 && row0 >= p.meta[kMetaBase + 1]) ? 1 : 0;
+  const int64_t ion_end = p.meta[kMetaBase + g] + p.meta[kMetaRows + g];
+  const int64_t row_end = row0 + R < ion_end ? row0 + R : ion_end;
+  if (row0 >= row_end) return;
+  const float* img = p.img[g] + p.gu_off;
+  const f32x4_t* P1 = reinterpret_cast<const f32x4_t*>(img);              // [Wz|Wr]: unit ((u * 4 + qq) * 2D + column)
+  const f32x4_t* P2 = reinterpret_cast<const f32x4_t*>(img + 4 * D * D);  // Wh: unit ((u * 4 + qq) * D + column)
+  const float* bias = img + 6 * D * D;                                    // bz br bh gamma beta
+  for (int i = tid; i < R * D / 4; i += kGuSmallThreads) {
+    const int r = i / (D / 4), c4 = i - r * (D / 4);
+    stv4(hs + r * LDH + 4 * c4, ldv4(p.h + (row0 + r) * D + 4 * c4));
+  }
+  // the aggregated messages of the lane's row (A operand: row a, k = 4 q .. 4 q + 3 of a slice): two sources
+  const int goff0 = agg_off(p.c2a[row0 + a], p.m_off, D) + 4 * q, goff1 = agg_off(p.c2b[row0 + a], p.m_off, D) + 4 * q;
+  const int f0 = 16 * (wv * NL) + a;  // the lane's column of the wave's first feature tile
+  f32x4_t z[NL], rr[NL], tt[NL];
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL) {
+    const float b0 = bias[f0 + 16 * TL], b1 = bias[D + f0 + 16 * TL], b2 = bias[2 * D + f0 + 16 * TL];
+    z[TL] = f32x4_t{b0, b0, b0, b0};
+    rr[TL] = f32x4_t{b1, b1, b1, b1};
+    tt[TL] = f32x4_t{b2, b2, b2, b2};
+  }
+  __syncthreads();
+  struct Ops {
+    f32x4_t av, aw, bz[NL], br[NL];
+  };
+  constexpr int kAhead = 3;
+  // ---- phase 1: [z|r] pre-activations = [h|agg] x [Wz|Wr]
+  {
+    Ops o[kAhead];
+    auto load1 = [&](int u, Ops& x) {
+      if (u < NS) {
+        x.av = ldv4(hs + a * LDH + 16 * u + 4 * q);
+        x.aw = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      } else {
+        x.av = ldv4(p.agg + goff0 + 16 * (u - NS));
+        x.aw = ldv4(p.agg + goff1 + 16 * (u - NS));
+      }
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL) {
+        x.bz[TL] = P1[(u * 4 + q) * 2 * D + f0 + 16 * TL];
+        x.br[TL] = P1[(u * 4 + q) * 2 * D + D + f0 + 16 * TL];
+      }
+    };
+#pragma unroll
+    for (int u = 0; u < kAhead - 1; ++u) load1(u, o[u]);
+#pragma unroll
+    for (int u = 0; u < 2 * NS; ++u) {
+      if (u + kAhead - 1 < 2 * NS) load1(u + kAhead - 1, o[(u + kAhead - 1) % kAhead]);
+      const Ops& x = o[u % kAhead];
+      const f32x4_t av = x.av + x.aw;  // (first slot first: the Reduce's order; h + 0 for a slice of h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int TL = 0; TL < NL; ++TL) {
+          z[TL] = mfma_f32(av[r], x.bz[TL][r], z[TL]);
+          rr[TL] = mfma_f32(av[r], x.br[TL][r], rr[TL]);
+        }
+    }
+  }
+  // ---- gates; r * h into LDS (accumulator layout: column a of the tile, rows 4 q + i)
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      z[TL][i] = fsig(z[TL][i]);
+      rhs[(4 * q + i) * LDH + f0 + 16 * TL] = gu_rh(rr[TL][i], hs[(4 * q + i) * LDH + f0 + 16 * TL]);
+    }
+  __syncthreads();
+  // ---- phase 2: candidate = [r * h|agg] x Wh
+  {
+    struct Ops2 {
+      f32x4_t av, aw, bh[NL];
+    };
+    Ops2 o[kAhead];
+    auto load2 = [&](int u, Ops2& x) {
+      if (u < NS) {
+        x.av = ldv4(rhs + a * LDH + 16 * u + 4 * q);
+        x.aw = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      } else {
+        x.av = ldv4(p.agg + goff0 + 16 * (u - NS));
+        x.aw = ldv4(p.agg + goff1 + 16 * (u - NS));
+      }
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL) x.bh[TL] = P2[(u * 4 + q) * D + f0 + 16 * TL];
+    };
+#pragma unroll
+    for (int u = 0; u < kAhead - 1; ++u) load2(u, o[u]);
+#pragma unroll
+    for (int u = 0; u < 2 * NS; ++u) {
+      if (u + kAhead - 1 < 2 * NS) load2(u + kAhead - 1, o[(u + kAhead - 1) % kAhead]);
+      const Ops2& x = o[u % kAhead];
+      const f32x4_t av = x.av + x.aw;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int TL = 0; TL < NL; ++TL) tt[TL] = mfma_f32(av[r], x.bh[TL][r], tt[TL]);
+    }
+  }
+  // ---- blend, LayerNorm over the D features of a row (partials of the four waves through LDS), residual
+  float hv[NL][4], sum[4], var[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL) {
+      hv[TL][i] = hs[(4 * q + i) * LDH + f0 + 16 * TL];
+      const float nv = gu_blend(z[TL][i], hv[TL][i], tt[TL][i]);
+      tt[TL][i] = nv;
+      sacc += nv;
+    }
+    sum[i] = row16_sum_f(sacc);
+    if (a == 0) part[0][wv][4 * q + i] = sum[i];
+  }
+  __syncthreads();
+  float mean[4], inv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rl = 4 * q + i;
+    mean[i] = (part[0][0][rl] + part[0][1][rl] + part[0][2][rl] + part[0][3][rl]) * (1.0f / D);
+    float vs = 0.f;
+#pragma unroll
+    for (int TL = 0; TL < NL; ++TL) {
+      const float dv = tt[TL][i] - mean[i];
+      vs = fmaf(dv, dv, vs);
+    }
+    var[i] = row16_sum_f(vs);
+    if (a == 0) part[1][wv][rl] = var[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rl = 4 * q + i;
+    inv[i] = gu_inv_std(part[1][0][rl] + part[1][1][rl] + part[1][2][rl] + part[1][3][rl], 1.0f / D, p.eps);
+  }
+#pragma unroll
+  for (int TL = 0; TL < NL; ++TL) {
+    const int f = f0 + 16 * TL;
+    const float gm = bias[3 * D + f], bt = bias[4 * D + f];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = row0 + 4 * q + i;
+      if (row < row_end) p.h[row * D + f] = gu_out(tt[TL][i], mean[i], inv[i], gm, bt, hv[TL][i]);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1371,7 +1559,7 @@ __global__ __launch_bounds__(kGuX3Threads, 2) void wide_update_x3_kernel(GuParam
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         z[rt][TL][gq] = fsig(z[rt][TL][gq]);
-        rhs[(32 * rg + 16 * rt + 4 * q + gq) * LDR + 16 * (fg * NL + TL) + a] = fsig(rr[rt][TL][gq]) * hreg[rt][TL][gq];
+        rhs[(32 * rg + 16 * rt + 4 * q + gq) * LDR + 16 * (fg * NL + TL) + a] = gu_rh(rr[rt][TL][gq], hreg[rt][TL][gq]);
       }
   f32x4_t tt[2][NL];
 #pragma unroll
@@ -1429,7 +1617,7 @@ __global__ __launch_bounds__(kGuX3Threads, 2) void wide_update_x3_kernel(GuParam
 #pragma unroll
       for (int TL = 0; TL < NL; ++TL) {
         const float hv = hreg[rt][TL][gq];
-        const float nv = (1.0f - z[rt][TL][gq]) * hv + z[rt][TL][gq] * ftanh(tt[rt][TL][gq]);
+        const float nv = gu_blend(z[rt][TL][gq], hv, tt[rt][TL][gq]);
         tt[rt][TL][gq] = nv;
         sacc += nv;
       }
@@ -1465,7 +1653,7 @@ __global__ __launch_bounds__(kGuX3Threads, 2) void wide_update_x3_kernel(GuParam
       float vs = 0.f;
 #pragma unroll
       for (int f2 = 0; f2 < FG; ++f2) vs += part[f2 * R + rl];
-      inv[rt][gq] = __builtin_amdgcn_rsqf(vs * (1.0f / D) + p.eps);  // (v_rsq_f32, as the 128-row kernel: a batch and its shards may take different tile sizes and must agree bitwise)
+      inv[rt][gq] = gu_inv_std(vs, 1.0f / D, p.eps);
     }
 #pragma unroll
   for (int TL = 0; TL < NL; ++TL) {
@@ -1477,7 +1665,7 @@ __global__ __launch_bounds__(kGuX3Threads, 2) void wide_update_x3_kernel(GuParam
       for (int gq = 0; gq < 4; ++gq) {
         const int64_t row = row0 + 32 * rg + 16 * rt + 4 * q + gq;
         if (row < row_end)
-          p.h[row * D + f] = (tt[rt][TL][gq] - mean[rt][gq]) * inv[rt][gq] * gm + bt + hreg[rt][TL][gq];
+          p.h[row * D + f] = gu_out(tt[rt][TL][gq], mean[rt][gq], inv[rt][gq], gm, bt, hreg[rt][TL][gq]);
       }
   }
 }
@@ -1712,7 +1900,7 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
           if (MINI) z[rt][TL][gq] = fsig(z[rt][TL][gq]);  // (whole tiles: between the MFMAs of phase 2, slice2)
-          rhs[(64 * rg + 16 * rt + 4 * q + gq) * LDR + 16 * (fg * NL + TL) + a] = fsig(rr[rt][TL][gq]) * hreg[rt][TL][gq];
+          rhs[(64 * rg + 16 * rt + 4 * q + gq) * LDR + 16 * (fg * NL + TL) + a] = gu_rh(rr[rt][TL][gq], hreg[rt][TL][gq]);
         }
     }
   f32x4_t tt[RTW][NL];
@@ -1826,7 +2014,7 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
 #pragma unroll
       for (int TL = 0; TL < NL; ++TL) {
         const float hv = hreg[rt][TL][gq];
-        const float nv = (1.0f - z[rt][TL][gq]) * hv + z[rt][TL][gq] * ftanh(tt[rt][TL][gq]);
+        const float nv = gu_blend(z[rt][TL][gq], hv, tt[rt][TL][gq]);
         tt[rt][TL][gq] = nv;
         sacc += nv;
       }
@@ -1876,7 +2064,7 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
       float vs = 0.f;
 #pragma unroll
       for (int f2 = 0; f2 < FG; ++f2) vs += part[f2 * R + rl];
-      inv[rt][gq] = __builtin_amdgcn_rsqf(vs * (1.0f / D) + p.eps);  // (v_rsq_f32: 1 ulp)
+      inv[rt][gq] = gu_inv_std(vs, 1.0f / D, p.eps);
     }
   WIDE_STAMP(p.stamps, 7);
   // Every row of the tile (MINI: of its 16-row piece) is stored: the rows past the ion's last are padding of the row
@@ -1892,7 +2080,7 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
         if (active(rt))
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq)
-          out[(16 * rt + gq) * D + 16 * TL] = (tt[rt][TL][gq] - mean[rt][gq]) * inv[rt][gq] * gm + bt + hreg[rt][TL][gq];
+          out[(16 * rt + gq) * D + 16 * TL] = gu_out(tt[rt][TL][gq], mean[rt][gq], inv[rt][gq], gm, bt, hreg[rt][TL][gq]);
     }
   }
   WIDE_STAMP(p.stamps, 4);
@@ -2159,7 +2347,7 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   }
   if (a.n_ions == 1) img[1] = img[0];
   profile_record_start(s);
-  wide_embed_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.rowbase), a.atom_table, F(w.h), a.D);
+  wide_embed_kernel<<<mols, 256, 0, s>>>(in, I(w.kept), I(w.rowbase), a.atom_table, F(w.h), a.D);
   const int cus = device_compute_units();  // persistent message workgroups: one per CU
   const size_t msg_lds = ((size_t)a.D * (a.D + 4) + 2 * (size_t)te * (a.D + 4)) * 4 + (size_t)(w.nT + 1) * 4;
   const int nt = a.D / 16;
@@ -2251,6 +2439,9 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     } else if (x3) {
       if (nt == 8) wide_update_x3_kernel<8><<<gu_grid, kGuX3Threads, gu_lds, s>>>(gp);
       else wide_update_x3_kernel<4><<<gu_grid, kGuX3Threads, gu_lds, s>>>(gp);
+    } else if (tile_rows == 16) {  // launches too small to fill the chip
+      if (nt == 8) wide_update_small_kernel<8><<<gu_grid, kGuSmallThreads, 0, s>>>(gp);
+      else wide_update_small_kernel<4><<<gu_grid, kGuSmallThreads, 0, s>>>(gp);
     } else if (nt == 8) {
       wide_update_kernel<8><<<gu_grid, kGuThreads, gu_lds, s>>>(gp);
     } else {
