@@ -1192,14 +1192,15 @@ __global__ __launch_bounds__(kGuThreads, 4) void wide_update_kernel(GuParams p) 
 // aggregated messages from their two sources - three slices ahead of the MFMAs: no staging, four barriers per tile.
 // Exact f32 (v_mfma_f32_16x16x4_f32), the products and their order per output as wide_update_kernel's.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kGuSmallThreads = 256;
 template <int NT>
-__global__ __launch_bounds__(kGuSmallThreads) void wide_update_small_kernel(GuParams p) {
-  constexpr int D = 16 * NT, NL = NT / 4, LDH = D + 4, R = 16, NS = NT;  // NS 16-k slices per D of contraction
+__global__ __launch_bounds__(NT >= 8 ? 512 : 256) void wide_update_small_kernel(GuParams p) {
+  // WV waves: wave w owns the features [w D / WV, (w + 1) D / WV) - one 16-feature tile at D = 128 (8 waves), at D = 64 (4)
+  constexpr int WV = NT >= 8 ? 8 : 4, T = 64 * WV;
+  constexpr int D = 16 * NT, NL = NT / WV, LDH = D + 4, R = 16, NS = NT;  // NS 16-k slices per D of contraction
   static_assert(NL >= 1, "tile shape");
   __shared__ __align__(16) float hs[R * LDH];   // h of the tile's rows
   __shared__ __align__(16) float rhs[R * LDH];  // r * h
-  __shared__ float part[2][4][R];               // LayerNorm partials: [sum | squared deviations][wave][row]
+  __shared__ float part[2][4][R];               // LayerNorm partials: [sum | squared deviations][feature group][row]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, a = lane & 15, q = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * R;
   const int end = p.meta[kMetaEnd];
@@ -1212,7 +1213,7 @@ __global__ __launch_bounds__(kGuSmallThreads) void wide_update_small_kernel(GuPa
   const f32x4_t* P1 = reinterpret_cast<const f32x4_t*>(img);              // [Wz|Wr]: unit ((u * 4 + qq) * 2D + column)
   const f32x4_t* P2 = reinterpret_cast<const f32x4_t*>(img + 4 * D * D);  // Wh: unit ((u * 4 + qq) * D + column)
   const float* bias = img + 6 * D * D;                                    // bz br bh gamma beta
-  for (int i = tid; i < R * D / 4; i += kGuSmallThreads) {
+  for (int i = tid; i < R * D / 4; i += T) {
     const int r = i / (D / 4), c4 = i - r * (D / 4);
     stv4(hs + r * LDH + 4 * c4, ldv4(p.h + (row0 + r) * D + 4 * c4));
   }
@@ -1254,6 +1255,7 @@ __global__ __launch_bounds__(kGuSmallThreads) void wide_update_small_kernel(GuPa
 #pragma unroll
     for (int u = 0; u < 2 * NS; ++u) {
       if (u + kAhead - 1 < 2 * NS) load1(u + kAhead - 1, o[(u + kAhead - 1) % kAhead]);
+      __builtin_amdgcn_sched_barrier(0);  // (the requests stay in front of this slice's MFMAs)
       const Ops& x = o[u % kAhead];
       const f32x4_t av = x.av + x.aw;  // (first slot first: the Reduce's order; h + 0 for a slice of h)
 #pragma unroll
@@ -1296,6 +1298,7 @@ __global__ __launch_bounds__(kGuSmallThreads) void wide_update_small_kernel(GuPa
 #pragma unroll
     for (int u = 0; u < 2 * NS; ++u) {
       if (u + kAhead - 1 < 2 * NS) load2(u + kAhead - 1, o[(u + kAhead - 1) % kAhead]);
+      __builtin_amdgcn_sched_barrier(0);
       const Ops2& x = o[u % kAhead];
       const f32x4_t av = x.av + x.aw;
 #pragma unroll
@@ -1304,41 +1307,82 @@ __global__ __launch_bounds__(kGuSmallThreads) void wide_update_small_kernel(GuPa
         for (int TL = 0; TL < NL; ++TL) tt[TL] = mfma_f32(av[r], x.bh[TL][r], tt[TL]);
     }
   }
-  // ---- blend, LayerNorm over the D features of a row (partials of the four waves through LDS), residual
-  float hv[NL][4], sum[4], var[4];
+  // ---- blend, LayerNorm over the D features of a row, residual.  The partial sums are formed exactly as
+  // wide_update_kernel forms them - per feature GROUP of D / 4 features: lane-wise over the group's tiles, then over the
+  // 16 lanes, then over the four groups - so that a batch and its chunks agree bit for bit whichever kernel they take.
+  // With 8 waves (D = 128) a group is two waves: the odd one hands its blended values to the even one through LDS.
+  constexpr bool kPair = WV == 8;
+  constexpr int NG = kPair ? 2 : NL;  // tiles of a feature group as the summing wave sees them
+  static_assert(!kPair || NL == 1, "pairs of single-tile waves");
+  float hv[NL][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float sacc = 0.f;
+  for (int TL = 0; TL < NL; ++TL)
 #pragma unroll
-    for (int TL = 0; TL < NL; ++TL) {
+    for (int i = 0; i < 4; ++i) {
       hv[TL][i] = hs[(4 * q + i) * LDH + f0 + 16 * TL];
-      const float nv = gu_blend(z[TL][i], hv[TL][i], tt[TL][i]);
-      tt[TL][i] = nv;
-      sacc += nv;
+      tt[TL][i] = gu_blend(z[TL][i], hv[TL][i], tt[TL][i]);
     }
-    sum[i] = row16_sum_f(sacc);
-    if (a == 0) part[0][wv][4 * q + i] = sum[i];
+  float grp[NG][4];  // the group's blended values at this lane's positions
+#pragma unroll
+  for (int i = 0; i < 4; ++i) grp[0][i] = tt[0][i];  // (an odd wave of a pair does not sum: its copy goes through LDS)
+  if (!kPair) {
+#pragma unroll
+    for (int TL = 1; TL < NL; ++TL)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) grp[TL < NG ? TL : 0][i] = tt[TL][i];
+  } else {
+    float* xch = rhs;  // (r * h is dead: every wave is past phase 2's reads only after the barrier below)
+    __syncthreads();
+    if (wv & 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xch[((wv >> 1) * 4 + i) * 64 + lane] = tt[0][i];
+    }
+    __syncthreads();
+    if (!(wv & 1)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) grp[1][i] = xch[((wv >> 1) * 4 + i) * 64 + lane];
+    }
+  }
+  const bool summing = !kPair || !(wv & 1);  // (wave-uniform)
+  const int fgi = kPair ? wv >> 1 : wv;      // feature group
+  if (summing) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int t2 = 0; t2 < NG; ++t2) sacc += grp[t2][i];
+      const float sm = row16_sum_f(sacc);
+      if (a == 0) part[0][fgi][4 * q + i] = sm;
+    }
   }
   __syncthreads();
   float mean[4], inv[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rl = 4 * q + i;
-    mean[i] = (part[0][0][rl] + part[0][1][rl] + part[0][2][rl] + part[0][3][rl]) * (1.0f / D);
-    float vs = 0.f;
+    float ms = 0.f;
 #pragma unroll
-    for (int TL = 0; TL < NL; ++TL) {
-      const float dv = tt[TL][i] - mean[i];
-      vs = fmaf(dv, dv, vs);
+    for (int f2 = 0; f2 < 4; ++f2) ms += part[0][f2][rl];
+    mean[i] = ms * (1.0f / D);
+    if (summing) {
+      float vs = 0.f;
+#pragma unroll
+      for (int t2 = 0; t2 < NG; ++t2) {
+        const float dv = grp[t2][i] - mean[i];
+        vs = fmaf(dv, dv, vs);
+      }
+      const float vr = row16_sum_f(vs);
+      if (a == 0) part[1][fgi][rl] = vr;
     }
-    var[i] = row16_sum_f(vs);
-    if (a == 0) part[1][wv][rl] = var[i];
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rl = 4 * q + i;
-    inv[i] = gu_inv_std(part[1][0][rl] + part[1][1][rl] + part[1][2][rl] + part[1][3][rl], 1.0f / D, p.eps);
+    float vs = 0.f;
+#pragma unroll
+    for (int f2 = 0; f2 < 4; ++f2) vs += part[1][f2][rl];
+    inv[i] = gu_inv_std(vs, 1.0f / D, p.eps);
   }
 #pragma unroll
   for (int TL = 0; TL < NL; ++TL) {
@@ -2440,8 +2484,8 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
       if (nt == 8) wide_update_x3_kernel<8><<<gu_grid, kGuX3Threads, gu_lds, s>>>(gp);
       else wide_update_x3_kernel<4><<<gu_grid, kGuX3Threads, gu_lds, s>>>(gp);
     } else if (tile_rows == 16) {  // launches too small to fill the chip
-      if (nt == 8) wide_update_small_kernel<8><<<gu_grid, kGuSmallThreads, 0, s>>>(gp);
-      else wide_update_small_kernel<4><<<gu_grid, kGuSmallThreads, 0, s>>>(gp);
+      if (nt == 8) wide_update_small_kernel<8><<<gu_grid, 512, 0, s>>>(gp);
+      else wide_update_small_kernel<4><<<gu_grid, 256, 0, s>>>(gp);
     } else if (nt == 8) {
       wide_update_kernel<8><<<gu_grid, kGuThreads, gu_lds, s>>>(gp);
     } else {
