@@ -441,19 +441,6 @@ __device__ __forceinline__ bool resolve_share(const PlanParams& p, int j, int la
 // -----------------------------------------------------------------------------------------
 constexpr int kDegBins = 18;    // in-degree 0..15, ">= 16", and "row beyond the chunk" (placed last)
 
-// Exclusive prefix sum over the 256 threads of a plan_chunks workgroup (4 waves); `total` gets the sum.
-__device__ __forceinline__ int block_excl_scan(int v, int32_t* wsum /* [4] LDS */, int& total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int incl = wave_incl_scan(v);
-  if (lane == 63) wsum[wave] = incl;
-  lds_barrier();
-  int off = 0;
-  for (int w = 0; w < wave; ++w) off += wsum[w];
-  total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  lds_barrier();  // wsum may be reused right away
-  return off + incl - v;
-}
-
 // Share tables of a plan_chunks workgroup (LDS): the virtual-row prefix of the share's molecules and its next-fit chain
 struct ShareTab {
   int32_t shst[kShareCap + 1];  // virtual-row prefix of the share's molecules (+ end)

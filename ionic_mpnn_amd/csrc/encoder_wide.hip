@@ -1440,7 +1440,6 @@ __global__ __launch_bounds__(kGuX3Threads, 2) void wide_update_x3_kernel(GuParam
   const int64_t ion_end = p.meta[kMetaBase + g] + p.meta[kMetaRows + g];
   const int64_t row_end = row0 + p.tile_rows < ion_end ? row0 + p.tile_rows : ion_end;
   if (row0 >= row_end) return;
-  const bool lv[2] = {32 * rg < p.tile_rows, 32 * rg + 16 < p.tile_rows};  // (wave-uniform) this wave's two row tiles
   const float* img = p.img[g] + p.gu_off;
   const uint4* P1 = reinterpret_cast<const uint4*>(img);
   const uint4* P2 = P1 + (size_t)NS * UB1;
@@ -1833,10 +1832,6 @@ __device__ __forceinline__ void x3b_tile(const GuParams& p, const int64_t row0, 
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl)
       av[pl] = __builtin_bit_cast(bf16x8_t, st[(pl * 4 + q) * R + 64 * rg + 16 * rt + a]);
-  };
-  auto read_b = [&](const uint4* bs, int ncols, int col, bf16x8_t (&bv)[3]) {
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) bv[pl] = __builtin_bit_cast(bf16x8_t, bs[(pl * 4 + q) * ncols + col]);
   };
   float hreg[RTW][NL][4];
   auto load_hreg = [&]() {
