@@ -263,7 +263,8 @@ class MPNNModel:
         "auto" picks exact-f32 arithmetic only: "f32t" (per-bond-type messages, any bond_dim) first, then "f32"
         (pull form, bond_dim <= 8).  "f16x2" (split-fp16 products, narrower than f32) is used on request only, and
         then only while its static range bound holds for every possible in-degree (<= E edge slots); otherwise the
-        request falls back to the exact modes."""
+        request falls back to the exact modes.  "f32x3" (f32 as bf16x9: as exact as f32, another summation order) is used
+        on request where the shape allows it and falls back to "f32t" where it does not."""
         if E is None:  # (older call sites passed E alone)
             N, E = 1, N
         sup = lambda m: ops.encoder_fused_supported(N, E, self.atom_dim, self.bond_dim, self.num_steps,
@@ -274,6 +275,8 @@ class MPNNModel:
             if sup("f16x2") and (self._split_deg_limit is None or E <= self._split_deg_limit):
                 return "f16x2"
             want = "auto"
+        if want == "f32x3" and not sup("f32x3") and sup("f32t"):
+            return "f32t"  # shapes beyond mode 3's LDS budget (E > 512 at atom_dim 32): the exact-f32 form of the same path
         if want in ("f32t", "f32", "f32x3"):
             return want if sup(want) else None
         for m in ("f32t", "f32"):

@@ -330,6 +330,10 @@ def test_mode_resolution_exact_by_default_split_only_inside_its_range_bound():
     huge["cat_bmm_0/bond_transform"] = w["cat_bmm_0/bond_transform"] * 1.0e4   # |W|*256 > fp16 max
     m.load_weights(huge)
     assert m._packed_weights() is not None and m._split_deg_limit == 0.0 and m.resolve_encoder_mode(40, 1) == "f32t"
+    # the bf16x9 form on request where the shape fits its LDS budget, the exact-f32 form of the same encoder where not
+    m.encoder_mode = "f32x3"
+    assert m.resolve_encoder_mode(40, 80) == "f32x3" and m.resolve_encoder_mode(160, 512) == "f32x3"
+    assert m.resolve_encoder_mode(160, 640) == "f32t"
 
 
 def test_plan_and_run_must_agree_on_geometry():
