@@ -2337,6 +2337,17 @@ int raise_lds(K kern, size_t bytes) {
 }
 }  // namespace
 
+// May the update kernels name messages directly as a row's sources (32-bit float offsets from `agg`)?  Not where the
+// message buffer lies beyond that range (~70 000 pairs at D = 128); IMPNN_WIDE_NO_DIRECT=1 (diagnostics, read once per
+// process) forces the other path - every row's sum in agg - for the tests.
+bool wide_direct_sources(const wide::Ws& w, int D) {
+  static const bool forced_off = [] {
+    const char* e = getenv("IMPNN_WIDE_NO_DIRECT");
+    return e && atoi(e) != 0;
+  }();
+  return !forced_off && (int64_t)((w.m - w.agg) / 4) + (int64_t)w.vmax * D < ((int64_t)1 << 31);
+}
+
 int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   using namespace wide;
   const bool x3 = a.mode == 3;
@@ -2360,7 +2371,7 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   const int te = tile_edges(a.D);
   if (a.phases & 1) {
     const int nz = (int)((w.kept - w.meta) / 4);  // meta and the type counters
-    const bool direct_ok = (int64_t)((w.m - w.agg) / 4) + (int64_t)w.vmax * a.D < ((int64_t)1 << 31);
+    const bool direct_ok = wide_direct_sources(w, a.D);
     wide_iota_kernel<<<(unsigned)(((w.rmax > nz ? w.rmax : nz) + 255) / 256), 256, 0, s>>>(I(w.aggc2), I(w.aggc2) + w.rmax, F(w.agg),
         (int)w.rmax, a.D, I(w.meta), nz);
     wide_count_kernel<<<mol_wgs, 256, 0, s>>>(in, I(w.kept), I(w.cnt));
@@ -2461,7 +2472,7 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     }
     wide_reduce_kernel<<<(unsigned)((red_threads + 255) / 256), 256, 0, s>>>(
         F(w.m), reinterpret_cast<const int2*>(base + w.rowinfo), I(w.csr), F(w.agg), I(w.meta), a.n_ions, a.D,
-        m_off + (int64_t)w.vmax * a.D < ((int64_t)1 << 31) ? 2 : 0);
+        wide_direct_sources(w, a.D) ? 2 : 0);
     GuParams gp{};
     gp.h = F(w.h); gp.agg = F(w.agg);
     gp.c2a = I(w.aggc2); gp.c2b = I(w.aggc2) + w.rmax; gp.m_off = (int)m_off;
