@@ -160,8 +160,8 @@ int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, i
  *                                 EXACTLY as three bf16 terms (3 x 8 significant bits, fp32's exponent range) and all nine
  *                                 cross products are accumulated in f32 (9 x v_mfma_f32_16x16x32_bf16 per 8 f32 MFMAs):
  *                                 the products are the f32 products, only their summation order differs.  atom_dim 32:
- *                                 messages stay on the f32 4x4x1 MFMA; atom_dim 128: the per-type message GEMMs run
- *                                 the same way (atom_dim 64: exact f32 messages).  Same records, prepared buffer of
+ *                                 messages stay on the f32 4x4x1 MFMA; atom_dim 64 / 128: the per-type message GEMMs
+ *                                 run the same way.  Same records, prepared buffer of
  *                                 its own (impnn_encoder_prepared_bytes with this mode).  Opt-in.
  *  `workgroups` - persistent workgroups of the launch: 0 = default (environment IMPNN_ENCODER_WORKGROUPS if set - a
  *  process-wide diagnostics override, read ONCE at the first call - else one per compute unit), n = min(max(n, 16), CUs);

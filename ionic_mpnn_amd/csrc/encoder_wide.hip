@@ -615,7 +615,8 @@ __global__ __launch_bounds__(1024) void wide_message_kernel(MsgParams p) {
 // ------------------------------------------------------------------------------------------------------------
 // a2 + a4 in mode IMPNN_ENCODER_F32X3_TYPED: the per-type GEMMs m = A[type] h[src] on the bf16 matrix pipe, every f32
 // operand carried exactly as three bf16 terms and all nine cross products accumulated in f32 (as the GatedUpdate of this
-// mode).  8 waves: a wave multiplies 32 edges x 32 features (2 x 2 MFMA tiles, 144 MFMAs per 64-edge tile).
+// mode).  8 waves: a wave multiplies 32 edges x 32 features (2 x 2 MFMA tiles; 64-edge tiles at D = 128, 128-edge tiles
+// at D = 64 - as the plan cuts them).
 //   * a wave keeps ITS operands of the type's matrix - 32 feature rows, all k, three planes: 96 VGPRs - in registers
 //     for the whole run of the type (a type's run is ~40 tiles; the planes come pre-split and in operand order from
 //     the prepared image, wide_mat_planes_kernel), so a tile costs LDS traffic for the rows only;
@@ -634,12 +635,13 @@ __global__ __launch_bounds__(kMsgX3Threads, 1) void wide_message_x3_kernel(MsgPa
                                        // that the 16 k octets a wave parks at once fall into different LDS banks
   constexpr int UX = 3 * KB * 4 * XS;  // ... of a tile of rows: [plane][k block][k octet][edge]
   constexpr int kX = TE * QD / T;      // 16-byte pieces of f32 rows per thread
-  static_assert(TE == 64 && kX >= 1 && KB % 2 == 0, "tile shape");
+  constexpr int EGN = TE / 32, FGN = 8 / EGN;  // 8 waves = EGN groups of 32 edges x FGN groups of 32 features
+  static_assert(EGN * FGN == 8 && NT == 2 * FGN && kX >= 2 && kX % 2 == 0 && KB % 2 == 0, "tile shape");
   extern __shared__ __align__(16) unsigned char smem_b[];
   uint4* const Xb = reinterpret_cast<uint4*>(smem_b);             // 2 x UX units
   int32_t* const tb_s = reinterpret_cast<int32_t*>(Xb + 2 * UX);  // tilebase[0 .. nT]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = lane & 15, q = lane >> 4;
-  const int eg = wave & 1, fg = wave >> 1;  // 32 edges x 32 features
+  const int eg = wave % EGN, fg = wave / EGN;  // 32 edges x 32 features
   const int ntiles = p.meta[kMetaTiles];
   const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
   const int t0 = blockIdx.x * per, t1 = t0 + per < ntiles ? t0 + per : ntiles;
@@ -2404,12 +2406,14 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   constexpr int R = kRT;
   const size_t gu_lds = x3 ? gu_x3_lds_bytes(a.D) : gu_lds_floats(a.D) * 4;
   const size_t gu_lds_big = gu_x3b_lds_bytes(a.D);
-  // mode 3 at atom_dim 128: the messages on the bf16 pipe too (64-edge tiles, as the plan cuts them for D = 128; the
-  // choice depends on the shape only, so a batch and its shards run the same kernels)
-  const bool x3_msg = x3 && nt == 8 && te == 64;
-  const size_t msg_x3_lds = msg_x3_lds_bytes(a.D, 64, w.nT);
+  // mode 3: the messages on the bf16 pipe too (the choice depends on the shape only, so a batch and its shards run the
+  // same kernels)
+  const bool x3_msg = x3 && ((nt == 8 && te == 64) || (nt == 4 && te == 128));
+  const size_t msg_x3_lds = msg_x3_lds_bytes(a.D, te, w.nT);
   if (x3_msg)
-    if (int rc = raise_lds<8>(wide_message_x3_kernel<8, 64>, msg_x3_lds)) return rc;
+    if (int rc = nt == 8 ? raise_lds<8>(wide_message_x3_kernel<8, 64>, msg_x3_lds)
+                         : raise_lds<9>(wide_message_x3_kernel<4, 128>, msg_x3_lds))
+      return rc;
   if (a.D == 128) {
     if (int rc = raise_lds<0>(wide_message_kernel<8, 64>, msg_lds)) return rc;
     if (int rc = x3 ? raise_lds<4>(wide_update_x3_kernel<8>, gu_lds) : raise_lds<1>(wide_update_kernel<8>, gu_lds)) return rc;
@@ -2465,7 +2469,8 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
     mp.stamps = stamps ? stamps + (size_t)gu_grid * 8 : nullptr;
     mp.planes_off = step_off + mat_planes_off(a.D, a.Vb);
     if (a.E > 0 && x3_msg) {
-      wide_message_x3_kernel<8, 64><<<cus, kMsgX3Threads, msg_x3_lds, s>>>(mp);
+      if (nt == 8) wide_message_x3_kernel<8, 64><<<cus, kMsgX3Threads, msg_x3_lds, s>>>(mp);
+      else wide_message_x3_kernel<4, 128><<<cus, kMsgX3Threads, msg_x3_lds, s>>>(mp);
     } else if (a.E > 0) {
       if (nt == 8) wide_message_kernel<8, 64><<<cus, 1024, msg_lds, s>>>(mp);
       else wide_message_kernel<4, 128><<<cus, 1024, msg_lds, s>>>(mp);
