@@ -44,7 +44,8 @@ constexpr int kRowAlign = 128; // an ion's rows start at a multiple of it (a til
 constexpr int kMaxN = 256;     // atoms per molecule (LDS tables of wide_place)
 constexpr int kMaxE = 512;     // edge slots per molecule
 constexpr int kMaxVb = 512;    // bond vocabulary (types of both ions: one per thread of wide_scan)
-constexpr int kMolPerWg = 16;  // molecules of a wide_count / wide_place workgroup (4 waves x 4)
+constexpr int kMolPerWg = 16;  // molecules of a wide_count / wide_place workgroup (4 waves x 4); launches of up to
+                               // 1024 molecules take one molecule per wave (Inputs::mpw: latency, not atomics, bounds them)
 
 // meta words (device): rows of ion g, first compact row of ion g, valid edges, message tiles
 enum { kMetaRows = 0, kMetaBase = 2, kMetaEnd = 4, kMetaValid = 5, kMetaTiles = 6, kMetaWords = 16 };
@@ -183,6 +184,7 @@ struct Inputs {
   const int32_t* bond_ids[2];
   const int32_t* conn[2];
   int n_ions, B, N, E, Va, Vb;
+  int mpw;  // molecules per wave of wide_count / wide_place: kMolPerWg / 4, or 1 for small launches
 };
 
 __device__ __forceinline__ int valid_type(const int32_t* conn, const int32_t* bond_ids, int64_t be, int N, int Vb,
@@ -225,8 +227,8 @@ __global__ __launch_bounds__(256) void wide_count_kernel(Inputs in, int32_t* __r
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mols = in.n_ions * in.B;
-  for (int i = 0; i < kMolPerWg / 4; ++i) {
-    const int mol = blockIdx.x * kMolPerWg + wave * (kMolPerWg / 4) + i;
+  for (int i = 0; i < in.mpw; ++i) {
+    const int mol = (blockIdx.x * 4 + wave) * in.mpw + i;
     if (mol >= mols) break;
     const int g = mol >= in.B ? 1 : 0, b = mol - g * in.B;
     const int32_t* ids = in.atom_ids[g] + (int64_t)b * in.N;
@@ -355,8 +357,8 @@ __global__ __launch_bounds__(256) void wide_place_kernel(Inputs in, const int32_
   const int mols = in.n_ions * in.B;
   for (int t = threadIdx.x; t < nT; t += 256) lh[t] = 0;
   __syncthreads();
-  for (int i = 0; i < kMolPerWg / 4; ++i) {
-    const int mol = blockIdx.x * kMolPerWg + wave * (kMolPerWg / 4) + i;
+  for (int i = 0; i < in.mpw; ++i) {
+    const int mol = (blockIdx.x * 4 + wave) * in.mpw + i;
     if (mol >= mols) break;
     const int g = mol >= in.B ? 1 : 0, b = mol - g * in.B;
     for (int e = lane; e < in.E; e += 64) {
@@ -371,8 +373,8 @@ __global__ __launch_bounds__(256) void wide_place_kernel(Inputs in, const int32_
     lh[t] = c ? atomicAdd(&cursor[t], c) : 0;
   }
   __syncthreads();
-  for (int i = 0; i < kMolPerWg / 4; ++i) {
-    const int mol = blockIdx.x * kMolPerWg + wave * (kMolPerWg / 4) + i;
+  for (int i = 0; i < in.mpw; ++i) {
+    const int mol = (blockIdx.x * 4 + wave) * in.mpw + i;
     if (mol >= mols) break;
     const int g = mol >= in.B ? 1 : 0, b = mol - g * in.B;
     const int r = kept[mol], rb = rowbase[mol];
@@ -2369,7 +2371,8 @@ int launch_encoder_wide(const EncoderArgs& a, hipStream_t s) {
   }
   in.n_ions = a.n_ions; in.B = a.B; in.N = a.N; in.E = a.E; in.Va = a.Va; in.Vb = a.Vb;
   const int mols = a.n_ions * a.B;
-  const int mol_wgs = (mols + kMolPerWg - 1) / kMolPerWg;
+  in.mpw = mols <= 1024 ? 1 : kMolPerWg / 4;
+  const int mol_wgs = (mols + 4 * in.mpw - 1) / (4 * in.mpw);
   const int te = tile_edges(a.D);
   if (a.phases & 1) {
     const int nz = (int)((w.kept - w.meta) / 4);  // meta and the type counters
