@@ -237,11 +237,17 @@ def time_other_configs(dev, Va, Vb):
         m = model.build_model(Va, Vb, atom_dim=32, bond_dim=8, num_steps=S, device=dev)
         m.load_weights(weights.init_weights("viscosity", Va, Vb, atom_dim=32, bond_dim=8, num_steps=S, seed=1))
         d = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
-        ms = _gpu_timed(lambda: m.encode_pooled(d), 10)
+        modes = {}
+        for mode in ("f32t", "f32x3"):
+            m.encoder_mode = mode
+            modes[mode] = _gpu_timed(lambda: m.encode_pooled(d), 10)
+        best = min(modes, key=modes.get)
+        ms = modes[best]
         rows, edges = executed_counts(inp)
         fl = S * (12 * 32 * 32 * rows + 2 * 32 * 32 * edges)
         out[name] = {
-            "ms_per_encode": ms, "graph_pairs_per_s": B / (ms * 1e-3), "encoder": m.resolve_encoder_mode(N, E),
+            "ms_per_encode": ms, "graph_pairs_per_s": B / (ms * 1e-3), "encoder": best, "modes_timed_ms_per_encode": modes,
+            "dtype": "f32 (bf16x9 emulation)" if best == "f32x3" else "f32",
             "overflow_fallbacks": int(getattr(m, "overflow_fallbacks", 0)), "kept_rows": rows, "valid_edges": edges,
             "executed_f32_tflops": fl / (ms * 1e-3) / 1e12,
             "note": "encode() of both ions (plan + fused typed encoder, 640-edge chunks; one 4-byte read-back of the plan's "

@@ -161,8 +161,8 @@ int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, i
  *                                 cross products are accumulated in f32 (9 x v_mfma_f32_16x16x32_bf16 per 8 f32 MFMAs):
  *                                 the products are the f32 products, only their summation order differs.  atom_dim 32:
  *                                 messages stay on the f32 4x4x1 MFMA; atom_dim 64 / 128: the per-type message GEMMs
- *                                 run the same way.  Same records, prepared buffer of
- *                                 its own (impnn_encoder_prepared_bytes with this mode).  Opt-in.
+ *                                 run the same way.  Same shapes as mode 2 (padded E > 512 included), same records,
+ *                                 prepared buffer of its own (impnn_encoder_prepared_bytes with this mode).  Opt-in.
  *  `workgroups` - persistent workgroups of the launch: 0 = default (environment IMPNN_ENCODER_WORKGROUPS if set - a
  *  process-wide diagnostics override, read ONCE at the first call - else one per compute unit), n = min(max(n, 16), CUs);
  *  a multiple of that for very large batches or padded shapes (the size query, plan and run agree on it by themselves).  It fixes the workspace layout, so the size query, the plan and

@@ -526,7 +526,6 @@ int launch_encoder_typed_run(const EncoderArgs& a, const enc::Ws& w, hipStream_t
 bool encoder_fused_supported(int mode, int N, int E, int D, int K, int S, int Vb) {
   using namespace enc;
   if ((mode == 2 || mode == 3) && D != kD) return encoder_wide_supported(N, E, D, K, S, Vb);  // atom_dim 64 / 128: encoder_wide.hip
-  if (mode == 3 && tecap_of(E) != kTECap) return false;  // the three-plane update image leaves no LDS for 640 edge slots
   if (mode == 2 || mode == 3) return K >= 1 && encoder_typed_supported(N, E, D, S, Vb);
   if (mode != 0 && mode != 1) return false;
   if (D != kD || K < 1 || K > kKMax || S < 0) return false;

@@ -30,13 +30,17 @@ namespace {
 
 constexpr int kOffUpd = 0;
 constexpr int off_h(bool x3) { return kOffUpd + (x3 ? kXUpdLds : kTUpdLds); }
-constexpr int off_msg(bool x3) { return off_h(x3) + kRCap * kTHS; }
-constexpr int off_rec(bool x3, int ecap) { return off_msg(x3) + tmsg_floats(ecap); }
+// hs: the LDS row stride of h - kTHS (36: rows spread over the banks), or 32 where mode 3 meets 640-edge chunks (explicit-
+// hydrogen shapes, E > 512): the three-plane update image and 642 message slots leave no room for the padding
+constexpr int kTHSBig3 = 32;
+constexpr int off_msg(bool x3, int hs = kTHS) { return off_h(x3) + kRCap * hs; }
+constexpr int off_rec(bool x3, int ecap, int hs = kTHS) { return off_msg(x3, hs) + tmsg_floats(ecap); }
 // then: the record (trec_lds_bytes(Vb, ecap)) and, when it fits, the atom table ((Va + 1) rows of kTAS floats)
-constexpr size_t lds_fixed_bytes(bool x3, int Vb, int ecap) {
-  return sizeof(float) * (size_t)off_rec(x3, ecap) + trec_lds_bytes(Vb, ecap);
+constexpr size_t lds_fixed_bytes(bool x3, int Vb, int ecap, int hs = kTHS) {
+  return sizeof(float) * (size_t)off_rec(x3, ecap, hs) + trec_lds_bytes(Vb, ecap);
 }
-static_assert(lds_fixed_bytes(true, kTVbMax, kTECap) <= 160 * 1024 && lds_fixed_bytes(false, kTVbMax, kTECapBig) <= 160 * 1024,
+static_assert(lds_fixed_bytes(true, kTVbMax, kTECap) <= 160 * 1024 && lds_fixed_bytes(false, kTVbMax, kTECapBig) <= 160 * 1024 &&
+                  lds_fixed_bytes(true, kTVbMax, kTECapBig, kTHSBig3) <= 160 * 1024,
               "LDS budget");
 
 // ---- mode 3 ("f32x3"): f32 GEMM products on the bf16 matrix pipe without narrowing them.  An f32 value is the exact
@@ -139,7 +143,7 @@ struct Run {
 #endif
 constexpr int kPfWhere = IMPNN_T_PF, kRunsEarly = IMPNN_T_EARLY;
 
-template <bool STAMPS, bool X3>
+template <bool STAMPS, bool X3, int HS = kTHS>
 __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel(TEncParams p) {
   extern __shared__ __align__(16) float smem[];
   constexpr int kUpdLds = X3 ? kXUpdLds : kTUpdLds, kUpdSlot = X3 ? kXUpdSlot : kTUpdSlot;
@@ -147,9 +151,9 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
   float* const wupd = smem + kOffUpd;
   float* const wvec = wupd + (X3 ? kXVecFloatOff : kTVecFloatOff);
   float* const hbuf = smem + off_h(X3);
-  float* const msg = smem + off_msg(X3);
+  float* const msg = smem + off_msg(X3, HS);
   const int zero_slot = p.ecap + 1;  // (dump slot: p.ecap)
-  unsigned char* const recl = reinterpret_cast<unsigned char*>(smem + off_rec(X3, p.ecap));
+  unsigned char* const recl = reinterpret_cast<unsigned char*>(smem + off_rec(X3, p.ecap, HS));
   const int rec_lds = p.rec_lds;                                 // trec_lds_bytes(Vb)
   float* const atab = reinterpret_cast<float*>(recl + rec_lds);  // Va rows + one zero row (when it fits)
   const uint16_t* const r_rowdeg = reinterpret_cast<const uint16_t*>(recl + kTRecRowdeg);
@@ -206,7 +210,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
         const int nr = r_molrows[m], mo = r_moloff[m];
         for (int n = part; n < nr; n += 8) {
           const int pr = r_poolrow[mo + n];
-          if (pr & 0x8000) acc += ld4(hbuf + (pr & 0xff) * kTHS + 4 * f4);
+          if (pr & 0x8000) acc += ld4(hbuf + (pr & 0xff) * HS + 4 * f4);
         }
       }
 #pragma unroll
@@ -234,8 +238,8 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
         v1 = ld4(p.atom_table + (int64_t)id * kD + 8 * sub + 4);
       }
     }
-    st4(hbuf + row * kTHS + 8 * sub, v0);
-    st4(hbuf + row * kTHS + 8 * sub + 4, v1);
+    st4(hbuf + row * HS + 8 * sub, v0);
+    st4(hbuf + row * HS + 8 * sub + 4, v1);
   };
 
   if (p.S == 0) {  // no message passing: pooled = GlobalSumPool(Embedding(atom ids)); kept apart from the step machinery
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
       __builtin_amdgcn_s_setprio(2);
       {
         const float* const abase = (g0 ? atab : hbuf) + acol;
-        const int astride = g0 ? kTAS : kTHS;
+        const int astride = g0 ? kTAS : HS;
         auto load_group = [&](int e, Grp& G) {
           G.ge = r_grp[e];
           int src = __builtin_amdgcn_ubfe(G.ge.y, ysh, 8);
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
           if (kRunsEarly >= 1) fetch_P(s + 1);
           if (kRunsEarly >= 2) fetch_Q(s + 1);
         }
-        int own = row * kTHS + (int)(hbuf - smem);
+        int own = row * HS + (int)(hbuf - smem);
         if (g0) {
           const int id = r_rowatom[row];
           own = ((unsigned)id < (unsigned)p.Va ? id : p.Va) * kTAS + (int)(atab - smem);
@@ -643,8 +647,8 @@ __global__ __launch_bounds__(kThreads, kThreads / 256) void encoder_typed_kernel
         const f32x4 bt0 = ld4(wvec + 4 * kD + 4 * q), bt1 = ld4(wvec + 4 * kD + 16 + 4 * q);
         const f32x4 o0 = n0 * (gm0 * inv) + (bt0 + h0);
         const f32x4 o1 = n1 * (gm1 * inv) + (bt1 + h1);
-        st4(hbuf + row * kTHS + 4 * q, o0);
-        st4(hbuf + row * kTHS + 16 + 4 * q, o1);
+        st4(hbuf + row * HS + 4 * q, o0);
+        st4(hbuf + row * HS + 16 + 4 * q, o1);
         if (mstamp && wave == 1 && lane == 0) stamp[10] = __builtin_amdgcn_s_memtime();
       }
       if (!has_tile && s + 1 < p.S) {  // waves without a tile in this chunk
@@ -693,7 +697,7 @@ bool encoder_typed_supported(int N, int E, int D, int S, int Vb) {
   // (PlanHeader::overflow), not here.
   if (N < 1 || N > 0xffff || E < 0 || E > 0xffff) return false;
   if (Vb < 1 || Vb > kTVbMax) return false;
-  return true;  // (mode 3 takes E <= 512 only: encoder_fused_supported)
+  return true;
 }
 
 size_t encoder_typed_prepared_bytes(int S, int Vb, bool x3) {
@@ -752,10 +756,13 @@ int launch_encoder_typed_run(const EncoderArgs& a, const enc::Ws& w, hipStream_t
   ep.upd_slot = (int)uslot;
   ep.ecap = tecap_of(a.E);
   ep.rec_lds = trec_lds_bytes(a.Vb, ep.ecap);
-  void (*kern)(TEncParams) = x3 ? (ep.stamps ? encoder_typed_kernel<true, true> : encoder_typed_kernel<false, true>)
-                                : (ep.stamps ? encoder_typed_kernel<true, false> : encoder_typed_kernel<false, false>);
-  if (int rc = ensure_lds_limit((const void*)kern, (ep.stamps ? 5 : 4) + (x3 ? 2 : 0))) return rc;
-  size_t lds = lds_fixed_bytes(x3, a.Vb, ep.ecap);
+  const bool big3 = x3 && ep.ecap == kTECapBig;  // mode 3 on 640-edge chunks: unpadded h rows (kTHSBig3)
+  void (*kern)(TEncParams) =
+      big3 ? (ep.stamps ? encoder_typed_kernel<true, true, kTHSBig3> : encoder_typed_kernel<false, true, kTHSBig3>)
+      : x3 ? (ep.stamps ? encoder_typed_kernel<true, true> : encoder_typed_kernel<false, true>)
+           : (ep.stamps ? encoder_typed_kernel<true, false> : encoder_typed_kernel<false, false>);
+  if (int rc = ensure_lds_limit((const void*)kern, big3 ? (ep.stamps ? 10 : 9) : (ep.stamps ? 5 : 4) + (x3 ? 2 : 0))) return rc;
+  size_t lds = lds_fixed_bytes(x3, a.Vb, ep.ecap, big3 ? kTHSBig3 : kTHS);
   const size_t atab_bytes = ((size_t)a.Va + 1) * kTAS * sizeof(float);
   ep.atab_lds = lds + atab_bytes <= 160 * 1024;
   if (ep.atab_lds) lds += atab_bytes;

@@ -276,7 +276,7 @@ class MPNNModel:
                 return "f16x2"
             want = "auto"
         if want == "f32x3" and not sup("f32x3") and sup("f32t"):
-            return "f32t"  # shapes beyond mode 3's LDS budget (E > 512 at atom_dim 32): the exact-f32 form of the same path
+            return "f32t"  # a shape only the exact-f32 form of the same path takes
         if want in ("f32t", "f32", "f32x3"):
             return want if sup(want) else None
         for m in ("f32t", "f32"):

@@ -149,7 +149,7 @@ def test_fused_encoder_single_atom_anions(mode, B):
     assert torch.equal(pa, ref_rows)
 
 
-@pytest.mark.parametrize("mode", ["f32t"])
+@pytest.mark.parametrize("mode", ["f32t", "f32x3"])
 def test_fused_encoder_explicit_hydrogen_cations_with_single_atom_anions(mode):
     """The real data sets' padded shape (N = 160, E = 640) with few bond types and halide-like anions, batch 2048."""
     Va, Vb, B = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, 2048
@@ -332,8 +332,8 @@ def test_mode_resolution_exact_by_default_split_only_inside_its_range_bound():
     assert m._packed_weights() is not None and m._split_deg_limit == 0.0 and m.resolve_encoder_mode(40, 1) == "f32t"
     # the bf16x9 form on request where the shape fits its LDS budget, the exact-f32 form of the same encoder where not
     m.encoder_mode = "f32x3"
-    assert m.resolve_encoder_mode(40, 80) == "f32x3" and m.resolve_encoder_mode(160, 512) == "f32x3"
-    assert m.resolve_encoder_mode(160, 640) == "f32t"
+    assert m.resolve_encoder_mode(40, 80) == "f32x3" and m.resolve_encoder_mode(160, 640) == "f32x3"
+    assert m.resolve_encoder_mode(300, 3000) == "f32x3"  # (any padded shape: molecules are checked per batch)
 
 
 def test_plan_and_run_must_agree_on_geometry():
@@ -766,8 +766,9 @@ def test_f32x3_propagates_nan_and_inf_like_f32t():
 # the trainers pad to E = 4 * max_bonds edge slots (train_viscosity.py:95,288-289): N = 160, E = 640 here.  The typed
 # encoder bounds a chunk by what a molecule HOLDS (plan kernels, per batch), not by the padded shape.
 # ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["auto", "f32x3"])
 @pytest.mark.parametrize("kind,K,S", [("viscosity", 8, 3), ("melting_point", 1024, 4)])
-def test_explicit_h_shape_runs_in_the_typed_encoder(kind, K, S):
+def test_explicit_h_shape_runs_in_the_typed_encoder(kind, K, S, mode):
     Va, Vb, B, N, E = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, 4096, 160, 640
     inp = synthetic.make_explicit_h_batch(B, max_atoms=N, max_edges=E, seed=41, with_temperature=(kind == "viscosity"))
     valid = (inp["cat_connectivity"][:, :, 0] > 0) & (inp["cat_connectivity"][:, :, 1] > 0)
@@ -778,7 +779,8 @@ def test_explicit_h_shape_runs_in_the_typed_encoder(kind, K, S):
     else:
         m = MM.build_melting_point_model(Va, Vb, atom_dim=32, num_steps=S, device=DEV)   # bond_dim = 32 ** 2
     m.load_weights(w)
-    assert m.bond_dim == K and m.resolve_encoder_mode(N, E) == "f32t"
+    m.encoder_mode = mode  # (f32x3 on 640-edge chunks: the kernel instantiation with unpadded h rows)
+    assert m.bond_dim == K and m.resolve_encoder_mode(N, E) == ("f32t" if mode == "auto" else mode)
     d = to_dev(inp)
     pc, pa = m.encode_pooled(d, fused=True)
     torch.cuda.synchronize()
