@@ -399,6 +399,25 @@ int impnn_gated_update_rows_bwd(const float* h, const float* agg, const float* W
                                 const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
                                 int64_t workspace_floats, const int32_t* row_index, const int32_t* n_rows,
                                 int64_t max_rows, int32_t D, int32_t accumulate, impnn_stream_t stream);
+/* The same pair for a training loop that keeps activations instead of recomputing them (atom_dim 64 / 128):
+ * impnn_gated_update_rows_train is impnn_gated_update_rows that also writes, per LISTED row (by list position), the
+ * gates z, r, the candidate tanh(.) and r * h of models/layers.py:145-152 into `saved`
+ * (impnn_gated_update_rows_saved_floats(max_rows, D) = 4 D max_rows floats, 16-byte aligned);
+ * impnn_gated_update_rows_bwd_saved is impnn_gated_update_rows_bwd without its two recompute GEMM passes (half of its
+ * matrix work): same arguments, same workspace size, plus that buffer - which it CONSUMES (it comes back holding the
+ * pre-activation gradients; a second backward over it needs a second forward). */
+int64_t impnn_gated_update_rows_saved_floats(int64_t max_rows, int32_t D);
+int impnn_gated_update_rows_train(const float* h, const float* agg, const float* Wz, const float* bz,
+                                  const float* Wr, const float* br, const float* Wh, const float* bh,
+                                  const float* gamma, const float* beta, float ln_eps, float* out,
+                                  const int32_t* row_index, const int32_t* n_rows, int64_t max_rows, int32_t D,
+                                  float* saved, impnn_stream_t stream);
+int impnn_gated_update_rows_bwd_saved(const float* h, const float* agg, const float* Wz, const float* bz,
+                                      const float* Wr, const float* br, const float* Wh, const float* bh,
+                                      const float* gamma, float ln_eps, const float* dout, float* dh, float* dagg,
+                                      float* dparams, float* workspace, int64_t workspace_floats,
+                                      const int32_t* row_index, const int32_t* n_rows, int64_t max_rows, int32_t D,
+                                      int32_t accumulate, float* saved, impnn_stream_t stream);
 
 /*  Optimizer step, one launch for all variables (train_viscosity.py:227-230):
  *      g <- g * clipnorm / max(||g||_2, clipnorm)      per variable (tf.clip_by_norm); clipnorm <= 0: off

@@ -72,6 +72,9 @@ SIGNATURES = {
     "impnn_gated_update_bwd": (C.c_int, [vp] * 9 + [f32] + [vp] * 5 + [i64, i64, i32, i32, vp]),
     "impnn_gated_update_rows_bwd_workspace_floats": (i64, [i64, i32]),
     "impnn_gated_update_rows_bwd": (C.c_int, [vp] * 9 + [f32] + [vp] * 5 + [i64, vp, vp, i64, i32, i32, vp]),
+    "impnn_gated_update_rows_saved_floats": (i64, [i64, i32]),
+    "impnn_gated_update_rows_train": (C.c_int, [vp] * 10 + [f32, vp, vp, vp, i64, i32, vp, vp]),
+    "impnn_gated_update_rows_bwd_saved": (C.c_int, [vp] * 9 + [f32] + [vp] * 5 + [i64, vp, vp, i64, i32, i32, vp, vp]),
     "impnn_adam_clipnorm_step": (C.c_int, [vp, vp, i32, i64, f32, f32, f32, f32, f32, vp]),
     "impnn_adam_clipnorm_step_counted": (C.c_int, [vp, vp, i32, vp, f32, f32, f32, f32, f32, vp]),
     "impnn_batch_assemble": (C.c_int, [i32, vp, i32, i32, PP, PP, PP, PP, PP, i32, i32, i32, PP, PP, PP, vp, vp, vp]),

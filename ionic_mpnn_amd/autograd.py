@@ -258,10 +258,12 @@ class GatedUpdate(torch.autograd.Function):
         return _gated_update_backward(ctx.saved_tensors, ctx.eps, dout)
 
 
-def _gated_update_backward(saved, eps, dout, row_list=None):
+def _gated_update_backward(saved, eps, dout, row_list=None, kept=None):
     """(dh, dagg, 8 parameter gradients or None where the kernel added into the sink, None for eps).
     row_list = (row_index, n_rows) of ops.kept_row_index: gradients of those rows only (impnn_gated_update_rows_bwd);
-    dh is zero elsewhere (padding atoms carry no gradient), dagg is undefined there and never read."""
+    dh is zero elsewhere (padding atoms carry no gradient), dagg is undefined there and never read.
+    kept: the buffer the training forward filled (ops.gated_update(.., save=True)) - the backward then skips its
+    recompute passes (impnn_gated_update_rows_bwd_saved) and overwrites the buffer."""
     h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta = saved
     D = h.shape[-1]
     rows = h.numel() // D
@@ -279,7 +281,10 @@ def _gated_update_backward(saved, eps, dout, row_list=None):
     def call(dparams, accumulate):
         common = (ptr(h), ptr(agg), ptr(Wz), ptr(bz), ptr(Wr), ptr(br), ptr(Wh), ptr(bh), ptr(gamma), eps, ptr(dout),
                   ptr(dh), ptr(dagg), ptr(dparams), ptr(ws), wsn)
-        if row_list is not None:
+        if kept is not None:
+            _lib_call(h.device, lib.impnn_gated_update_rows_bwd_saved, *common, ptr(row_list[0]), ptr(row_list[1]),
+                      rows, D, accumulate, ptr(kept))
+        elif row_list is not None:
             _lib_call(h.device, lib.impnn_gated_update_rows_bwd, *common, ptr(row_list[0]), ptr(row_list[1]), rows, D,
                       accumulate)
         else:
@@ -328,7 +333,13 @@ class MessagePassingStep(torch.autograd.Function):
         agg = ops.reduce_scatter_add(m, conn[:, :, 1], h.shape[1])
         del m
         ctx.row_list = (row_index, n_rows) if row_index is not None else None
-        out = ops.gated_update(h, agg, *gu, beta, eps, rows=ctx.row_list)
+        ctx.kept = None
+        if ctx.row_list is not None and h.shape[-1] in (64, 128):
+            # the gates, the candidate and r * h of the kept rows stay for the backward (4 D floats per row and step)
+            # instead of being recomputed there with half of its matrix work
+            out, ctx.kept = ops.gated_update(h, agg, *gu, beta, eps, rows=ctx.row_list, save=True)
+        else:
+            out = ops.gated_update(h, agg, *gu, beta, eps, rows=ctx.row_list)
         ctx.save_for_backward(h, agg, *gu, beta, bond_ids, conn, type_mats)
         ctx.eps = float(eps)
         ctx.graph_key = (conn, bond_ids, _pass["id"])
@@ -339,7 +350,14 @@ class MessagePassingStep(torch.autograd.Function):
     def backward(ctx, dout):
         saved = ctx.saved_tensors
         h, bond_ids, conn, mats = saved[0], saved[10], saved[11], saved[12]
-        dh, dagg, *dparams = _gated_update_backward(saved[:10], ctx.eps, dout, ctx.row_list)
+        kept = ctx.kept
+        if kept is not None:
+            if kept is False:
+                raise RuntimeError("MessagePassingStep: the kept activations were consumed by an earlier backward "
+                                   "(run the forward again instead of retain_graph)")
+            ctx.kept = False
+        dh, dagg, *dparams = _gated_update_backward(saved[:10], ctx.eps, dout, ctx.row_list, kept)
+        del kept
         B, N, D = h.shape
         E, Vb = conn.shape[1], mats.shape[0]
         dmats = ctx.dmats_buf if ctx.dmats_buf is not None else torch.zeros_like(mats)

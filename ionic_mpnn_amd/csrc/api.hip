@@ -601,6 +601,47 @@ int impnn_gated_update_rows_bwd(const float* h, const float* agg, const float* W
                                  max_rows, D, accumulate != 0, as_stream(stream), row_index, n_rows);
 }
 
+int64_t impnn_gated_update_rows_saved_floats(int64_t max_rows, int32_t D) {
+  if (max_rows < 0 || (D != 64 && D != 128)) return 0;
+  return max_rows * 4 * D;
+}
+
+int impnn_gated_update_rows_train(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,
+                                  const float* br, const float* Wh, const float* bh, const float* gamma,
+                                  const float* beta, float ln_eps, float* out, const int32_t* row_index,
+                                  const int32_t* n_rows, int64_t max_rows, int32_t D, float* saved,
+                                  impnn_stream_t stream) {
+  REQUIRE(max_rows >= 0, "bad shape");
+  if (D != 64 && D != 128)
+    return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_train: atom_dim %d (the saving forward covers 64 and 128)", D);
+  if (max_rows == 0) return IMPNN_OK;
+  REQUIRE(h && agg && Wz && bz && Wr && br && Wh && bh && gamma && beta && out && row_index && n_rows && saved,
+          "null pointer");
+  REQUIRE((reinterpret_cast<uintptr_t>(saved) & 15u) == 0, "saved must be 16-byte aligned");
+  REQUIRE(ln_eps >= 0.f, "ln_eps must be >= 0");
+  return launch_gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, ln_eps, out, max_rows, D, as_stream(stream),
+                             row_index, n_rows, saved);
+}
+
+int impnn_gated_update_rows_bwd_saved(const float* h, const float* agg, const float* Wz, const float* bz,
+                                      const float* Wr, const float* br, const float* Wh, const float* bh,
+                                      const float* gamma, float ln_eps, const float* dout, float* dh, float* dagg,
+                                      float* dparams, float* workspace, int64_t workspace_floats,
+                                      const int32_t* row_index, const int32_t* n_rows, int64_t max_rows, int32_t D,
+                                      int32_t accumulate, float* saved, impnn_stream_t stream) {
+  REQUIRE(max_rows >= 0, "bad shape");
+  if (D != 64 && D != 128)
+    return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_bwd_saved: atom_dim %d (covers 64 and 128)", D);
+  REQUIRE(h && agg && Wz && bz && Wr && br && Wh && bh && gamma && dout && dh && dagg && dparams && workspace &&
+          row_index && n_rows && saved, "null pointer");
+  if (workspace_floats < impnn_gated_update_rows_bwd_workspace_floats(max_rows, D))
+    return fail(IMPNN_E_WORKSPACE, "gated_update_rows_bwd_saved: workspace of %lld floats is too small",
+                (long long)workspace_floats);
+  if (max_rows == 0) return IMPNN_OK;
+  return launch_gated_update_bwd(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, ln_eps, dout, dh, dagg, dparams, workspace,
+                                 max_rows, D, accumulate != 0, as_stream(stream), row_index, n_rows, saved);
+}
+
 int impnn_adam_clipnorm_step(const void* var_table, const int64_t* sizes, int32_t n_vars, int64_t step, float lr,
                              float beta1, float beta2, float eps, float clipnorm, impnn_stream_t stream) {
   REQUIRE(n_vars >= 0 && step >= 1, "bad arguments (step counts from 1)");

@@ -42,7 +42,8 @@ int launch_reduce_scatter_add(const float* m, const int32_t* tgt, int tgt_stride
 int launch_gated_update(const float* h, const float* agg, const float* Wz, const float* bz,
                         const float* Wr, const float* br, const float* Wh, const float* bh,
                         const float* gamma, const float* beta, float eps, float* out, int64_t rows,
-                        int D, hipStream_t s, const int32_t* ridx = nullptr, const int32_t* nrows_dev = nullptr);
+                        int D, hipStream_t s, const int32_t* ridx = nullptr, const int32_t* nrows_dev = nullptr,
+                        float* save = nullptr);
 int launch_kept_rows(const int32_t* atom_ids, const int32_t* bond_ids, const int32_t* conn, int32_t* rows_out, int B,
                      int N, int E, int Vb, hipStream_t s);
 int launch_row_index_fill(const int32_t* r, const int32_t* incl, int32_t* idx, int32_t* count, int B, int N,
@@ -93,7 +94,7 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
                             const float* br, const float* Wh, const float* bh, const float* gamma, float eps,
                             const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
                             int64_t rows, int D, int accumulate, hipStream_t s, const int32_t* ridx = nullptr,
-                            const int32_t* nrows_dev = nullptr);
+                            const int32_t* nrows_dev = nullptr, float* saved = nullptr);
 int launch_adam_clipnorm(const void* table, const void* sizes, int n_vars, int64_t step, int64_t* step_dev, float lr,
                          float b1, float b2, float eps, float clipnorm, hipStream_t s);
 

@@ -794,7 +794,11 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
     const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
     const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float* __restrict__ out, int64_t rows,
-    const int32_t* __restrict__ ridx, const int32_t* __restrict__ nrows_dev, int tile_rows) {
+    const int32_t* __restrict__ ridx, const int32_t* __restrict__ nrows_dev, int tile_rows,
+    float* __restrict__ save) {
+  // save (optional; the training forward, impnn_gated_update_rows_train): what the backward would otherwise recompute
+  // with two of its four GEMM passes, by LIST POSITION - [z | r | tanh(t)] in 3 D floats per row, and from float
+  // 3 D max_rows on r * h (the layout gated_update_bwd_wide16_kernel keeps its pre-activation gradients in).
   // ridx / nrows_dev (optional): the kernel works on the rows ridx[0 .. *nrows_dev) of h / agg / out instead of on
   // rows [0, rows) - the model's layered path skips padding atoms this way (impnn_kept_row_index); the grid is
   // sized for `rows`, workgroups beyond the list leave at once.
@@ -927,7 +931,14 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
       for (int g = 0; g < 4; ++g) {
         const int rl = 16 * wave + 4 * q + g, f = 16 * (fg * NL + TL) + a;
         z[TL][g] = fsig(z[TL][g]);
-        rhs[rl * LDR + f] = fsig(rg[TL][g]) * cs[rl * LDC + f];
+        const float rv = fsig(rg[TL][g]), rhv = rv * cs[rl * LDC + f];
+        rhs[rl * LDR + f] = rhv;
+        if (save && row0 + rl < rows) {
+          float* sv = save + (row0 + rl) * 3 * D + f;
+          sv[0] = z[TL][g];
+          sv[D] = rv;
+          save[max_rows * 3 * D + (row0 + rl) * D + f] = rhv;
+        }
       }
   }
   f32x4_t tt[NL];
@@ -997,7 +1008,10 @@ __global__ __launch_bounds__(1024) void gated_update_wide16_kernel(
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float hv = cs[(16 * wave + 4 * q + g) * LDC + 16 * (fg * NL + TL) + a];
-        const float n = (1.0f - z[TL][g]) * hv + z[TL][g] * ftanh(tt[TL][g]);
+        const float tv = ftanh(tt[TL][g]);
+        const float n = (1.0f - z[TL][g]) * hv + z[TL][g] * tv;
+        if (save && row0 + 16 * wave + 4 * q + g < rows)
+          save[(row0 + 16 * wave + 4 * q + g) * 3 * D + 2 * D + 16 * (fg * NL + TL) + a] = tv;
         tt[TL][g] = n;
         sum[g] += n;
       }
@@ -1418,8 +1432,10 @@ int launch_row_index_fill(const int32_t* r, const int32_t* incl, int32_t* idx, i
 int launch_gated_update(const float* h, const float* agg, const float* Wz, const float* bz,
                         const float* Wr, const float* br, const float* Wh, const float* bh,
                         const float* gamma, const float* beta, float eps, float* out, int64_t rows,
-                        int D, hipStream_t s, const int32_t* ridx, const int32_t* nrows_dev) {
+                        int D, hipStream_t s, const int32_t* ridx, const int32_t* nrows_dev, float* save) {
   if (rows == 0) return IMPNN_OK;
+  if (save && !(ridx && (D == 64 || D == 128)))
+    return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_train: atom_dim %d (the saving forward covers 64 and 128)", D);
   if (ridx && !(D == 32 || (D % 64 == 0 && D <= 128)))
     return fail(IMPNN_E_UNSUPPORTED, "gated_update: a row list is supported for atom_dim 32, 64 and 128 only");
   if (ridx && D == 32 && !(aligned16(h) && aligned16(agg) && aligned16(out)))
@@ -1453,7 +1469,7 @@ int launch_gated_update(const float* h, const float* agg, const float* Wz, const
         (void)hipFuncSetAttribute((const void*)gated_update_wide16_kernel<NT_>,                                     \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)l16);                            \
         gated_update_wide16_kernel<NT_><<<blocks16, 1024, l16, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, out, \
-                                                                   rows, ridx, nrows_dev, tile_rows);               \
+                                                                   rows, ridx, nrows_dev, tile_rows, save);         \
         return check_launch("gated_update_wide16");                                                                 \
       } while (0)
       if (D == 64) WIDE16(4);

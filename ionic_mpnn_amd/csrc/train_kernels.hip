@@ -1345,7 +1345,9 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_d32_kernel(
 // LDS: c = [h|agg] (later [dzp|drp]), r*h (later dtp), two slice buffers, LayerNorm row partials, column sums.
 // Outputs and partial sums are those of gated_update_bwd_kernel.
 // ---------------------------------------------------------------------------------------
-template <int NT>
+// SAVED: dpre / rh_out arrive holding what the training forward kept (gated_update_wide16_kernel's `save`: z, r, tanh(t)
+// in the slots that receive dzp, drp, dtp; r * h) - the recompute passes P1 and P2, half of the kernel's MFMAs, go.
+template <int NT, bool SAVED>
 __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     const float* __restrict__ h, const float* __restrict__ agg, const float* __restrict__ Wz,
     const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
@@ -1438,6 +1440,10 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     }
     const float* crow = cs + (16 * rt + a) * LDC + 4 * q;
     const float* rrow = rhs + (16 * rt + a) * LDR + 4 * q;
+    f32x4_t tt[NL];
+    if constexpr (SAVED) {
+      __syncthreads();  // the tile of [h | agg] is in LDS
+    } else {
     // ---- P1: z, r
     f32x4_t z[NL], rr[NL];
 #pragma unroll
@@ -1498,7 +1504,6 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
         }
       }
     // ---- P2: t
-    f32x4_t tt[NL];
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL) {
       const float b2 = bh[16 * (fg * NL + TL) + a];
@@ -1532,6 +1537,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       if (u + 1 < 2 * NT) park(nxt, D);
       __syncthreads();
     }
+    }
     // ---- blend, LayerNorm forward statistics
     relane();
     f32x4_t xh[NL];
@@ -1542,11 +1548,13 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       for (int g = 0; g < 4; ++g) {
         const int rl = 16 * rt + 4 * q + g, f = 16 * (fg * NL + TL) + a;
         const float hv = cs[rl * LDC + f];
-        const float tv = tanhf(tt[TL][g]);
+        float tv;
+        if constexpr (SAVED) tv = rl < nrt ? dpre_t[rl * 3 * D + 2 * D + f] : 0.f;
+        else tv = tanhf(tt[TL][g]);
         const float zz = rl < nrt ? dpre_t[rl * 3 * D + f] : 0.f;
         xh[TL][g] = (1.0f - zz) * hv + zz * tv;
         sum[g] += xh[TL][g];
-        if (rl < nrt) dpre_t[rl * 3 * D + 2 * D + f] = tv;
+        if (!SAVED && rl < nrt) dpre_t[rl * 3 * D + 2 * D + f] = tv;
       }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -2735,16 +2743,20 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
                             const float* br, const float* Wh, const float* bh, const float* gamma, float eps,
                             const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
                             int64_t rows, int D, int accumulate, hipStream_t s, const int32_t* ridx,
-                            const int32_t* nrows_dev) {
+                            const int32_t* nrows_dev, float* saved) {
   if (D > kBlock || kBlock % D != 0)
     return fail(IMPNN_E_UNSUPPORTED, "gated_update_bwd: atom_dim %d must divide %d", D, kBlock);
   if (ridx && D != 64 && D != 128)
     return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_bwd: atom_dim %d (the row-list form covers 64 and 128)", D);
   const int R = kBlock / D;
   const int nblk = gu_main_blocks(rows, D), nchunk = gu_chunks(rows, D);
-  float* dpre = workspace;
+  if (saved && !(ridx && (D == 64 || D == 128)))
+    return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_bwd_saved: atom_dim %d (covers 64 and 128)", D);
+  // saved (impnn_gated_update_rows_train's buffer, [z | r | tanh(t)] then r * h): used in place of the workspace's
+  // first two regions and CONSUMED - it leaves holding the pre-activation gradients
+  float* dpre = saved ? saved : workspace;
   float* rh = dpre + rows * 3 * D;
-  float* small = rh + rows * D;
+  float* small = workspace + rows * 4 * D;
   float* gpart = small + (int64_t)nblk * 5 * D;
   float* wt = gpart + (int64_t)3 * nchunk * 2 * D * D;
   float* hc = ridx ? wt + (int64_t)3 * 2 * D * D : nullptr;  // compact copies of the listed rows (row-list form)
@@ -2754,7 +2766,7 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   const size_t wlds = sizeof(float) * (size_t)3 * 2 * D * (D + 1);
   const bool al16 = ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(agg) | reinterpret_cast<uintptr_t>(dout) |
                       reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(dagg) |
-                      reinterpret_cast<uintptr_t>(workspace)) & 15u) == 0;
+                      reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(dpre)) & 15u) == 0;
   if (ridx && !al16) return fail(IMPNN_E_BADARG, "gated_update_rows_bwd: tensors must be 16B aligned");
   if ((D == 64 || D == 128) && al16) {
     const size_t lw = sizeof(float) * ((size_t)64 * (2 * D + 4) + 64 * (D + 4) + 2 * 16 * 2 * D + 4 * 256 + 4 * 5 * D) + 64 * sizeof(int32_t);
@@ -2764,17 +2776,20 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
     // (zeroing is a kernel, not hipMemsetAsync: the call may sit inside a captured graph)
     zero_floats_kernel<<<grid_for((int64_t)nblk * 5 * D), kBlock, 0, s>>>(small, (int64_t)nblk * 5 * D);
     if (int rc = check_launch("zero_floats")) return rc;
+#define BWD16(NT_, SV_)                                                                                              \
+    do {                                                                                                              \
+      (void)hipFuncSetAttribute((const void*)gated_update_bwd_wide16_kernel<NT_, SV_>,                                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);                                 \
+      gated_update_bwd_wide16_kernel<NT_, SV_><<<nb, 1024, lw, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, \
+                                                                   dagg, dpre, rh, small, rows, ridx, nrows_dev, hc,  \
+                                                                   aggc, tile_rows);                                  \
+    } while (0)
     if (D == 64) {
-      (void)hipFuncSetAttribute((const void*)gated_update_bwd_wide16_kernel<4>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
-      gated_update_bwd_wide16_kernel<4><<<nb, 1024, lw, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, dagg,
-                                                            dpre, rh, small, rows, ridx, nrows_dev, hc, aggc, tile_rows);
+      if (saved) BWD16(4, true); else BWD16(4, false);
     } else {
-      (void)hipFuncSetAttribute((const void*)gated_update_bwd_wide16_kernel<8>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);
-      gated_update_bwd_wide16_kernel<8><<<nb, 1024, lw, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, dagg,
-                                                            dpre, rh, small, rows, ridx, nrows_dev, hc, aggc, tile_rows);
+      if (saved) BWD16(8, true); else BWD16(8, false);
     }
+#undef BWD16
   } else if (D == 32 && al16) {
     const size_t l32 = sizeof(float) * ((size_t)3 * 32 * kBwT + 3 * 64 * kBwN + 4 * 32 + 4 * 5 * 32);
     if (l32 > 48 * 1024)

@@ -248,9 +248,11 @@ def kept_row_index(atom_ids, bond_ids, conn, Vb):
     return idx, cnt
 
 
-def gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps=LN_EPS, rows=None):
+def gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps=LN_EPS, rows=None, save=False):
     """GatedUpdate.call, models/layers.py:142-156.  ``rows`` = (row_index, n_rows) of kept_row_index: only those rows
-    of the output are computed (model-internal use: padding atoms; the rest of ``out`` is undefined)."""
+    of the output are computed (model-internal use: padding atoms; the rest of ``out`` is undefined).
+    ``save`` (with ``rows``, atom_dim 64 / 128; the training forward): returns (out, saved) - the gates, the candidate
+    and r * h of the listed rows for impnn_gated_update_rows_bwd_saved."""
     if _wants_grad(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta):
         from . import autograd
         return autograd.GatedUpdate.apply(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps)
@@ -265,6 +267,13 @@ def gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps=LN_EPS, rows=N
     out = torch.empty_like(ts[0])
     nrows = ts[0].numel() // D
     with torch.cuda.device(h.device):
+        if save:
+            lib = _lib.load()
+            saved = torch.empty(int(lib.impnn_gated_update_rows_saved_floats(nrows, D)), dtype=torch.float32,
+                                device=h.device)
+            check(lib.impnn_gated_update_rows_train(*[ptr(t) for t in ts], float(eps), ptr(out), ptr(rows[0]),
+                                                    ptr(rows[1]), nrows, D, ptr(saved), stream_ptr()))
+            return out, saved
         if rows is not None and D in (32, 64, 128):
             check(_lib.load().impnn_gated_update_rows(*[ptr(t) for t in ts], float(eps), ptr(out), ptr(rows[0]),
                                                       ptr(rows[1]), nrows, D, stream_ptr()))
