@@ -350,7 +350,10 @@ int impnn_global_sum_pool_bwd(const float* dpooled, const int32_t* atom_ids, flo
 int64_t impnn_bmm_message_typed_bwd_workspace_bytes(int32_t B, int32_t E, int32_t Vb);
 /*  impnn_bmm_message_typed (forward) over the same type-sorted edge segments, any D <= 128: A[type] staged in LDS,
  *  one workgroup per <= 64 edges of a type.  Same workspace (and size query) as the backward entry: a sort made here
- *  serves the backward call of the layer and every other layer of the ion (sorted_ready = 1 there). */
+ *  serves the backward call of the layer and every other layer of the ion (sorted_ready = 1 there).
+ *  sorted_ready | 2: `messages` is the buffer an earlier call on the SAME (bond_ids, conn) wrote and nothing else
+ *  touched since - the zero rows of masked / out-of-range edges (models/layers.py:114-115) are still in place and
+ *  the pass that writes them is skipped (a training loop that keeps one message buffer per ion for all its layers). */
 int impnn_bmm_message_typed_sorted(const float* h, const int32_t* bond_ids, const int32_t* conn,
                                    const float* type_mats, float* messages, void* workspace, int64_t workspace_bytes,
                                    int32_t B, int32_t N, int32_t E, int32_t D, int32_t Vb, int32_t sorted_ready,
@@ -405,7 +408,8 @@ int impnn_gated_update_rows_bwd(const float* h, const float* agg, const float* W
  * (impnn_gated_update_rows_saved_floats(max_rows, D) = 4 D max_rows floats, 16-byte aligned);
  * impnn_gated_update_rows_bwd_saved is impnn_gated_update_rows_bwd without its two recompute GEMM passes (half of its
  * matrix work): same arguments, same workspace size, plus that buffer - which it CONSUMES (it comes back holding the
- * pre-activation gradients; a second backward over it needs a second forward). */
+ * pre-activation gradients; a second backward over it needs a second forward).  Both take row_index = n_rows = NULL
+ * for "all max_rows rows" (the small batches a training loop does not build a list for). */
 int64_t impnn_gated_update_rows_saved_floats(int64_t max_rows, int32_t D);
 int impnn_gated_update_rows_train(const float* h, const float* agg, const float* Wz, const float* bz,
                                   const float* Wr, const float* br, const float* Wh, const float* bh,

@@ -272,7 +272,7 @@ def _gated_update_backward(saved, eps, dout, row_list=None, kept=None):
     dh = torch.zeros_like(h) if row_list is not None else torch.empty_like(h)
     dagg = torch.empty_like(agg)
     P = int(lib.impnn_gated_update_param_floats(D))
-    if row_list is not None:
+    if row_list is not None or kept is not None:
         wsn = int(lib.impnn_gated_update_rows_bwd_workspace_floats(rows, D))
     else:
         wsn = int(lib.impnn_gated_update_bwd_workspace_floats(rows, D))
@@ -282,8 +282,8 @@ def _gated_update_backward(saved, eps, dout, row_list=None, kept=None):
         common = (ptr(h), ptr(agg), ptr(Wz), ptr(bz), ptr(Wr), ptr(br), ptr(Wh), ptr(bh), ptr(gamma), eps, ptr(dout),
                   ptr(dh), ptr(dagg), ptr(dparams), ptr(ws), wsn)
         if kept is not None:
-            _lib_call(h.device, lib.impnn_gated_update_rows_bwd_saved, *common, ptr(row_list[0]), ptr(row_list[1]),
-                      rows, D, accumulate, ptr(kept))
+            ri, rn = (ptr(row_list[0]), ptr(row_list[1])) if row_list is not None else (None, None)
+            _lib_call(h.device, lib.impnn_gated_update_rows_bwd_saved, *common, ri, rn, rows, D, accumulate, ptr(kept))
         elif row_list is not None:
             _lib_call(h.device, lib.impnn_gated_update_rows_bwd, *common, ptr(row_list[0]), ptr(row_list[1]), rows, D,
                       accumulate)
@@ -329,13 +329,19 @@ class MessagePassingStep(torch.autograd.Function):
         and their gradient is zero (include/impnn.h, impnn_gated_update_rows[_bwd])."""
         h, type_mats, bond_ids, conn = f32c(h), f32c(type_mats), i32c(bond_ids), i32c(conn)
         gu = [f32c(t) for t in (Wz, bz, Wr, br, Wh, bh, gamma)]
-        m = ops.bmm_message_typed(h, bond_ids, conn, type_mats)
+        if h.shape[-1] != 32:
+            # one message buffer per ion and pass (the Reduce behind each layer consumes it at once)
+            buf, reused = ops.message_scratch(conn, bond_ids, h.shape[0], conn.shape[1], h.shape[-1])
+            m = ops.bmm_message_typed(h, bond_ids, conn, type_mats, out=buf, out_reused=reused)
+            del buf
+        else:
+            m = ops.bmm_message_typed(h, bond_ids, conn, type_mats)
         agg = ops.reduce_scatter_add(m, conn[:, :, 1], h.shape[1])
         del m
         ctx.row_list = (row_index, n_rows) if row_index is not None else None
         ctx.kept = None
-        if ctx.row_list is not None and h.shape[-1] in (64, 128):
-            # the gates, the candidate and r * h of the kept rows stay for the backward (4 D floats per row and step)
+        if h.shape[-1] in (64, 128):
+            # the gates, the candidate and r * h of the (kept) rows stay for the backward (4 D floats per row and step)
             # instead of being recomputed there with half of its matrix work
             out, ctx.kept = ops.gated_update(h, agg, *gu, beta, eps, rows=ctx.row_list, save=True)
         else:

@@ -499,7 +499,7 @@ int impnn_bmm_message_typed_sorted(const float* h, const int32_t* bond_ids, cons
     return fail(IMPNN_E_WORKSPACE, "bmm_message_typed_sorted: workspace of %lld bytes is too small",
                 (long long)workspace_bytes);
   return launch_bmm_message_typed_sorted(h, bond_ids, conn, type_mats, messages, static_cast<int32_t*>(workspace), B,
-                                         N, E, D, Vb, sorted_ready != 0, as_stream(stream));
+                                         N, E, D, Vb, sorted_ready & 3, as_stream(stream));
 }
 
 int impnn_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn,
@@ -615,8 +615,8 @@ int impnn_gated_update_rows_train(const float* h, const float* agg, const float*
   if (D != 64 && D != 128)
     return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_train: atom_dim %d (the saving forward covers 64 and 128)", D);
   if (max_rows == 0) return IMPNN_OK;
-  REQUIRE(h && agg && Wz && bz && Wr && br && Wh && bh && gamma && beta && out && row_index && n_rows && saved,
-          "null pointer");
+  REQUIRE(h && agg && Wz && bz && Wr && br && Wh && bh && gamma && beta && out && saved, "null pointer");
+  REQUIRE((row_index != nullptr) == (n_rows != nullptr), "row_index and n_rows: both or neither");
   REQUIRE((reinterpret_cast<uintptr_t>(saved) & 15u) == 0, "saved must be 16-byte aligned");
   REQUIRE(ln_eps >= 0.f, "ln_eps must be >= 0");
   return launch_gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, ln_eps, out, max_rows, D, as_stream(stream),
@@ -632,8 +632,9 @@ int impnn_gated_update_rows_bwd_saved(const float* h, const float* agg, const fl
   REQUIRE(max_rows >= 0, "bad shape");
   if (D != 64 && D != 128)
     return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_bwd_saved: atom_dim %d (covers 64 and 128)", D);
-  REQUIRE(h && agg && Wz && bz && Wr && br && Wh && bh && gamma && dout && dh && dagg && dparams && workspace &&
-          row_index && n_rows && saved, "null pointer");
+  REQUIRE(h && agg && Wz && bz && Wr && br && Wh && bh && gamma && dout && dh && dagg && dparams && workspace && saved,
+          "null pointer");
+  REQUIRE((row_index != nullptr) == (n_rows != nullptr), "row_index and n_rows: both or neither");
   if (workspace_floats < impnn_gated_update_rows_bwd_workspace_floats(max_rows, D))
     return fail(IMPNN_E_WORKSPACE, "gated_update_rows_bwd_saved: workspace of %lld floats is too small",
                 (long long)workspace_floats);

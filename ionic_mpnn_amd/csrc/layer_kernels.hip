@@ -1434,7 +1434,7 @@ int launch_gated_update(const float* h, const float* agg, const float* Wz, const
                         const float* gamma, const float* beta, float eps, float* out, int64_t rows,
                         int D, hipStream_t s, const int32_t* ridx, const int32_t* nrows_dev, float* save) {
   if (rows == 0) return IMPNN_OK;
-  if (save && !(ridx && (D == 64 || D == 128)))
+  if (save && !(D == 64 || D == 128))
     return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_train: atom_dim %d (the saving forward covers 64 and 128)", D);
   if (ridx && !(D == 32 || (D % 64 == 0 && D <= 128)))
     return fail(IMPNN_E_UNSUPPORTED, "gated_update: a row list is supported for atom_dim 32, 64 and 128 only");

@@ -1354,7 +1354,11 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma, float eps,
     const float* __restrict__ dout, float* __restrict__ dh, float* __restrict__ dagg, float* __restrict__ dpre,
     float* __restrict__ rh_out, float* __restrict__ small, int64_t rows, const int32_t* __restrict__ ridx,
-    const int32_t* __restrict__ nrows_dev, float* __restrict__ hc, float* __restrict__ aggc, int tile_rows) {
+    const int32_t* __restrict__ nrows_dev, float* __restrict__ hc, float* __restrict__ aggc, int tile_rows,
+    const float* __restrict__ wt) {
+  // wt = [Wz^T | Wr^T | Wh^T], each D x 2D (transpose3_kernel, once per call): the slices of P3 / P4 are then rows of
+  // 2D consecutive floats - fetched and parked like the forward's (coalesced 4-byte loads two slices ahead, one
+  // conflict-free 16-byte LDS store, a ring of three buffers) instead of 64-byte pieces and 4-way conflicting stores.
   // tile_rows = 64, or 16 for launches with too few rows to fill the chip with 64-row tiles (the reference trains with
   // 32 pairs per step): then only the four waves of row tile 0 - one per SIMD - run the four GEMM passes.
   // ridx / nrows_dev (optional): the kernel works on the rows ridx[0 .. *nrows_dev) of h / agg / dout / dh / dagg
@@ -1369,10 +1373,11 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
   extern __shared__ __align__(16) float smem[];
   float* cs = smem;                   // 64 x LDC
   float* rhs = cs + 64 * LDC;         // 64 x LDR
-  float* ws = rhs + 64 * LDR;         // 2 x 16 x LDW, element (k = 4*qq + r, column c) at ((qq * LDW + c) * 4 + r)
-  float* part = ws + 2 * 16 * LDW;    // 4 x (4 x 64): LayerNorm row partials (sum, sq. deviation, m1, m2)
-  float* red = part + 4 * 256;        // 4 row tiles x 5 x D column sums
-  int32_t* grow_s = reinterpret_cast<int32_t*>(red + 4 * 5 * D);  // 64 global rows of the tile
+  float* ws = rhs + 64 * LDR;         // 3 x 16 x LDW, element (k = 4*qq + r, column c) at ((qq * LDW + c) * 4 + r)
+  float* part = ws + 3 * 16 * LDW;    // 4 x (4 x 64): LayerNorm row partials (sum, sq. deviation, m1, m2)
+  float* red = ws;                    // 4 row tiles x 5 x D column sums (after the last tile: the slices are dead)
+  static_assert(4 * 5 * D <= 3 * 16 * LDW, "column sums alias the slice ring");
+  int32_t* grow_s = reinterpret_cast<int32_t*>(part + 4 * 256);  // 64 global rows of the tile
   const int tid = threadIdx.x;
   int a = tid & 15, q = (tid >> 4) & 3, fg = (tid >> 6) & 3, rt = tid >> 8;  // lane = 16 q + a, wave = 4 rt + fg: a row tile's four waves sit on four SIMDs
   const bool act = 16 * (tid >> 8) < tile_rows;  // (wave-uniform) does this wave's row tile hold rows of the tile?
@@ -1621,7 +1626,7 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       m2[g] = ((part[768 + rl] + part[832 + rl]) + (part[896 + rl] + part[960 + rl])) * (1.0f / D);
     }
     relane();
-    f32x4_t dzp[NL], dhA[NL];
+    f32x4_t dhA[NL];
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL)
 #pragma unroll
@@ -1630,14 +1635,14 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
         const float hv = cs[rl * LDC + f];
         const float dn = inv[g] * (dxh[TL][g] - m1[g] - xh[TL][g] * m2[g]);
         const float zz = rl < nrt ? dpre_t[rl * 3 * D + f] : 0.f, tv = rl < nrt ? dpre_t[rl * 3 * D + 2 * D + f] : 0.f;
-        dzp[TL][g] = dn * (tv - hv) * zz * (1.0f - zz);
+        const float dzp = dn * (tv - hv) * zz * (1.0f - zz);
         const float dtp = dn * zz * (1.0f - tv * tv);
         dhA[TL][g] = dy[TL][g] + dn * (1.0f - zz);
-        s_bz[TL] += dzp[TL][g];
+        s_bz[TL] += dzp;
         s_bh[TL] += dtp;
         rhs[rl * LDR + f] = dtp;  // A operand of P3
         if (rl < nrt) {
-          dpre_t[rl * 3 * D + f] = dzp[TL][g];
+          dpre_t[rl * 3 * D + f] = dzp;
           dpre_t[rl * 3 * D + 2 * D + f] = dtp;
         }
       }
@@ -1645,100 +1650,96 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     f32x4_t lo[NL], hi[NL];
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL) lo[TL] = hi[TL] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    auto fetch3 = [&](int u) {
-      const int tid = opaque(threadIdx.x);  // slice u of Wh^T: (k = j - 16u, column i') = Wh[i'][16u + k]
+    // slices of a transposed kernel (rows k0 .. k0 + 15 of a D x 2D block of wt): thread (qq, c) moves rows 4qq .. 4qq + 3
+    // of column c
+    constexpr int kIT = 4 * 2 * D;
+    static_assert(kIT <= 1024, "one item per thread");
+    auto fetchT = [&](const float* base, int k0, f32x4_t& pre4) {
+      const int t_ = opaque(threadIdx.x);
+      if (t_ < kIT) {
+        const int qq = t_ / (2 * D), c = t_ - qq * (2 * D);
+        const float* src = base + (int64_t)(k0 + 4 * qq) * (2 * D) + c;
 #pragma unroll
-      for (int i = 0; i < kPre; ++i) {
-        const int t = tid + 1024 * i;
-        pre[i] = Wh[(int64_t)(t >> 4) * D + 16 * u + (t & 15)];
+        for (int r = 0; r < 4; ++r) pre4[r] = src[r * 2 * D];
       }
     };
-    fetch3(0);
-    park_t(ws);
-    __syncthreads();
-#pragma unroll 1
-    for (int u = 0; u < NT; ++u) {
-      float* cur = ws + (u & 1) * 16 * LDW;
-      float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
-      if (u + 1 < NT) fetch3(u + 1);
-      if (act) {
-      const f32x4_t av = ldv4(rrow + 16 * u);
+    auto parkT = [&](float* dst, const f32x4_t& pre4) {
+      const int t_ = opaque(threadIdx.x);
+      if (t_ < kIT) {
+        const int qq = t_ / (2 * D), c = t_ - qq * (2 * D);
+        *reinterpret_cast<f32x4_t*>(dst + ((qq * LDW + c) << 2)) = pre4;
+      }
+    };
+    struct OpsT {
+      f32x4_t av, b0[NL], b1[NL];
+    };
+    auto readT = [&](const float* arow, int u, OpsT& o) {
+      const float* cur = ws + (u % 3) * 16 * LDW;
+      o.av = ldv4(arow + 16 * u);
 #pragma unroll
       for (int TL = 0; TL < NL; ++TL) {
         const int col = 16 * (fg * NL + TL) + a;
-        const f32x4_t b0 = ldv4(cur + ((q * LDW + col) << 2)), b1 = ldv4(cur + ((q * LDW + D + col) << 2));
+        o.b0[TL] = ldv4(cur + ((q * LDW + col) << 2));
+        o.b1[TL] = ldv4(cur + ((q * LDW + D + col) << 2));
+      }
+    };
+    auto mmaT = [&](const OpsT& o) {
+      if (!act) return;
+#pragma unroll
+      for (int TL = 0; TL < NL; ++TL)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          lo[TL] = mfma_f32(av[r], b0[r], lo[TL]);
-          hi[TL] = mfma_f32(av[r], b1[r], hi[TL]);
+          lo[TL] = mfma_f32(o.av[r], o.b0[TL][r], lo[TL]);
+          hi[TL] = mfma_f32(o.av[r], o.b1[TL][r], hi[TL]);
         }
-      }
-      }
-      if (u + 1 < NT) park_t(nxt);
+    };
+    // [lo | hi] += A (rows of `arow`, 16 nsl contraction indices) x the nsl slices that start at `base`
+    auto passT = [&](const float* base, int nsl, const float* arow) {
+      f32x4_t preA, preB;
+      fetchT(base, 0, preA);
+      fetchT(base, 16, preB);
+      parkT(ws, preA);
       __syncthreads();
-    }
+#pragma unroll 1
+      for (int u = 0; u < nsl; u += 2) {
+        OpsT o;
+        if (u + 2 < nsl) fetchT(base, 16 * (u + 2), preA);
+        readT(arow, u, o);
+        __builtin_amdgcn_sched_barrier(0);
+        parkT(ws + ((u + 1) % 3) * 16 * LDW, preB);
+        __builtin_amdgcn_sched_barrier(0);
+        mmaT(o);
+        __syncthreads();
+        if (u + 3 < nsl) fetchT(base, 16 * (u + 3), preB);
+        readT(arow, u + 1, o);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 2 < nsl) parkT(ws + ((u + 2) % 3) * 16 * LDW, preA);
+        __builtin_amdgcn_sched_barrier(0);
+        mmaT(o);
+        __syncthreads();
+      }
+    };
+    passT(wt + (int64_t)2 * 2 * D * D, NT, rrow);
     relane();
-    f32x4_t daA[NL];
+    // lo / hi go on as P4's accumulators: they start from the direct terms (dh: dy + dn (1 - z) + r dc2_lo, dagg: dc2_hi).
+    // c = [h | agg] becomes [dzp | drp] element by element - a thread reads and replaces its own h, nobody reads agg
+    // after P2 - so only the barrier in front of P4's first operand read is needed.
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int rl = 16 * rt + 4 * q + g, f = 16 * (fg * NL + TL) + a;
         const float hv = cs[rl * LDC + f], rv = rl < nrt ? dpre_t[rl * 3 * D + D + f] : 0.f;
+        const float dzp = rl < nrt ? dpre_t[rl * 3 * D + f] : 0.f;  // parked above
         const float drp = lo[TL][g] * hv * rv * (1.0f - rv);
-        dhA[TL][g] = fmaf(lo[TL][g], rv, dhA[TL][g]);
-        daA[TL][g] = hi[TL][g];
         s_br[TL] += drp;
-        lo[TL][g] = drp;  // parked below, after every wave is done with h
         if (rl < nrt) dpre_t[rl * 3 * D + D + f] = drp;
-      }
-    __syncthreads();  // all reads of c = [h|agg] are done: it becomes [dzp|drp]
-    relane();
-#pragma unroll
-    for (int TL = 0; TL < NL; ++TL)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int rl = 16 * rt + 4 * q + g, f = 16 * (fg * NL + TL) + a;
-        cs[rl * LDC + f] = dzp[TL][g];
-        cs[rl * LDC + D + f] = lo[TL][g];
+        cs[rl * LDC + f] = dzp;
+        cs[rl * LDC + D + f] = drp;
+        lo[TL][g] = fmaf(lo[TL][g], rv, dhA[TL][g]);
       }
     // ---- P4: dc = [dzp|drp] [Wz^T ; Wr^T]
-#pragma unroll
-    for (int TL = 0; TL < NL; ++TL) lo[TL] = hi[TL] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    auto fetch4 = [&](int u) {
-      const int tid = opaque(threadIdx.x);
-      const float* W = u < NT ? Wz : Wr;
-      const int u0 = u < NT ? u : u - NT;
-#pragma unroll
-      for (int i = 0; i < kPre; ++i) {
-        const int t = tid + 1024 * i;
-        pre[i] = W[(int64_t)(t >> 4) * D + 16 * u0 + (t & 15)];
-      }
-    };
-    fetch4(0);
-    park_t(ws);
-    __syncthreads();
-#pragma unroll 1
-    for (int u = 0; u < 2 * NT; ++u) {
-      float* cur = ws + (u & 1) * 16 * LDW;
-      float* nxt = ws + ((u + 1) & 1) * 16 * LDW;
-      if (u + 1 < 2 * NT) fetch4(u + 1);
-      if (act) {
-      const f32x4_t av = ldv4(crow + 16 * u);
-#pragma unroll
-      for (int TL = 0; TL < NL; ++TL) {
-        const int col = 16 * (fg * NL + TL) + a;
-        const f32x4_t b0 = ldv4(cur + ((q * LDW + col) << 2)), b1 = ldv4(cur + ((q * LDW + D + col) << 2));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          lo[TL] = mfma_f32(av[r], b0[r], lo[TL]);
-          hi[TL] = mfma_f32(av[r], b1[r], hi[TL]);
-        }
-      }
-      }
-      if (u + 1 < 2 * NT) park_t(nxt);
-      __syncthreads();
-    }
+    passT(wt, 2 * NT, crow);  // [Wz^T ; Wr^T] are consecutive rows of wt
     relane();
 #pragma unroll
     for (int TL = 0; TL < NL; ++TL)
@@ -1747,8 +1748,8 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
         const int rl = 16 * rt + 4 * q + g, f = 16 * (fg * NL + TL) + a;
         if (rl < nrt) {
           const int64_t dst = (int64_t)grow_s[rl] * D + f;
-          dh[dst] = dhA[TL][g] + lo[TL][g];
-          dagg[dst] = daA[TL][g] + hi[TL][g];
+          dh[dst] = lo[TL][g];
+          dagg[dst] = hi[TL][g];
         }
       }
   }
@@ -2595,10 +2596,12 @@ int launch_bmm_message_typed_sorted(const float* h, const int32_t* bond_ids, con
   if (Vb > kMaxTypes) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed_sorted: Vb=%d too large", Vb);
   if (D > 128) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed_sorted: D=%d > 128", D);
   const int64_t BE = (int64_t)B * E;
-  if (!sorted_ready)
+  if (!(sorted_ready & 1))
     if (int rc = launch_edge_type_sort(bond_ids, conn, workspace, B, N, E, Vb, s)) return rc;
-  zero_invalid_messages_kernel<<<grid_for(BE * D), kBlock, 0, s>>>(conn, bond_ids, m, BE, N, D, Vb);
-  if (int rc = check_launch("zero_invalid_messages")) return rc;
+  if (!(sorted_ready & 2)) {  // (bit 1: the caller's buffer still holds the zero rows of an earlier call on this batch)
+    zero_invalid_messages_kernel<<<grid_for(BE * D), kBlock, 0, s>>>(conn, bond_ids, m, BE, N, D, Vb);
+    if (int rc = check_launch("zero_invalid_messages")) return rc;
+  }
   const int32_t* start = workspace + (Vb + 1);
   const int32_t* segbase = workspace + 3 * (Vb + 1);
   const int32_t* order = workspace + 4 * (Vb + 1);
@@ -2750,7 +2753,8 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
     return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_bwd: atom_dim %d (the row-list form covers 64 and 128)", D);
   const int R = kBlock / D;
   const int nblk = gu_main_blocks(rows, D), nchunk = gu_chunks(rows, D);
-  if (saved && !(ridx && (D == 64 || D == 128)))
+  int nsmall = nblk;  // slices of `small` the reduction reads
+  if (saved && !(D == 64 || D == 128))
     return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_bwd_saved: atom_dim %d (covers 64 and 128)", D);
   // saved (impnn_gated_update_rows_train's buffer, [z | r | tanh(t)] then r * h): used in place of the workspace's
   // first two regions and CONSUMED - it leaves holding the pre-activation gradients
@@ -2767,22 +2771,22 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   const bool al16 = ((reinterpret_cast<uintptr_t>(h) | reinterpret_cast<uintptr_t>(agg) | reinterpret_cast<uintptr_t>(dout) |
                       reinterpret_cast<uintptr_t>(dh) | reinterpret_cast<uintptr_t>(dagg) |
                       reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(dpre)) & 15u) == 0;
-  if (ridx && !al16) return fail(IMPNN_E_BADARG, "gated_update_rows_bwd: tensors must be 16B aligned");
+  if ((ridx || saved) && !al16) return fail(IMPNN_E_BADARG, "gated_update_rows_bwd: tensors must be 16B aligned");
   if ((D == 64 || D == 128) && al16) {
-    const size_t lw = sizeof(float) * ((size_t)64 * (2 * D + 4) + 64 * (D + 4) + 2 * 16 * 2 * D + 4 * 256 + 4 * 5 * D) + 64 * sizeof(int32_t);
+    const size_t lw = sizeof(float) * ((size_t)64 * (2 * D + 4) + 64 * (D + 4) + 3 * 16 * 2 * D + 4 * 256) + 64 * sizeof(int32_t);
     const int tile_rows = gu_wide_tile_rows(rows);  // (as the forward kernel: 16-row tiles below ~8 K rows)
+    transpose3_kernel<<<dim3((D + 31) / 32, (2 * D + 31) / 32, 3), dim3(32, 8), 0, s>>>(Wz, Wr, Wh, wt, D);
+    if (int rc = check_launch("transpose3")) return rc;
     const int64_t tiles64 = (rows + tile_rows - 1) / tile_rows;
-    const int nb = (int)(tiles64 < nblk ? tiles64 : nblk);  // `small` has nblk slices: unused ones must be zero
-    // (zeroing is a kernel, not hipMemsetAsync: the call may sit inside a captured graph)
-    zero_floats_kernel<<<grid_for((int64_t)nblk * 5 * D), kBlock, 0, s>>>(small, (int64_t)nblk * 5 * D);
-    if (int rc = check_launch("zero_floats")) return rc;
+    const int nb = (int)(tiles64 < nblk ? tiles64 : nblk);  // every launched workgroup writes its slice of `small`
+    nsmall = nb;                                            // (zeros when the row list ends before its tiles)
 #define BWD16(NT_, SV_)                                                                                              \
     do {                                                                                                              \
       (void)hipFuncSetAttribute((const void*)gated_update_bwd_wide16_kernel<NT_, SV_>,                                \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lw);                                 \
       gated_update_bwd_wide16_kernel<NT_, SV_><<<nb, 1024, lw, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, \
                                                                    dagg, dpre, rh, small, rows, ridx, nrows_dev, hc,  \
-                                                                   aggc, tile_rows);                                  \
+                                                                   aggc, tile_rows, wt);                              \
     } while (0)
     if (D == 64) {
       if (saved) BWD16(4, true); else BWD16(4, false);
@@ -2839,7 +2843,7 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   if (int rc = check_launch("strided_gemm_splitk")) return rc;
   const int64_t welems = (int64_t)3 * 2 * D * D * (nchunk <= 64 ? 1 : 64);  // a thread or a wave per kernel element
   const int wblocks = (int)((welems + kBlock - 1) / kBlock), vblocks = (5 * D * 64 + kBlock - 1) / kBlock;
-  gated_update_reduce_kernel<<<wblocks + vblocks, kBlock, 0, s>>>(small, gpart, dparams, nblk, nchunk, D, accumulate,
+  gated_update_reduce_kernel<<<wblocks + vblocks, kBlock, 0, s>>>(small, gpart, dparams, nsmall, nchunk, D, accumulate,
                                                                  wblocks);
   return check_launch("gated_update_reduce");
 }

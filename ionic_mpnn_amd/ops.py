@@ -136,7 +136,25 @@ def bond_type_matrices(bond_table, W):
     return out
 
 
-def bmm_message_typed(h, bond_ids, conn, type_mats):
+def message_scratch(conn, bond_ids, B, E, D):
+    """(buffer, reuse) - the (B,E,D) message buffer of this (conn, bond_ids) inside an ``autograd.training_pass``: the
+    layers of an ion write their messages into the same buffer one after the other (each is consumed by the Reduce right
+    behind it), so the zero rows of masked edges are written by the first layer only.  Outside a pass: (None, False)."""
+    from . import autograd
+    pass_id = autograd.current_pass()
+    if pass_id is None:
+        return None, False
+    key = (pass_id, conn._version, bond_ids.data_ptr(), bond_ids._version, B, E, D)
+    cached = getattr(conn, "_impnn_msg_scratch", None)
+    if cached is not None and cached[0] == key:
+        return cached[1], True
+    m = torch.empty(B, E, D, dtype=torch.float32, device=conn.device)
+    conn._impnn_msg_scratch = (key, m)
+    return m, False
+
+
+def bmm_message_typed(h, bond_ids, conn, type_mats, out=None, out_reused=False):
+    """``out`` / ``out_reused``: ops.message_scratch's pair (model-internal: the training loop's message buffer)."""
     if _wants_grad(h, type_mats):
         from . import autograd
         return autograd.BmmMessageTyped.apply(h, bond_ids, conn, type_mats)
@@ -147,14 +165,15 @@ def bmm_message_typed(h, bond_ids, conn, type_mats):
     E, Vb = conn.shape[1], type_mats.shape[0]
     if DEBUG_VALIDATE:
         validate_indices(conn=conn, bond_ids=bond_ids, N=N, Vb=Vb)
-    m = torch.empty(B, E, D, dtype=torch.float32, device=h.device)
+    m = out if out is not None else torch.empty(B, E, D, dtype=torch.float32, device=h.device)
     lib = _lib.load()
     with torch.cuda.device(h.device):
         if D != 32 and D <= 128 and E > 0 and B > 0:
             # any other width: type-sorted segments with A[type] in LDS (the D = 32 kernel sorts inside its workgroups)
             ws, ready = edge_sort_workspace(conn, bond_ids, B, E, Vb)
+            flags = (1 if ready else 0) | (2 if out is not None and out_reused else 0)
             check(lib.impnn_bmm_message_typed_sorted(ptr(h), ptr(bond_ids), ptr(conn), ptr(type_mats), ptr(m), ptr(ws),
-                                                     ws.numel(), B, N, E, D, Vb, 1 if ready else 0, stream_ptr()))
+                                                     ws.numel(), B, N, E, D, Vb, flags, stream_ptr()))
         else:
             check(lib.impnn_bmm_message_typed(ptr(h), ptr(bond_ids), ptr(conn), ptr(type_mats), ptr(m), B, N,
                                               E, D, Vb, stream_ptr()))
@@ -251,7 +270,7 @@ def kept_row_index(atom_ids, bond_ids, conn, Vb):
 def gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps=LN_EPS, rows=None, save=False):
     """GatedUpdate.call, models/layers.py:142-156.  ``rows`` = (row_index, n_rows) of kept_row_index: only those rows
     of the output are computed (model-internal use: padding atoms; the rest of ``out`` is undefined).
-    ``save`` (with ``rows``, atom_dim 64 / 128; the training forward): returns (out, saved) - the gates, the candidate
+    ``save`` (atom_dim 64 / 128; the training forward): returns (out, saved) - the gates, the candidate
     and r * h of the listed rows for impnn_gated_update_rows_bwd_saved."""
     if _wants_grad(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta):
         from . import autograd
@@ -271,8 +290,9 @@ def gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps=LN_EPS, rows=N
             lib = _lib.load()
             saved = torch.empty(int(lib.impnn_gated_update_rows_saved_floats(nrows, D)), dtype=torch.float32,
                                 device=h.device)
-            check(lib.impnn_gated_update_rows_train(*[ptr(t) for t in ts], float(eps), ptr(out), ptr(rows[0]),
-                                                    ptr(rows[1]), nrows, D, ptr(saved), stream_ptr()))
+            ri, rn = (ptr(rows[0]), ptr(rows[1])) if rows is not None else (None, None)
+            check(lib.impnn_gated_update_rows_train(*[ptr(t) for t in ts], float(eps), ptr(out), ri, rn, nrows, D,
+                                                    ptr(saved), stream_ptr()))
             return out, saved
         if rows is not None and D in (32, 64, 128):
             check(_lib.load().impnn_gated_update_rows(*[ptr(t) for t in ts], float(eps), ptr(out), ptr(rows[0]),

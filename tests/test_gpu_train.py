@@ -206,6 +206,58 @@ def test_gated_update_backward_on_a_row_list(D, rows, keep):
     assert float(dh[rest].abs().max()) == 0.0 if len(rest) else True
 
 
+@pytest.mark.parametrize("D,rows,keep", [(128, 1000, 0.6), (64, 5000, 0.3), (128, 70, 1.0), (64, 64, 0.0), (128, 12000, 0.7),
+                                         (128, 1280, None), (64, 40, None)])
+def test_gated_update_backward_from_kept_activations(D, rows, keep):
+    """impnn_gated_update_rows_train + impnn_gated_update_rows_bwd_saved (the training loop's pair: the forward keeps z, r,
+    tanh(.) and r * h, the backward skips its recompute passes) against the fp64 oracle; keep = None: no row list.  The
+    forward's output equals impnn_gated_update_rows' bit for bit, and a second backward over the consumed buffer is refused
+    at the autograd node (test_wide_state_model_gradients... run through the same pair)."""
+    from ionic_mpnn_amd import autograd
+    rng = np.random.default_rng(3 * D + rows)
+    names = ["Wz", "bz", "Wr", "br", "Wh", "bh", "gamma", "beta"]
+    vals = {"Wz": rng.normal(size=(2 * D, D)) / np.sqrt(2 * D), "Wr": rng.normal(size=(2 * D, D)) / np.sqrt(2 * D),
+            "Wh": rng.normal(size=(2 * D, D)) / np.sqrt(2 * D), "bz": rng.normal(size=D) * 0.1,
+            "br": rng.normal(size=D) * 0.1, "bh": rng.normal(size=D) * 0.1, "gamma": 1 + 0.1 * rng.normal(size=D),
+            "beta": 0.1 * rng.normal(size=D)}
+    h, agg, go = rng.normal(size=(rows, D)), rng.normal(size=(rows, D)), rng.normal(size=(rows, D))
+    sel = (np.arange(rows) if keep is None else np.flatnonzero(rng.random(rows) < keep)).astype(np.int32)
+    n = len(sel)
+    po = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in vals.items()}
+    ho, ao = (torch.tensor(a[sel], dtype=torch.float64, requires_grad=True) for a in (h, agg))
+    if n:
+        out64 = TR.gated_update(ho, ao, po)
+        (out64 * torch.tensor(go[sel])).sum().backward()
+    f32 = lambda a: torch.tensor(a, dtype=torch.float32, device=DEV)
+    row_list = None
+    if keep is not None:
+        idx = torch.zeros(rows, dtype=torch.int32, device=DEV)
+        idx[:n] = torch.tensor(sel, device=DEV)
+        idx[n:] = -7
+        row_list = (idx, torch.tensor([n], dtype=torch.int32, device=DEV))
+    ts = (f32(h), f32(agg), *[f32(vals[k]) for k in names])
+    out, kept = ops.gated_update(*ts, 1e-3, rows=row_list, save=True)
+    plain = ops.gated_update(*ts, 1e-3, rows=row_list)
+    torch.cuda.synchronize()
+    if n:
+        assert torch.equal(out[sel], plain[sel])
+        close(out[sel], out64.detach(), what="forward output of the listed rows")
+    dh, dagg, *dp = autograd._gated_update_backward(ts, 1e-3, f32(go), row_list, kept)[:10]
+    torch.cuda.synchronize()
+    if n:
+        close(dh[sel], ho.grad, what="dh of the listed rows")
+        close(dagg[sel], ao.grad, what="dagg of the listed rows")
+        for k, g in zip(names, dp):
+            close(g, po[k].grad, what=f"d{k}")
+    else:
+        for g in dp:
+            assert float(g.abs().max()) == 0.0
+    rest = np.setdiff1d(np.arange(rows), sel)
+    if len(rest):
+        assert float(dh[rest].abs().max()) == 0.0
+
+
+
 def test_embedding_and_pool_backward():
     rng = np.random.default_rng(3)
     B, N, D, V = 6, 11, 16, 9
