@@ -384,6 +384,15 @@ int impnn_bond_type_matrices_multi_bwd(const float* bond_table, const float* con
                                        const float* const* dtype_mats, float* const* dW, float* dbond_table,
                                        int32_t n, int32_t Vb, int32_t K, int32_t D, int32_t accumulate,
                                        impnn_stream_t stream);
+/* The same with a workspace (impnn_bond_type_matrices_multi_bwd_workspace_floats floats, 16-byte aligned): the bond-table
+ * gradient - a (Vb x K) result over a contraction of n D^2 - runs on the matrix cores, per-wave partials in the
+ * workspace, added in a fixed order (bitwise reproducible; 116-170 us -> ~15 us at atom_dim 128, all of it on the
+ * critical path of a training step).  K <= 16, Vb <= 128, D % 16 == 0; other shapes take the entry above's kernels. */
+int64_t impnn_bond_type_matrices_multi_bwd_workspace_floats(int32_t n, int32_t Vb, int32_t K, int32_t D);
+int impnn_bond_type_matrices_multi_bwd_ws(const float* bond_table, const float* const* W,
+                                          const float* const* dtype_mats, float* const* dW, float* dbond_table,
+                                          int32_t n, int32_t Vb, int32_t K, int32_t D, int32_t accumulate,
+                                          float* workspace, int64_t workspace_floats, impnn_stream_t stream);
 int64_t impnn_gated_update_param_floats(int32_t D);
 int64_t impnn_gated_update_bwd_workspace_floats(int64_t rows, int32_t D);
 int impnn_gated_update_bwd(const float* h, const float* agg, const float* Wz, const float* bz, const float* Wr,

@@ -67,6 +67,8 @@ SIGNATURES = {
     "impnn_bond_type_matrices_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "impnn_bond_type_matrices_multi": (C.c_int, [vp, PP, PP, i32, i32, i32, i32, vp]),
     "impnn_bond_type_matrices_multi_bwd": (C.c_int, [vp, PP, PP, PP, vp, i32, i32, i32, i32, i32, vp]),
+    "impnn_bond_type_matrices_multi_bwd_workspace_floats": (i64, [i32, i32, i32, i32]),
+    "impnn_bond_type_matrices_multi_bwd_ws": (C.c_int, [vp, PP, PP, PP, vp, i32, i32, i32, i32, i32, vp, i64, vp]),
     "impnn_gated_update_param_floats": (i64, [i32]),
     "impnn_gated_update_bwd_workspace_floats": (i64, [i64, i32]),
     "impnn_gated_update_bwd": (C.c_int, [vp] * 9 + [f32] + [vp] * 5 + [i64, i64, i32, i32, vp]),

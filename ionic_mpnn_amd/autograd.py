@@ -150,8 +150,11 @@ class BondTypeMatricesAll(torch.autograd.Function):
         wt = (C.c_void_p * n)(*[W.data_ptr() for W in Ws])
         dt = (C.c_void_p * n)(*[d.data_ptr() for d in dmats])
         gt = (C.c_void_p * n)(*[g.data_ptr() for g in dWs])
-        _lib_call(bond_table.device, _lib.load().impnn_bond_type_matrices_multi_bwd, ptr(bond_table), wt, dt, gt, ptr(dtb),
-                  n, Vb, K, D, 1 if use_sinks else 0)
+        lib = _lib.load()
+        wsn = int(lib.impnn_bond_type_matrices_multi_bwd_workspace_floats(n, Vb, K, D))
+        ws = torch.empty(max(wsn, 1), dtype=torch.float32, device=bond_table.device)
+        _lib_call(bond_table.device, lib.impnn_bond_type_matrices_multi_bwd_ws, ptr(bond_table), wt, dt, gt, ptr(dtb),
+                  n, Vb, K, D, 1 if use_sinks else 0, ptr(ws), wsn)
         if use_sinks:
             return (None,) * (n + 1)
         return (dtb, *dWs)

@@ -558,6 +558,25 @@ int impnn_bond_type_matrices_multi_bwd(const float* bond_table, const float* con
                                              as_stream(stream));
 }
 
+int64_t impnn_bond_type_matrices_multi_bwd_workspace_floats(int32_t n, int32_t Vb, int32_t K, int32_t D) {
+  if (n <= 0 || Vb <= 0 || K <= 0 || D <= 0) return 0;
+  return bond_type_matrices_multi_bwd_workspace(n, Vb, K, D);
+}
+
+int impnn_bond_type_matrices_multi_bwd_ws(const float* bond_table, const float* const* W,
+                                          const float* const* dtype_mats, float* const* dW, float* dbond_table,
+                                          int32_t n, int32_t Vb, int32_t K, int32_t D, int32_t accumulate,
+                                          float* workspace, int64_t workspace_floats, impnn_stream_t stream) {
+  REQUIRE(n >= 0 && Vb > 0 && K > 0 && D > 0, "bad shape");
+  if (n == 0) return IMPNN_OK;
+  REQUIRE(bond_table && W && dtype_mats && dW && dbond_table && workspace, "null pointer");
+  if (workspace_floats < impnn_bond_type_matrices_multi_bwd_workspace_floats(n, Vb, K, D))
+    return fail(IMPNN_E_WORKSPACE, "bond_type_matrices_multi_bwd_ws: workspace of %lld floats is too small",
+                (long long)workspace_floats);
+  return launch_bond_type_matrices_multi_bwd(bond_table, W, dtype_mats, dW, dbond_table, n, Vb, K, D, accumulate != 0,
+                                             as_stream(stream), workspace);
+}
+
 int64_t impnn_gated_update_param_floats(int32_t D) { return D > 0 ? gated_update_param_floats(D) : 0; }
 
 int64_t impnn_gated_update_bwd_workspace_floats(int64_t rows, int32_t D) {

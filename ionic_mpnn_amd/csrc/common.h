@@ -84,7 +84,8 @@ int launch_bond_type_matrices_multi(const float* tb, const float* const* W, floa
                                     int D, hipStream_t s);
 int launch_bond_type_matrices_multi_bwd(const float* tb, const float* const* W, const float* const* dA,
                                         float* const* dW, float* dtb, int n, int Vb, int K, int D, int accumulate,
-                                        hipStream_t s);
+                                        hipStream_t s, float* workspace = nullptr);
+int64_t bond_type_matrices_multi_bwd_workspace(int n, int Vb, int K, int D);
 int launch_bond_type_matrices_bwd(const float* tb, const float* W, const float* dA, float* dW, float* dtb, int Vb,
                                   int K, int D, int accumulate, hipStream_t s);
 int gated_update_bwd_blocks(int64_t rows, int D);

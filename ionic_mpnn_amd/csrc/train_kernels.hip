@@ -875,6 +875,63 @@ __global__ void bond_type_matrices_multi_bwd_t_kernel(BtmBatch bt, float* __rest
   if (lane == 0) dtb[(int64_t)v * K + k] = accumulate ? dtb[(int64_t)v * K + k] + acc : acc;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// dtb[v,k] = sum_p sum_ij dA_p[v,ij] W_p[k,ij] on the matrix cores (exact f32 products): bond types on M (VT tiles of
+// 16), k on N (K <= 16, padded with zeros), the contraction over (p, ij) cut into chunks of kBtC per WAVE - a lane loads
+// 16 bytes of a dA row and of a W row per 16 contraction indices (the MFMA's k = the lane's quarter q, component r of
+// the quad: any bijection serves as long as both operands use it).  The per-wave partials land in `part`
+// ([wave][v][k]) and bond_type_matrices_t_sum_kernel adds them in wave order: bitwise reproducible.
+// The one-wave-per-output kernel above walked 12 x 16 K products per lane with eight loads in flight: 116-170 us at
+// atom_dim 128 - alone on the stream at the end of every backward pass, so all of it on the critical path of a step.
+// ---------------------------------------------------------------------------------------
+constexpr int kBtC = 256;
+template <int VT>
+__global__ __launch_bounds__(256) void bond_type_matrices_multi_bwd_t_mfma_kernel(BtmBatch bt, float* __restrict__ part,
+                                                                                  int Vb, int K, int DD, int waves) {
+  BTM_STAGE(bt)
+  const int w = blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = threadIdx.x & 63, a = lane & 15, q = lane >> 4;
+  if (w >= waves) return;
+  const int cpp = DD / kBtC, p = w / cpp, c0 = (w - p * cpp) * kBtC + 4 * q;
+  const float* Wp = sW[p] + (int64_t)(a < K ? a : 0) * DD + c0;
+  const float* dAp = sdA[p] + c0;
+  const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4_t acc[VT];
+#pragma unroll
+  for (int t = 0; t < VT; ++t) acc[t] = zero;
+#pragma unroll 2
+  for (int st = 0; st < kBtC / 16; ++st) {
+    const f32x4_t wv = a < K ? ldv4(Wp + 16 * st) : zero;
+    f32x4_t x[VT];
+#pragma unroll
+    for (int t = 0; t < VT; ++t) {
+      const int v = 16 * t + a;
+      x[t] = v < Vb ? ldv4(dAp + (int64_t)v * DD + 16 * st) : zero;
+    }
+#pragma unroll
+    for (int t = 0; t < VT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t] = mfma_f32(x[t][r], wv[r], acc[t]);
+  }
+  float* mine = part + (int64_t)w * Vb * K;
+#pragma unroll
+  for (int t = 0; t < VT; ++t)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int v = 16 * t + 4 * q + g;
+      if (v < Vb && a < K) mine[v * K + a] = acc[t][g];
+    }
+}
+__global__ void bond_type_matrices_t_sum_kernel(const float* __restrict__ part, float* __restrict__ dtb, int VK, int waves,
+                                                int accumulate) {
+  const int e = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (e >= VK) return;
+  float acc = 0.f;
+  for (int w = lane; w < waves; w += 64) acc += part[(int64_t)w * VK + e];
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if (lane == 0) dtb[e] = accumulate ? dtb[e] + acc : acc;
+}
+
 // ---------------------------------------------------------------------------------------
 // a7 backward (models/layers.py:142-156).  Forward per row, c = [h|agg]:
 //   z = sig(c Wz + bz); r = sig(c Wr + br); t = tanh([r*h|agg] Wh + bh); n = (1-z) h + z t;
@@ -2952,10 +3009,18 @@ int launch_bond_type_matrices_multi(const float* tb, const float* const* W, floa
   return IMPNN_OK;
 }
 
+int64_t bond_type_matrices_multi_bwd_workspace(int n, int Vb, int K, int D) {
+  const int nb = n < kBtmMax ? n : kBtmMax;
+  return (int64_t)nb * ((int64_t)D * D / kBtC + 1) * Vb * K;
+}
+
 int launch_bond_type_matrices_multi_bwd(const float* tb, const float* const* W, const float* const* dA,
                                         float* const* dW, float* dtb, int n, int Vb, int K, int D, int accumulate,
-                                        hipStream_t s) {
+                                        hipStream_t s, float* workspace) {
   const int DD = D * D;
+  // with a workspace: the bond-table gradient on the matrix cores (partials per wave, summed in a fixed order)
+  const bool mfma_t = workspace && K <= 16 && Vb <= 128 && DD % kBtC == 0 && DD >= 4096 &&  // (small matrices: one launch less)
+                      (reinterpret_cast<uintptr_t>(workspace) & 15u) == 0;
   for (int p0 = 0; p0 < n; p0 += kBtmMax) {
     BtmBatch bt{};
     bt.n = n - p0 < kBtmMax ? n - p0 : kBtmMax;
@@ -2969,6 +3034,25 @@ int launch_bond_type_matrices_multi_bwd(const float* tb, const float* const* W, 
     bond_type_matrices_multi_bwd_w_kernel<<<dim3((DD + kBlock - 1) / kBlock, K, bt.n), kBlock, 0, s>>>(tb, bt, Vb, K, DD,
                                                                                                      accumulate);
     if (int rc = check_launch("bond_type_matrices_multi_bwd_w")) return rc;
+    bool al = mfma_t;
+    for (int q = 0; q < bt.n; ++q)
+      al = al && ((reinterpret_cast<uintptr_t>(bt.W[q]) | reinterpret_cast<uintptr_t>(bt.dA[q])) & 15u) == 0;
+    if (al) {
+      const int nw = bt.n * (DD / kBtC), nwg = (nw + 3) / 4, acc_t = (accumulate || p0 > 0) ? 1 : 0;
+      switch ((Vb + 15) / 16) {
+#define BTM_T(VT_)                                                                                                  \
+        case VT_:                                                                                                     \
+          bond_type_matrices_multi_bwd_t_mfma_kernel<VT_><<<nwg, 256, 0, s>>>(bt, workspace, Vb, K, DD, nw);          \
+          break;
+        BTM_T(1) BTM_T(2) BTM_T(3) BTM_T(4) BTM_T(5) BTM_T(6) BTM_T(7) BTM_T(8)
+#undef BTM_T
+      }
+      if (int rc = check_launch("bond_type_matrices_multi_bwd_t_mfma")) return rc;
+      bond_type_matrices_t_sum_kernel<<<(Vb * K * 64 + kBlock - 1) / kBlock, kBlock, 0, s>>>(workspace, dtb, Vb * K, nw,
+                                                                                           acc_t);
+      if (int rc = check_launch("bond_type_matrices_t_sum")) return rc;
+      continue;
+    }
     const int64_t waves = (int64_t)Vb * K;
     // (tried for bond_dim <= 8: one workgroup per bond type with the K partial dot products per thread, dA read once
     //  instead of once per k - 71 workgroups are far too few: 116 us -> 1.3 ms at atom_dim 128)
