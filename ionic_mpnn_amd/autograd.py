@@ -261,7 +261,7 @@ class GatedUpdate(torch.autograd.Function):
         return _gated_update_backward(ctx.saved_tensors, ctx.eps, dout)
 
 
-def _gated_update_backward(saved, eps, dout, row_list=None, kept=None):
+def _gated_update_backward(saved, eps, dout, row_list=None, kept=None, unlisted_undefined=False):
     """(dh, dagg, 8 parameter gradients or None where the kernel added into the sink, None for eps).
     row_list = (row_index, n_rows) of ops.kept_row_index: gradients of those rows only (impnn_gated_update_rows_bwd);
     dh is zero elsewhere (padding atoms carry no gradient), dagg is undefined there and never read.
@@ -272,7 +272,7 @@ def _gated_update_backward(saved, eps, dout, row_list=None, kept=None):
     rows = h.numel() // D
     lib = _lib.load()
     dout = f32c(dout)
-    dh = torch.zeros_like(h) if row_list is not None else torch.empty_like(h)
+    dh = torch.zeros_like(h) if row_list is not None and not unlisted_undefined else torch.empty_like(h)
     dagg = torch.empty_like(agg)
     P = int(lib.impnn_gated_update_param_floats(D))
     if row_list is not None or kept is not None:
@@ -326,12 +326,15 @@ class MessagePassingStep(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, bond_ids, conn, type_mats, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, row_index=None,
-                n_rows=None):
+                n_rows=None, inner=False):
         """row_index / n_rows (ops.kept_row_index; atom_dim 64 / 128): GatedUpdate forward and backward on the kept rows
         only - padding atoms reach neither a message nor the pool, so their rows of the output are left undefined
         and their gradient is zero (include/impnn.h, impnn_gated_update_rows[_bwd])."""
         h, type_mats, bond_ids, conn = f32c(h), f32c(type_mats), i32c(bond_ids), i32c(conn)
         gu = [f32c(t) for t in (Wz, bz, Wr, br, Wh, bh, gamma)]
+        # inner (with a row list): this step's input is the output of another MessagePassingStep on the SAME list - that
+        # node reads its incoming gradient at the listed rows only, so the rows outside the list need no zero fill here
+        ctx.inner = bool(inner) and row_index is not None
         if h.shape[-1] != 32:
             # one message buffer per ion and pass (the Reduce behind each layer consumes it at once)
             buf, reused = ops.message_scratch(conn, bond_ids, h.shape[0], conn.shape[1], h.shape[-1])
@@ -365,7 +368,7 @@ class MessagePassingStep(torch.autograd.Function):
                 raise RuntimeError("MessagePassingStep: the kept activations were consumed by an earlier backward "
                                    "(run the forward again instead of retain_graph)")
             ctx.kept = False
-        dh, dagg, *dparams = _gated_update_backward(saved[:10], ctx.eps, dout, ctx.row_list, kept)
+        dh, dagg, *dparams = _gated_update_backward(saved[:10], ctx.eps, dout, ctx.row_list, kept, ctx.inner)
         del kept
         B, N, D = h.shape
         E, Vb = conn.shape[1], mats.shape[0]
@@ -379,7 +382,7 @@ class MessagePassingStep(torch.autograd.Function):
             _pass["id"] = prev
         _lib_call(h.device, _lib.load().impnn_message_reduce_typed_bwd, ptr(h), ptr(bond_ids), ptr(conn), ptr(mats),
                   ptr(dagg), ptr(dh), ptr(dmats), ptr(ws), ws.numel(), B, N, E, D, Vb, 1 if ready else 0)
-        return (dh, None, None, dmats, *dparams, None, None)
+        return (dh, None, None, dmats, *dparams, None, None, None)
 
 
 class GlobalSumPool(torch.autograd.Function):

@@ -331,7 +331,7 @@ class MPNNModel:
                 h = autograd.MessagePassingStep.apply(
                     h, bond.ids, conn, mats, w["dense_z/kernel"], w["dense_z/bias"], w["dense_r/kernel"],
                     w["dense_r/bias"], w["dense_h/kernel"], w["dense_h/bias"], u.gamma, u.beta, u.epsilon,
-                    *(rows if rows is not None else (None, None)))
+                    *(rows if rows is not None else (None, None)), i > 0)
                 continue
             m = br["bmm"][i]([h, bond, conn])
             agg = br["reduce"][i]([m, conn[:, :, 1], h])
