@@ -411,7 +411,8 @@ int impnn_gated_update_rows_bwd(const float* h, const float* agg, const float* W
                                 const float* dout, float* dh, float* dagg, float* dparams, float* workspace,
                                 int64_t workspace_floats, const int32_t* row_index, const int32_t* n_rows,
                                 int64_t max_rows, int32_t D, int32_t accumulate, impnn_stream_t stream);
-/* The same pair for a training loop that keeps activations instead of recomputing them (atom_dim 64 / 128):
+/* The same pair for a training loop that keeps activations instead of recomputing them (atom_dim 64 / 128, and 32
+ * without a row list - workspace of impnn_gated_update_bwd_workspace_floats there):
  * impnn_gated_update_rows_train is impnn_gated_update_rows that also writes, per LISTED row (by list position), the
  * gates z, r, the candidate tanh(.) and r * h of models/layers.py:145-152 into `saved`
  * (impnn_gated_update_rows_saved_floats(max_rows, D) = 4 D max_rows floats, 16-byte aligned);

@@ -275,7 +275,7 @@ def _gated_update_backward(saved, eps, dout, row_list=None, kept=None, unlisted_
     dh = torch.zeros_like(h) if row_list is not None and not unlisted_undefined else torch.empty_like(h)
     dagg = torch.empty_like(agg)
     P = int(lib.impnn_gated_update_param_floats(D))
-    if row_list is not None or kept is not None:
+    if row_list is not None or (kept is not None and D != 32):
         wsn = int(lib.impnn_gated_update_rows_bwd_workspace_floats(rows, D))
     else:
         wsn = int(lib.impnn_gated_update_bwd_workspace_floats(rows, D))
@@ -346,7 +346,7 @@ class MessagePassingStep(torch.autograd.Function):
         del m
         ctx.row_list = (row_index, n_rows) if row_index is not None else None
         ctx.kept = None
-        if h.shape[-1] in (64, 128):
+        if h.shape[-1] in (64, 128) or (h.shape[-1] == 32 and ctx.row_list is None):
             # the gates, the candidate and r * h of the (kept) rows stay for the backward (4 D floats per row and step)
             # instead of being recomputed there with half of its matrix work
             out, ctx.kept = ops.gated_update(h, agg, *gu, beta, eps, rows=ctx.row_list, save=True)

@@ -621,7 +621,7 @@ int impnn_gated_update_rows_bwd(const float* h, const float* agg, const float* W
 }
 
 int64_t impnn_gated_update_rows_saved_floats(int64_t max_rows, int32_t D) {
-  if (max_rows < 0 || (D != 64 && D != 128)) return 0;
+  if (max_rows < 0 || (D != 32 && D != 64 && D != 128)) return 0;
   return max_rows * 4 * D;
 }
 
@@ -631,8 +631,8 @@ int impnn_gated_update_rows_train(const float* h, const float* agg, const float*
                                   const int32_t* n_rows, int64_t max_rows, int32_t D, float* saved,
                                   impnn_stream_t stream) {
   REQUIRE(max_rows >= 0, "bad shape");
-  if (D != 64 && D != 128)
-    return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_train: atom_dim %d (the saving forward covers 64 and 128)", D);
+  if (D != 32 && D != 64 && D != 128)
+    return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_train: atom_dim %d (the saving forward covers 32, 64 and 128)", D);
   if (max_rows == 0) return IMPNN_OK;
   REQUIRE(h && agg && Wz && bz && Wr && br && Wh && bh && gamma && beta && out && saved, "null pointer");
   REQUIRE((row_index != nullptr) == (n_rows != nullptr), "row_index and n_rows: both or neither");
@@ -649,12 +649,15 @@ int impnn_gated_update_rows_bwd_saved(const float* h, const float* agg, const fl
                                       const int32_t* row_index, const int32_t* n_rows, int64_t max_rows, int32_t D,
                                       int32_t accumulate, float* saved, impnn_stream_t stream) {
   REQUIRE(max_rows >= 0, "bad shape");
-  if (D != 64 && D != 128)
-    return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_bwd_saved: atom_dim %d (covers 64 and 128)", D);
+  if (D != 32 && D != 64 && D != 128)
+    return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_bwd_saved: atom_dim %d (covers 32, 64 and 128)", D);
   REQUIRE(h && agg && Wz && bz && Wr && br && Wh && bh && gamma && dout && dh && dagg && dparams && workspace && saved,
           "null pointer");
   REQUIRE((row_index != nullptr) == (n_rows != nullptr), "row_index and n_rows: both or neither");
-  if (workspace_floats < impnn_gated_update_rows_bwd_workspace_floats(max_rows, D))
+  if (D == 32 && row_index)
+    return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_bwd_saved: atom_dim 32 takes no row list");
+  if (workspace_floats < (D == 32 ? impnn_gated_update_bwd_workspace_floats(max_rows, D)
+                                  : impnn_gated_update_rows_bwd_workspace_floats(max_rows, D)))
     return fail(IMPNN_E_WORKSPACE, "gated_update_rows_bwd_saved: workspace of %lld floats is too small",
                 (long long)workspace_floats);
   if (max_rows == 0) return IMPNN_OK;

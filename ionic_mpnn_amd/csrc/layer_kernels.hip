@@ -508,7 +508,9 @@ __global__ __launch_bounds__(256) void gated_update_d32_kernel(
     const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
     const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, float* __restrict__ out, int64_t rows,
-    const int32_t* __restrict__ ridx, const int32_t* __restrict__ nrows_dev) {
+    const int32_t* __restrict__ ridx, const int32_t* __restrict__ nrows_dev, float* __restrict__ save) {
+  // save (optional; impnn_gated_update_rows_train): [z | r | tanh(t)] per row by list position, then r * h from float
+  // 3 D max_rows on - see gated_update_wide16_kernel
   constexpr int D = 32;
   const int64_t max_rows = rows;  // what the launch and every buffer are sized for
   if (nrows_dev) {  // row list (impnn_gated_update_rows): rows ridx[0 .. *nrows_dev) only; never beyond the sizing
@@ -567,8 +569,20 @@ __global__ __launch_bounds__(256) void gated_update_d32_kernel(
     for (int i = 0; i < 4; ++i) {
       z0[i] = fsig(z0[i]);
       z1[i] = fsig(z1[i]);
-      rh0[i] = fsig(r0[i]) * h0[i];  // models/layers.py:149
-      rh1[i] = fsig(r1[i]) * h1[i];
+      r0[i] = fsig(r0[i]);
+      r1[i] = fsig(r1[i]);
+      rh0[i] = r0[i] * h0[i];  // models/layers.py:149
+      rh1[i] = r1[i] * h1[i];
+    }
+    if (save && row < rows) {
+      float* sv = save + row * 3 * D + 4 * q;
+      *reinterpret_cast<f32x4_t*>(sv) = z0;
+      *reinterpret_cast<f32x4_t*>(sv + 16) = z1;
+      *reinterpret_cast<f32x4_t*>(sv + D) = r0;
+      *reinterpret_cast<f32x4_t*>(sv + D + 16) = r1;
+      float* sr = save + max_rows * 3 * D + row * D + 4 * q;
+      *reinterpret_cast<f32x4_t*>(sr) = rh0;
+      *reinterpret_cast<f32x4_t*>(sr + 16) = rh1;
     }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -588,9 +602,16 @@ __global__ __launch_bounds__(256) void gated_update_d32_kernel(
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      n0[i] = fmaf(z0[i], ftanh(t0[i]) - h0[i], h0[i]);  // (1-z) h + z tanh(.)
-      n1[i] = fmaf(z1[i], ftanh(t1[i]) - h1[i], h1[i]);
+      t0[i] = ftanh(t0[i]);
+      t1[i] = ftanh(t1[i]);
+      n0[i] = fmaf(z0[i], t0[i] - h0[i], h0[i]);  // (1-z) h + z tanh(.)
+      n1[i] = fmaf(z1[i], t1[i] - h1[i], h1[i]);
       sum += n0[i] + n1[i];
+    }
+    if (save && row < rows) {
+      float* sv = save + row * 3 * D + 2 * D + 4 * q;
+      *reinterpret_cast<f32x4_t*>(sv) = t0;
+      *reinterpret_cast<f32x4_t*>(sv + 16) = t1;
     }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
@@ -1434,8 +1455,10 @@ int launch_gated_update(const float* h, const float* agg, const float* Wz, const
                         const float* gamma, const float* beta, float eps, float* out, int64_t rows,
                         int D, hipStream_t s, const int32_t* ridx, const int32_t* nrows_dev, float* save) {
   if (rows == 0) return IMPNN_OK;
-  if (save && !(D == 64 || D == 128))
-    return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_train: atom_dim %d (the saving forward covers 64 and 128)", D);
+  if (save && !(D == 32 || D == 64 || D == 128))
+    return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_train: atom_dim %d (the saving forward covers 32, 64 and 128)", D);
+  if (save && D == 32 && !(aligned16(h) && aligned16(agg) && aligned16(out) && aligned16(save)))
+    return fail(IMPNN_E_BADARG, "gated_update_rows_train: needs 16-byte aligned tensors");
   if (ridx && !(D == 32 || (D % 64 == 0 && D <= 128)))
     return fail(IMPNN_E_UNSUPPORTED, "gated_update: a row list is supported for atom_dim 32, 64 and 128 only");
   if (ridx && D == 32 && !(aligned16(h) && aligned16(agg) && aligned16(out)))
@@ -1445,7 +1468,7 @@ int launch_gated_update(const float* h, const float* agg, const float* Wz, const
     int64_t blocks = (tiles + 3) / 4;
     if (blocks > 256 * 4) blocks = 256 * 4;  // grid-stride: the weight transpose is paid once per workgroup
     gated_update_d32_kernel<<<(unsigned)blocks, 256, 0, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps, out, rows,
-                                                             ridx, nrows_dev);
+                                                             ridx, nrows_dev, save);
     return check_launch("gated_update_d32");
   }
   if (D % 16 == 0 && D >= 48 && D <= 128) {  // matrix cores; the kernels stream through LDS in 16-row slices

@@ -1163,7 +1163,10 @@ __device__ __forceinline__ float row16_sum(float v) {
 constexpr int kBwT = 68;  // stride of the transposed kernels (rows: gate*32 + out, cols: 2D inputs)
 constexpr int kBwN = 36;  // stride of the natural kernels (rows: gate*64 + in, cols: D outputs)
 
-__global__ __launch_bounds__(kBlock) void gated_update_bwd_d32_kernel(
+// SAVED: dpre / rh_out arrive holding the training forward's z, r, tanh(t) / r * h (gated_update_d32_kernel's `save`):
+// no recompute, no transposed kernels in LDS - 24 of the kernel's 48 MFMAs per 16 rows.
+template <bool SAVED>
+__global__ __launch_bounds__(kBlock, SAVED ? 2 : 1) void gated_update_bwd_d32_kernel(
     const float* __restrict__ h, const float* __restrict__ agg, const float* __restrict__ Wz,
     const float* __restrict__ bz, const float* __restrict__ Wr, const float* __restrict__ br,
     const float* __restrict__ Wh, const float* __restrict__ bh, const float* __restrict__ gamma, float eps,
@@ -1171,8 +1174,8 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_d32_kernel(
     float* __restrict__ rh_out, float* __restrict__ small, int64_t rows) {
   constexpr int D = 32;
   extern __shared__ __align__(16) float smem[];
-  float* wt = smem;                       // 3*D rows x kBwT
-  float* wn = wt + 3 * D * kBwT;          // 3*2D rows x kBwN
+  float* wt = smem;                       // 3*D rows x kBwT (not with SAVED)
+  float* wn = wt + (SAVED ? 0 : 3 * D * kBwT);  // 3*2D rows x kBwN
   float* wvec = wn + 3 * 2 * D * kBwN;    // bz | br | bh | gamma
   float* red = wvec + 4 * D;              // 4 waves x 5 x D column sums
   for (int t = threadIdx.x; t < 3 * 2 * D * D; t += kBlock) {
@@ -1180,7 +1183,7 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_d32_kernel(
     const int jj = rem / D, io = rem - jj * D;  // keras kernel (in = jj, out = io)
     const float* Wg = gate == 0 ? Wz : (gate == 1 ? Wr : Wh);
     const float w = Wg[rem];
-    wt[(gate * D + io) * kBwT + jj] = w;
+    if (!SAVED) wt[(gate * D + io) * kBwT + jj] = w;
     wn[(gate * 2 * D + jj) * kBwN + io] = w;
   }
   for (int t = threadIdx.x; t < 4 * D; t += kBlock) {
@@ -1207,10 +1210,17 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_d32_kernel(
       dy0 = zero4;
       dy1 = zero4;
     }
-    // ---- forward recompute (as gated_update_d32_kernel)
-    f32x4_t z0 = ldv4(wvec + 4 * q), z1 = ldv4(wvec + 16 + 4 * q);
-    f32x4_t r0 = ldv4(wvec + D + 4 * q), r1 = ldv4(wvec + D + 16 + 4 * q);
-    f32x4_t t0 = ldv4(wvec + 2 * D + 4 * q), t1 = ldv4(wvec + 2 * D + 16 + 4 * q);
+    // ---- forward recompute (as gated_update_d32_kernel), or what that kernel kept
+    f32x4_t z0, z1, r0, r1, t0, t1;
+    if constexpr (SAVED) {
+      const float* sv = dpre + rl * 3 * D + 4 * q;
+      z0 = ldv4(sv); z1 = ldv4(sv + 16);
+      r0 = ldv4(sv + D); r1 = ldv4(sv + D + 16);
+      t0 = ldv4(sv + 2 * D); t1 = ldv4(sv + 2 * D + 16);
+    } else {
+    z0 = ldv4(wvec + 4 * q); z1 = ldv4(wvec + 16 + 4 * q);
+    r0 = ldv4(wvec + D + 4 * q); r1 = ldv4(wvec + D + 16 + 4 * q);
+    t0 = ldv4(wvec + 2 * D + 4 * q); t1 = ldv4(wvec + 2 * D + 16 + 4 * q);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -1252,12 +1262,20 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_d32_kernel(
         }
       }
     }
-    f32x4_t n0, n1;
-    float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       t0[i] = tanhf(t0[i]);
       t1[i] = tanhf(t1[i]);
+    }
+    if (live) {
+      stv4(rh_out + row * D + 4 * q, rh0);
+      stv4(rh_out + row * D + 16 + 4 * q, rh1);
+    }
+    }
+    f32x4_t n0, n1;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
       n0[i] = fmaf(z0[i], t0[i] - h0[i], h0[i]);
       n1[i] = fmaf(z1[i], t1[i] - h1[i], h1[i]);
       sum += n0[i] + n1[i];
@@ -1370,8 +1388,6 @@ __global__ __launch_bounds__(kBlock) void gated_update_bwd_d32_kernel(
       stv4(dp + D + 16 + 4 * q, drp1);
       stv4(dp + 2 * D + 4 * q, dtp0);
       stv4(dp + 2 * D + 16 + 4 * q, dtp1);
-      stv4(rh_out + row * D + 4 * q, rh0);
-      stv4(rh_out + row * D + 16 + 4 * q, rh1);
     }
   }
   // ---- column sums: over the 16 rows of a DPP row, then over the 4 waves (fixed order)
@@ -2811,8 +2827,10 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   const int R = kBlock / D;
   const int nblk = gu_main_blocks(rows, D), nchunk = gu_chunks(rows, D);
   int nsmall = nblk;  // slices of `small` the reduction reads
-  if (saved && !(D == 64 || D == 128))
-    return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_bwd_saved: atom_dim %d (covers 64 and 128)", D);
+  if (saved && !(D == 32 || D == 64 || D == 128))
+    return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_bwd_saved: atom_dim %d (covers 32, 64 and 128)", D);
+  if (saved && D == 32 && ridx)
+    return fail(IMPNN_E_UNSUPPORTED, "gated_update_rows_bwd_saved: atom_dim 32 takes no row list");
   // saved (impnn_gated_update_rows_train's buffer, [z | r | tanh(t)] then r * h): used in place of the workspace's
   // first two regions and CONSUMED - it leaves holding the pre-activation gradients
   float* dpre = saved ? saved : workspace;
@@ -2854,10 +2872,16 @@ int launch_gated_update_bwd(const float* h, const float* agg, const float* Wz, c
   } else if (D == 32 && al16) {
     const size_t l32 = sizeof(float) * ((size_t)3 * 32 * kBwT + 3 * 64 * kBwN + 4 * 32 + 4 * 5 * 32);
     if (l32 > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)gated_update_bwd_d32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+      (void)hipFuncSetAttribute((const void*)gated_update_bwd_d32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)l32);
-    gated_update_bwd_d32_kernel<<<nblk, kBlock, l32, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, dagg, dpre,
-                                                         rh, small, rows);
+    if (saved) {
+      const size_t l32s = l32 - sizeof(float) * 3 * 32 * kBwT;  // no transposed kernels
+      gated_update_bwd_d32_kernel<true><<<nblk, kBlock, l32s, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, dagg,
+                                                                 dpre, rh, small, rows);
+    } else {
+      gated_update_bwd_d32_kernel<false><<<nblk, kBlock, l32, s>>>(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, eps, dout, dh, dagg,
+                                                                  dpre, rh, small, rows);
+    }
   } else if (lds + wlds <= 120 * 1024) {
     lds += wlds;
     if (lds > 48 * 1024)

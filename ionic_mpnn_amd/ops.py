@@ -270,7 +270,7 @@ def kept_row_index(atom_ids, bond_ids, conn, Vb):
 def gated_update(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta, eps=LN_EPS, rows=None, save=False):
     """GatedUpdate.call, models/layers.py:142-156.  ``rows`` = (row_index, n_rows) of kept_row_index: only those rows
     of the output are computed (model-internal use: padding atoms; the rest of ``out`` is undefined).
-    ``save`` (atom_dim 64 / 128; the training forward): returns (out, saved) - the gates, the candidate
+    ``save`` (atom_dim 32 / 64 / 128; the training forward): returns (out, saved) - the gates, the candidate
     and r * h of the listed rows for impnn_gated_update_rows_bwd_saved."""
     if _wants_grad(h, agg, Wz, bz, Wr, br, Wh, bh, gamma, beta):
         from . import autograd

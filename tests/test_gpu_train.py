@@ -207,7 +207,7 @@ def test_gated_update_backward_on_a_row_list(D, rows, keep):
 
 
 @pytest.mark.parametrize("D,rows,keep", [(128, 1000, 0.6), (64, 5000, 0.3), (128, 70, 1.0), (64, 64, 0.0), (128, 12000, 0.7),
-                                         (128, 1280, None), (64, 40, None)])
+                                         (128, 1280, None), (64, 40, None), (32, 5000, None), (32, 7, None)])
 def test_gated_update_backward_from_kept_activations(D, rows, keep):
     """impnn_gated_update_rows_train + impnn_gated_update_rows_bwd_saved (the training loop's pair: the forward keeps z, r,
     tanh(.) and r * h, the backward skips its recompute passes) against the fp64 oracle; keep = None: no row list.  The
