@@ -56,7 +56,7 @@ __global__ void embed_gather_bwd_kernel(const int32_t* __restrict__ ids, const f
       }
 #pragma unroll
       for (int u = 0; u < kU; ++u)
-        if (at[u] >= 0) atomicAdd(&smem[at[u]], v[u]);
+        if (at[u] >= 0 && v[u] != 0.f) atomicAdd(&smem[at[u]], v[u]);  // (padding atoms: half of the rows, all zeros)
     }
     __syncthreads();
     for (int t = threadIdx.x; t < tsize; t += blockDim.x) {
@@ -2133,7 +2133,15 @@ __global__ void gated_update_reduce_kernel(const float* __restrict__ small, cons
   const int q = e < 3 * D ? (e / D) * (DD2 + D) + DD2 + (e % D) : 3 * (DD2 + D) + (e - 3 * D);
   const float* src = small + e;
   float acc = 0.f;
-  for (int c = lane; c < nblk; c += 64) acc += src[(int64_t)c * 5 * D];
+  int c = lane;
+  for (; c + 7 * 64 < nblk; c += 8 * 64) {  // eight slices in flight (a lane's loads are 5 D floats apart), added in order
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) x[u] = src[(int64_t)(c + 64 * u) * 5 * D];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += x[u];
+  }
+  for (; c < nblk; c += 64) acc += src[(int64_t)c * 5 * D];
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if (lane == 0) dparams[q] = accumulate ? dparams[q] + acc : acc;
 }
