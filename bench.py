@@ -256,6 +256,29 @@ def time_other_configs(dev, Va, Vb):
         del m, d
         torch.cuda.empty_cache()
 
+    # the same padded shape at config 5's model size (atom_dim 128, 6 steps) through the wide encoder (E <= 1024 there)
+    B, N, E, D, S = 1024, 160, 640, 128, 6
+    inp = synthetic.make_explicit_h_batch(B, max_atoms=N, max_edges=E, seed=0)
+    m = model.build_model(Va, Vb, atom_dim=D, bond_dim=8, num_steps=S, device=dev)
+    m.load_weights(weights.init_weights("viscosity", Va, Vb, atom_dim=D, bond_dim=8, num_steps=S, seed=1))
+    d = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    modes = {}
+    for mode in ("f32t", "f32x3"):
+        m.encoder_mode = mode
+        modes[mode] = _gpu_timed(lambda: m.encode_pooled(d), 6)
+    best = min(modes, key=modes.get)
+    rows, edges = executed_counts(inp)
+    fl = S * (12 * D * D * rows + 2 * D * D * edges)
+    out["explicit_h_shape_N160_E640_D128_K8_S6_B1024"] = {
+        "ms_per_encode": modes[best], "graph_pairs_per_s": B / (modes[best] * 1e-3), "encoder": best,
+        "modes_timed_ms_per_encode": modes, "dtype": "f32 (bf16x9 emulation)" if best == "f32x3" else "f32",
+        "kept_rows": rows, "valid_edges": edges, "executed_f32_tflops": fl / (modes[best] * 1e-3) / 1e12,
+        "frac_of_f32_mfma_peak": fl / (modes[best] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+        "note": "encode() of both ions through the wide encoder (plan + run in one call) at the explicit-hydrogen padded "
+                "shape; executed flops = exact-f32 products on kept rows / valid edges"}
+    del m, d
+    torch.cuda.empty_cache()
+
     # configs[4]: the full training step at atom_dim 128, 6 steps
     D, K, S = 128, 8, 6
     for B, graphed, iters in ((32, True, 30), (4096, True, 8)):  # (eager launches at batch 4096: 15.8 vs 15.2 ms)

@@ -152,7 +152,7 @@ int impnn_global_sum_pool(const float* h, const int32_t* atom_ids, float* out, i
  *                                 impnn_encoder_plan_overflow_offset() of the workspace (device memory; a caller whose
  *                                 shapes allow it - N > 256 or E > 255 - reads the word back and takes the layer-at-a-
  *                                 time entries for that batch, as ionic_mpnn_amd.model does).  atom_dim 64 / 128 (train_viscosity.py with atom_dim=128,
- *                                 num_steps=6), N <= 256, E <= 512, Vb <= 512: the same arithmetic as a short sequence
+ *                                 num_steps=6), N <= 256, E <= 1024, Vb <= 512: the same arithmetic as a short sequence
  *                                 of launches per call on compact kept rows (per type-run GEMMs for the messages,
  *                                 slot-order sums, GatedUpdate on 64-row tiles; csrc/encoder_wide.hip); `workgroups`
  *                                 is ignored there.

@@ -42,7 +42,7 @@ namespace wide {
 constexpr int kRT = 64;        // rows of a GatedUpdate tile (the exact-f32 kernel; mode 3's large-batch kernel: 128)
 constexpr int kRowAlign = 128; // an ion's rows start at a multiple of it (a tile never holds rows of two ions)
 constexpr int kMaxN = 256;     // atoms per molecule (LDS tables of wide_place)
-constexpr int kMaxE = 512;     // edge slots per molecule
+constexpr int kMaxE = 1024;    // edge slots per molecule (LDS tables of wide_place; the explicit-hydrogen data sets pad to E = 4 max_bonds = 640)
 constexpr int kMaxVb = 512;    // bond vocabulary (types of both ions: one per thread of wide_scan)
 constexpr int kMolPerWg = 16;  // molecules of a wide_count / wide_place workgroup (4 waves x 4); launches of up to
                                // 1024 molecules take one molecule per wave (Inputs::mpw: latency, not atomics, bounds them)
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void wide_place_kernel(Inputs in, const int32_
   __shared__ int32_t lh[2 * kMaxVb];
   __shared__ int16_t tg_s[4][kMaxE];   // target row of a slot, -1 = not a valid edge
   __shared__ int32_t pos_s[4][kMaxE];  // its sorted position
-  __shared__ int32_t deg_s[4][kMaxN], off_s[4][kMaxN];
+  __shared__ int32_t deg_s[4][kMaxN], off_s[4][kMaxN], cnt_s[4][kMaxN];
   const int nT = in.n_ions * in.Vb;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mols = in.n_ions * in.B;
@@ -414,18 +414,34 @@ __global__ __launch_bounds__(256) void wide_place_kernel(Inputs in, const int32_
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    // slot order inside a row's list: rank = earlier valid slots with the same target
-    for (int e = lane; e < in.E; e += 64) {
-      const int tg = tg_s[wave][e];
-      if (tg < 0) continue;
-      int rank = 0;
-      for (int e2 = 0; e2 < e; ++e2) rank += tg_s[wave][e2] == tg ? 1 : 0;
-      csr[(int64_t)mol * in.E + off_s[wave][tg] + rank] = pos_s[wave][e];
-      const int dg = deg_s[wave][tg];  // (wide_iota_kernel: the sources of rows with one or two in-edges)
-      if (dg <= 2 && direct_ok) (rank == 0 ? c2a : c2b)[rb + tg] = ~pos_s[wave][e];
-    }
+    // slot order inside a row's list: rank = earlier valid slots with the same target = those of earlier 64-slot groups
+    // (a running count per target in LDS) + the lower lanes of this group that name the same target (63 readlanes).
+    // (Walking all earlier slots per slot was E^2 / 64 LDS reads per lane: 390 us per call at the explicit-hydrogen
+    //  shape E = 640, a tenth of the whole encode.)
+    for (int n = lane; n < r; n += 64) cnt_s[wave][n] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
+    for (int e0 = 0; e0 < in.E; e0 += 64) {
+      const int e = e0 + lane;
+      const int tg = e < in.E ? tg_s[wave][e] : -1;
+      int rank = 0;
+#pragma unroll
+      for (int j = 0; j < 63; ++j) {
+        const int tj = __builtin_amdgcn_readlane(tg, j);
+        rank += (j < lane && tj == tg) ? 1 : 0;
+      }
+      if (tg >= 0) {
+        rank += cnt_s[wave][tg];
+        csr[(int64_t)mol * in.E + off_s[wave][tg] + rank] = pos_s[wave][e];
+        const int dg = deg_s[wave][tg];  // (wide_iota_kernel: the sources of rows with one or two in-edges)
+        if (dg <= 2 && direct_ok) (rank == 0 ? c2a : c2b)[rb + tg] = ~pos_s[wave][e];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // every lane has read the counts of the earlier groups
+      __builtin_amdgcn_wave_barrier();
+      if (tg >= 0) atomicAdd(&cnt_s[wave][tg], 1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 

@@ -66,7 +66,8 @@ def test_encoder_shape_coverage_is_reported():
     assert (256 << 20) < need.value < (2 << 30)
     assert lib.impnn_encoder_workspace_bytes(2, 64, 40, 80, 64, 8, 3, 72, TYPED, 0, C.byref(need)) == 0        # D=64
     assert lib.impnn_encoder_workspace_bytes(2, 64, 40, 80, 48, 8, 3, 72, TYPED, 0, C.byref(need)) == -2       # D=48
-    assert lib.impnn_encoder_workspace_bytes(2, 64, 40, 600, 128, 8, 3, 72, TYPED, 0, C.byref(need)) == -2     # E > 512
+    assert lib.impnn_encoder_workspace_bytes(2, 64, 40, 1100, 128, 8, 3, 72, TYPED, 0, C.byref(need)) == -2    # E > 1024
+    assert lib.impnn_encoder_workspace_bytes(2, 64, 160, 640, 128, 8, 3, 72, TYPED, 0, C.byref(need)) == 0 and need.value > 0
     assert lib.impnn_encoder_workspace_bytes(2, 64, 40, 80, 128, 8, 3, 72, 3, 0, C.byref(need)) == 0           # f32x3 (round 3)
     # K = D*D (train_melting_point.py:146): the typed mode covers it (BASELINE config 3), the pull form does not
     assert lib.impnn_encoder_workspace_bytes(2, 8192, 40, 80, 32, 1024, 4, 72, TYPED, 0, C.byref(need)) == 0

@@ -395,3 +395,35 @@ def test_wide_encoder_single_atom_anions(mode):
     first = {int(v): int(np.argmax(ids == v)) for v in np.unique(ids)}
     ref_rows = pa[torch.as_tensor([first[int(v)] for v in ids], device=pa.device)]
     assert torch.equal(pa, ref_rows)
+
+
+@pytest.mark.parametrize("mode", WIDE_MODES)
+@pytest.mark.parametrize("D,S,B", [(128, 6, 1024), (64, 3, 512)])
+def test_wide_encoder_explicit_hydrogen_shape(D, S, B, mode):
+    """The padded shape of the reference's real (explicit-hydrogen) data sets at wide states - N = 160, E = 640
+    (src/featurize.py:45, train_viscosity.py:95,288-289 with atom_dim=128, num_steps=6): the wide encoder takes E <= 1024
+    (round 2: 512, so this shape ran layer at a time).  Sampled molecules vs the oracle, shard-concat bitwise, and the
+    layer-at-a-time HIP path."""
+    Va, Vb, N, E = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, 160, 640
+    inp = synthetic.make_explicit_h_batch(B, max_atoms=N, max_edges=E, seed=51)
+    valid = (inp["cat_connectivity"][:, :, 0] > 0) & (inp["cat_connectivity"][:, :, 1] > 0)
+    assert valid.sum(axis=1).max() > 512
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=D, bond_dim=8, num_steps=S, seed=52, perturb=True)
+    m = make_model(w, Va, Vb, D, mode=mode)
+    assert m.resolve_encoder_mode(N, E) == mode and m.fused_supported(N, E)
+    d = to_dev(inp)
+    pc, pa = m.encode_pooled(d, fused=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(pc).all() and torch.isfinite(pa).all()
+    idx = np.random.default_rng(8).choice(B, size=10, replace=False)
+    idx[0] = int(valid.sum(axis=1).argmax())
+    rc, ra = oracle_pooled(w, {k: v[idx] for k, v in inp.items()})
+    assert_close(pc.cpu().numpy()[idx], rc, what="explicit-H cat pooled (sample)")
+    assert_close(pa.cpu().numpy()[idx], ra, what="explicit-H an pooled (sample)")
+    h = B // 2 + 9
+    c0, a0 = m.encode_pooled({k: v[:h].contiguous() for k, v in d.items()}, fused=True)
+    c1, a1 = m.encode_pooled({k: v[h:].contiguous() for k, v in d.items()}, fused=True)
+    assert torch.equal(torch.cat([c0, c1]), pc) and torch.equal(torch.cat([a0, a1]), pa)
+    lc, la = m.encode_pooled({k: v[:32].contiguous() for k, v in d.items()}, fused=False)
+    assert_close(lc.cpu().numpy(), pc[:32].cpu().numpy(), what="explicit-H layered vs wide cat")
+    assert_close(la.cpu().numpy(), pa[:32].cpu().numpy(), what="explicit-H layered vs wide an")
