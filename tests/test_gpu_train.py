@@ -326,6 +326,31 @@ def test_wide_state_model_gradients_match_the_oracle(B, N):
         close(t.grad, wo[name].grad, 2e-4, f"grad {name}")
 
 
+@pytest.mark.parametrize("D,B", [(64, 6), (32, 5)])
+def test_gradients_at_the_explicit_hydrogen_padded_shape(D, B):
+    """Training on the padded shape of the reference's real data sets (N = 160, E = 640: src/featurize.py:45,
+    train_viscosity.py:95,288-289) - long edge lists per molecule in the message / Reduce adjoints, kept activations in
+    the GatedUpdate pair: every parameter gradient against fp64 autograd over oracle/torch_ref.py."""
+    Va, Vb, K, S, N, E = 13, 6, 4, 2, 160, 640
+    w = weights.init_weights("viscosity", Va, Vb, atom_dim=D, bond_dim=K, fp_size=12, mixing_size=10, num_steps=S, seed=19,
+                             perturb=True)
+    m = MM.build_model(Va, Vb, atom_dim=D, bond_dim=K, fp_size=12, mixing_size=10, num_steps=S, device=DEV)
+    m.load_weights(w)
+    inp = synthetic.make_explicit_h_batch(B, max_atoms=N, max_edges=E, atom_vocab_size=Va, bond_vocab_size=Vb, seed=19)
+    y = np.random.default_rng(19).normal(1.0, 0.5, size=B).astype(np.float32)
+    m.compile(train.Adam(1e-3, clipnorm=1.0))
+    loss = m._loss(m._to_device(inp), y, training=True)
+    loss.backward()
+    wo = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w.items()}
+    pred = TR.viscosity_forward(wo, inp, torch.float64)
+    lo = torch.mean((pred.reshape(-1) - torch.tensor(y, dtype=torch.float64)) ** 2) \
+        + 1e-4 * ((wo["cat_fp/kernel"] ** 2).sum() + (wo["an_fp/kernel"] ** 2).sum())
+    lo.backward()
+    close(loss, lo, 1e-5, "loss")
+    for name, t in m.trainable_variables():
+        close(t.grad, wo[name].grad, 2e-4, f"grad {name}")
+
+
 @pytest.mark.parametrize("D", [16, 64])
 def test_gradients_with_single_atom_anions_and_few_bond_types(D):
     """The statistics real ionic-liquid data has - halide-like anions (one atom, no bond) and two bond types - through
