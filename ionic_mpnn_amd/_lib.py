@@ -64,6 +64,8 @@ SIGNATURES = {
     "impnn_bmm_message_typed_sorted": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
     "impnn_bmm_message_typed_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
     "impnn_message_reduce_typed_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32, vp]),
+    "impnn_message_reduce_typed_bwd_scratch": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32,
+                                                         vp]),
     "impnn_bond_type_matrices_bwd": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]),
     "impnn_bond_type_matrices_multi": (C.c_int, [vp, PP, PP, i32, i32, i32, i32, vp]),
     "impnn_bond_type_matrices_multi_bwd": (C.c_int, [vp, PP, PP, PP, vp, i32, i32, i32, i32, i32, vp]),

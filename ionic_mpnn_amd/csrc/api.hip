@@ -531,6 +531,22 @@ int impnn_message_reduce_typed_bwd(const float* h, const int32_t* bond_ids, cons
                                       as_stream(stream));
 }
 
+int impnn_message_reduce_typed_bwd_scratch(const float* h, const int32_t* bond_ids, const int32_t* conn,
+                                           const float* type_mats, const float* dagg, float* dh, float* dtype_mats,
+                                           void* workspace, int64_t workspace_bytes, float* edge_scratch, int32_t B,
+                                           int32_t N, int32_t E, int32_t D, int32_t Vb, int32_t sorted_ready,
+                                           impnn_stream_t stream) {
+  REQUIRE(B >= 0 && N > 0 && E >= 0 && D > 0 && Vb > 0, "bad shape");
+  if (B == 0 || E == 0) return IMPNN_OK;
+  REQUIRE(h && bond_ids && conn && type_mats && dagg && dh && dtype_mats && workspace && edge_scratch, "null pointer");
+  if (workspace_bytes < impnn_bmm_message_typed_bwd_workspace_bytes(B, E, Vb))
+    return fail(IMPNN_E_WORKSPACE, "message_reduce_typed_bwd_scratch: workspace of %lld bytes is too small",
+                (long long)workspace_bytes);
+  return launch_bmm_message_typed_bwd(h, bond_ids, conn, type_mats, dagg, dh, dtype_mats,
+                                      static_cast<int32_t*>(workspace), B, N, E, D, Vb, sorted_ready != 0, 1,
+                                      as_stream(stream), edge_scratch);
+}
+
 int impnn_bond_type_matrices_bwd(const float* bond_table, const float* W, const float* dtype_mats, float* dW,
                                  float* dbond_table, int32_t Vb, int32_t K, int32_t D, int32_t accumulate,
                                  impnn_stream_t stream) {

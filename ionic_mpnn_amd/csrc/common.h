@@ -38,7 +38,7 @@ int launch_bmm_message_typed(const float* h, const int32_t* bond_ids, const int3
                              const float* type_mats, float* m, int B, int N, int E, int D, int Vb,
                              hipStream_t s);
 int launch_reduce_scatter_add(const float* m, const int32_t* tgt, int tgt_stride, float* agg, int B,
-                              int N, int E, int D, hipStream_t s);
+                              int N, int E, int D, hipStream_t s, int accumulate = 0);
 int launch_gated_update(const float* h, const float* agg, const float* Wz, const float* bz,
                         const float* Wr, const float* br, const float* Wh, const float* bh,
                         const float* gamma, const float* beta, float eps, float* out, int64_t rows,
@@ -77,7 +77,7 @@ int launch_bmm_message_typed_sorted(const float* h, const int32_t* bond_ids, con
                                     hipStream_t s);
 int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn, const float* A,
                                  const float* dm, float* dh, float* dA, int32_t* workspace, int B, int N, int E,
-                                 int D, int Vb, int sorted_ready, int from_agg, hipStream_t s);
+                                 int D, int Vb, int sorted_ready, int from_agg, hipStream_t s, float* du = nullptr);
 int launch_strided_gemm(const float* A, const float* B, float* out, int64_t rows, int M, int N, int64_t a_rs,
                         int64_t a_cs, int64_t b_rs, int64_t b_cs, hipStream_t s);
 int launch_bond_type_matrices_multi(const float* tb, const float* const* W, float* const* out, int n, int Vb, int K,

@@ -339,9 +339,11 @@ __global__ __launch_bounds__(512) void bmm_message_typed_d32_kernel(
 // order and adds into its own column of agg[b] - no atomics, bitwise equal to a sequential
 // scatter_nd.  agg[b] lives in LDS when it fits, else directly in HBM/L2.
 // ---------------------------------------------------------------------------------------
+// accumulate: the sums start from what agg holds instead of from zero (the message adjoint's source-row sums on top
+// of the GatedUpdate's dh: launch_bmm_message_typed_bwd with a per-edge buffer).
 __global__ void reduce_scatter_kernel(const float* __restrict__ m, const int32_t* __restrict__ tgt,
                                       int tgt_stride, float* __restrict__ agg, int B, int N, int E,
-                                      int D, int mols_per_block, int use_lds) {
+                                      int D, int mols_per_block, int use_lds, int accumulate) {
   extern __shared__ __align__(16) float smem[];
   const int cols = D < (int)blockDim.x ? D : (int)blockDim.x;  // threads per molecule
   const int ml = threadIdx.x / cols;
@@ -350,8 +352,11 @@ __global__ void reduce_scatter_kernel(const float* __restrict__ m, const int32_t
   const bool active = ml < mols_per_block && b < B;
   float* acc = use_lds ? smem + (size_t)ml * N * D : (active ? agg + (int64_t)b * N * D : nullptr);
   if (active) {
-    for (int n = 0; n < N; ++n)
-      for (int i = c0; i < D; i += cols) acc[(size_t)n * D + i] = 0.f;
+    if (use_lds || !accumulate) {
+      const float* ab0 = agg + (int64_t)b * N * D;
+      for (int n = 0; n < N; ++n)
+        for (int i = c0; i < D; i += cols) acc[(size_t)n * D + i] = accumulate ? ab0[(size_t)n * D + i] : 0.f;
+    }
     const float* mb = m + (int64_t)b * E * D;
     const int32_t* tb = tgt + (int64_t)b * E * tgt_stride;
     if (cols == D) {  // one column per thread: keep 16 edge rows in flight; adds stay in edge-slot order
@@ -1371,9 +1376,9 @@ __global__ __launch_bounds__(256) void reduce_scatter_small_kernel(const float* 
 }
 
 int launch_reduce_scatter_add(const float* m, const int32_t* tgt, int tgt_stride, float* agg, int B,
-                              int N, int E, int D, hipStream_t s) {
+                              int N, int E, int D, hipStream_t s, int accumulate) {
   if (B == 0) return IMPNN_OK;
-  if (B < 2048 && D <= 128 && E > 0 && E < 65536 && N < 65536) {  // too few (molecule, column) threads to hide latency
+  if (!accumulate && B < 2048 && D <= 128 && E > 0 && E < 65536 && N < 65536) {  // too few (molecule, column) threads to hide latency
     int P = 256 / D;
     P = P > kRsP ? kRsP : P;
     const size_t l = sizeof(float) * (size_t)N * D + sizeof(uint16_t) * ((size_t)P * E + E);
@@ -1391,7 +1396,7 @@ int launch_reduce_scatter_add(const float* m, const int32_t* tgt, int tgt_stride
     (void)hipFuncSetAttribute((const void*)reduce_scatter_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   reduce_scatter_kernel<<<(B + mpb - 1) / mpb, kBlock, lds, s>>>(m, tgt, tgt_stride, agg, B, N, E, D, mpb,
-                                                                 use_lds);
+                                                                 use_lds, accumulate);
   return check_launch("reduce_scatter_add");
 }
 

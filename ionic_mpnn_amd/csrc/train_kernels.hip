@@ -335,7 +335,10 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
     const float* __restrict__ h, const int32_t* __restrict__ conn, const float* __restrict__ A,
     const float* __restrict__ dm, float* __restrict__ dh, float* __restrict__ dA, const int32_t* __restrict__ start,
     const int32_t* __restrict__ segbase, const int32_t* __restrict__ order, int N, int E, int Vb, int from_agg,
-    int owner_mode) {
+    int owner_mode, float* __restrict__ du) {
+  // du (optional, (B,E,D) with zero rows at masked edges): the per-edge vectors A_t^T g_e go to their edge slot's row with
+  // plain 16-byte stores and a slot-order pass (reduce_scatter_kernel keyed by the source index) adds them into dh -
+  // instead of float atomics on dh from here: 22 M of them at batch 4096 were 260 of the kernel's 349 us.
   // owner_mode (small batches): workgroup t takes ALL segments of bond type t and is the only one that touches dA_t,
   // which it updates with plain loads / adds / stores - flushing 64 KB of accumulators with float atomics after a
   // single segment costs ~50 us per workgroup (one 256-byte atomic wave-instruction per ~50 ns and CU).
@@ -350,6 +353,7 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
   int32_t* hrow_s = reinterpret_cast<int32_t*>(X + kSeg * LD);  // kSeg source rows (b * N + src)
   int32_t* sb_s = hrow_s + kSeg;    // segbase[0 .. Vb]
   int32_t* st_s = sb_s + Vb + 1;    // start[0 .. Vb]
+  int32_t* be_s = st_s + Vb + 1;    // kSeg edge slots (b * E + e; -1 past the segment's edges) - with du
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, a = lane & 15, q = lane >> 4;
   const int nseg = segbase[Vb];
   const int per = (nseg + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -394,6 +398,7 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
   int64_t hrow_x[kX];
   f32x4_t gr[kX], xr[kX];
   int hrow_n[kX], ok_n[kX];  // of the pieces held in gr / xr
+  int bes_a[kX], bes_n[kX];  // their edge slots (with du)
   auto stage_c = [&](const Seg& d, int* be, int* ok) {
 #pragma unroll
     for (int i = 0; i < kX; ++i) {
@@ -405,13 +410,14 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
       be[i] = order[d.p0 + (e < d.n ? e : e % d.n)];
     }
   };
-  auto stage_b = [&](const int* be, int* hrow, int* grow) {
+  auto stage_b = [&](const int* be, int* hrow, int* grow, int* bes) {
 #pragma unroll
     for (int i = 0; i < kX; ++i) {
       const int b = be[i] / E;
       const int2 st = *reinterpret_cast<const int2*>(conn + (int64_t)be[i] * 2);
       hrow[i] = b * N + st.x;
       grow[i] = from_agg ? b * N + st.y : be[i];
+      bes[i] = be[i];
     }
   };
   auto stage_a = [&](const int* hrow, const int* grow) {
@@ -429,7 +435,10 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
       const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
       stv4(G + e * LD + 4 * c4, ok_n[i] ? gr[i] : zero);  // rows past the segment's edges are zero: they add nothing to dA
       stv4(X + e * LD + 4 * c4, ok_n[i] ? xr[i] : zero);
-      if (c4 == 0) hrow_s[e] = hrow_n[i];
+      if (c4 == 0) {
+        hrow_s[e] = hrow_n[i];
+        be_s[e] = ok_n[i] ? bes_n[i] : -1;
+      }
     }
   };
   auto load_matrix = [&](int ty) {  // transposing copy: lanes run along i (conflict-free LDS stores)
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
   {
     int be0[kX], ok0[kX], hr0[kX], gr0[kX];
     stage_c(d0, be0, ok0);
-    stage_b(be0, hr0, gr0);
+    stage_b(be0, hr0, gr0, bes_n);
     stage_a(hr0, gr0);
 #pragma unroll
     for (int i = 0; i < kX; ++i) {
@@ -462,7 +471,7 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
     load_matrix(d0.ty);
     park();
     stage_c(d1, be0, ok0);
-    stage_b(be0, hrow_a, grow_a);
+    stage_b(be0, hrow_a, grow_a, bes_a);
 #pragma unroll
     for (int i = 0; i < kX; ++i) ok_a[i] = ok0[i];
     stage_c(d2, be_b, ok_b);
@@ -501,14 +510,15 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
   };
   for (int seg = s0; seg < s1; ++seg) {
     // requests for the segments ahead (each consumes what the previous iteration requested)
-    int hrow_t[kX], ok_t[kX];
+    int hrow_t[kX], ok_t[kX], bes_t[kX];
 #pragma unroll
     for (int i = 0; i < kX; ++i) {
       hrow_t[i] = hrow_a[i];
       ok_t[i] = ok_a[i];
+      bes_t[i] = bes_a[i];
     }
     stage_a(hrow_a, grow_a);                 // rows of seg + 1
-    stage_b(be_b, hrow_a, grow_a);           // row indices of seg + 2
+    stage_b(be_b, hrow_a, grow_a, bes_a);    // row indices of seg + 2
 #pragma unroll
     for (int i = 0; i < kX; ++i) {
       ok_a[i] = ok_b[i];
@@ -539,12 +549,21 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
       // (unconditional: rows past the segment's edges are zero in G, so their sums are exact zeros added to rows of
       //  the segment's real edges - a conditional atomic would keep the compiler from counting outstanding
       //  memory operations, and the LDS stores below would wait for every atomic of the tile)
-      float* dst = dh + (int64_t)hrow_s[16 * et + a] * D + 16 * (fg * NLW) + 4 * q;
 #ifndef IMPNN_DIAG_BWD_NODH
+      if (du) {  // (workgroup-uniform)
+        const int bes = be_s[16 * et + a];
+        if (bes >= 0) {
+          float* dst = du + (int64_t)bes * D + 16 * (fg * NLW) + 4 * q;
 #pragma unroll
-      for (int TL = 0; TL < NLW; ++TL)
+          for (int TL = 0; TL < NLW; ++TL) stv4(dst + 16 * TL, acc1[TL]);
+        }
+      } else {
+        float* dst = dh + (int64_t)hrow_s[16 * et + a] * D + 16 * (fg * NLW) + 4 * q;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) atomicAdd(dst + 16 * TL + g, acc1[TL][g]);
+        for (int TL = 0; TL < NLW; ++TL)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) atomicAdd(dst + 16 * TL + g, acc1[TL][g]);
+      }
 #endif
     }
     // ---- GEMM 2: dA_t += G^T X over the segment's edges (k = edge)
@@ -569,6 +588,7 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_mfma_kernel(
     for (int i = 0; i < kX; ++i) {
       hrow_n[i] = hrow_t[i];
       ok_n[i] = ok_t[i];
+      bes_n[i] = bes_t[i];
     }
     park();
     if (new_type) load_matrix(d1.ty);
@@ -2710,7 +2730,7 @@ int launch_bmm_message_typed_sorted(const float* h, const int32_t* bond_ids, con
 
 int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const int32_t* conn, const float* A,
                                  const float* dm, float* dh, float* dA, int32_t* workspace, int B, int N, int E,
-                                 int D, int Vb, int sorted_ready, int from_agg, hipStream_t s) {
+                                 int D, int Vb, int sorted_ready, int from_agg, hipStream_t s, float* du) {
   if (Vb > kMaxTypes) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed_bwd: Vb=%d too large", Vb);
   if (D > 128) return fail(IMPNN_E_UNSUPPORTED, "bmm_message_typed_bwd: D=%d > 128", D);
   const int64_t BE = (int64_t)B * E;
@@ -2727,19 +2747,23 @@ int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const 
   const char* force = getenv("IMPNN_MESSAGE_BWD");  // diagnostics: "valu" / "mfma"
   const bool want_mfma = force ? force[0] == 'm' : true;
   if ((D == 64 || D == 128) && Vb <= kBwdMfmaMaxTypes && al16 && want_mfma) {
-    const size_t lm = sizeof(float) * ((size_t)D * (D + 4) + 2 * (size_t)kSeg * (D + 4)) + sizeof(int32_t) * (kSeg + 2 * (size_t)(Vb + 1));
+    const size_t lm = sizeof(float) * ((size_t)D * (D + 4) + 2 * (size_t)kSeg * (D + 4)) + sizeof(int32_t) * (2 * kSeg + 2 * (size_t)(Vb + 1));
+    if (du && (reinterpret_cast<uintptr_t>(du) & 15u)) return fail(IMPNN_E_BADARG, "message backward: the per-edge buffer must be 16B aligned");
     // one workgroup per type without atomics on dA ("mo", diagnostics) was never faster than balanced segment ranges:
     // 26.8 vs 26.1 us per call at batch 32, 423 vs 331 us at batch 4096 (VALU kernel: 41.7 / 887 us)
     const int owner = force && force[1] == 'o' ? 1 : 0;
     const int grid = owner ? Vb : (int)(max_segs < 256 ? max_segs : 256);
     if (D == 128) {
       (void)hipFuncSetAttribute((const void*)bmm_message_typed_bwd_mfma_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
-      bmm_message_typed_bwd_mfma_kernel<8><<<grid, 1024, lm, s>>>(h, conn, A, dm, dh, dA, start, segbase, order, N, E, Vb, from_agg, owner);
+      bmm_message_typed_bwd_mfma_kernel<8><<<grid, 1024, lm, s>>>(h, conn, A, dm, dh, dA, start, segbase, order, N, E, Vb, from_agg, owner, du);
     } else {
       (void)hipFuncSetAttribute((const void*)bmm_message_typed_bwd_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lm);
-      bmm_message_typed_bwd_mfma_kernel<4><<<grid, 1024, lm, s>>>(h, conn, A, dm, dh, dA, start, segbase, order, N, E, Vb, from_agg, owner);
+      bmm_message_typed_bwd_mfma_kernel<4><<<grid, 1024, lm, s>>>(h, conn, A, dm, dh, dA, start, segbase, order, N, E, Vb, from_agg, owner, du);
     }
-    return check_launch("bmm_message_typed_bwd (mfma)");
+    if (int rc = check_launch("bmm_message_typed_bwd (mfma)")) return rc;
+    // the per-edge vectors, added into dh at their source rows in edge-slot order (conn[b, e, 0]: stride 2)
+    if (du) return launch_reduce_scatter_add(du, conn, 2, dh, B, N, E, D, s, 1);
+    return IMPNN_OK;
   }
   const size_t lds = sizeof(float) * ((size_t)D * D + 2 * (size_t)kSeg * D);
   // wide states need > 64 KB of LDS (one workgroup per CU): 16 waves instead of 4 keep every SIMD busy

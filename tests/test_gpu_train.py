@@ -103,6 +103,51 @@ def test_message_backward_on_the_matrix_cores_equals_the_valu_kernel(D, Vb, from
     close(dA1, dA0.double().cpu(), 5e-6, "dA mfma vs valu")
 
 
+@pytest.mark.parametrize("D,Vb,B,N,E", [(128, 12, 700, 40, 80), (64, 72, 700, 40, 80), (128, 72, 32, 40, 80), (128, 9, 40, 160, 640),
+                                        (64, 5, 3000, 12, 30)])
+def test_message_backward_through_the_edge_buffer(D, Vb, B, N, E):
+    """impnn_message_reduce_typed_bwd_scratch: per-edge vectors into the (zero-rowed) message buffer, then slot-order sums
+    at the source rows on top of what dh holds - the same dh as the atomics form up to f32 addition order, equal bits
+    from run to run, masked edges' rows left zero."""
+    from ionic_mpnn_amd import _lib
+    rng = np.random.default_rng(D + Vb + B)
+    conn, bond, _ = rand_graph(B, N, E, Vb, rng)
+    h = torch.tensor(rng.normal(size=(B, N, D)), dtype=torch.float32, device=DEV)
+    mats = torch.tensor(rng.normal(size=(Vb, D, D)) / np.sqrt(D), dtype=torch.float32, device=DEV)
+    dagg = torch.tensor(rng.normal(size=(B, N, D)), dtype=torch.float32, device=DEV)
+    dh_init = torch.tensor(rng.normal(size=(B, N, D)), dtype=torch.float32, device=DEV)
+    cg, bg = torch.tensor(conn, device=DEV), torch.tensor(bond, device=DEV)
+    lib = _lib.load()
+    nb = int(lib.impnn_bmm_message_typed_bwd_workspace_bytes(B, E, Vb))
+    # the buffer as a forward call leaves it: messages at valid edges, zero rows elsewhere
+    m = ops.bmm_message_typed(h, bg, cg, mats)
+    valid = (cg[:, :, 0] > 0) & (cg[:, :, 1] > 0) & (bg >= 0) & (bg < Vb)
+    assert float(m[~valid].abs().max()) == 0.0 if (~valid).any() else True
+
+    def run(scratch):
+        dh, dA = dh_init.clone(), torch.zeros_like(mats)
+        ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+        common = (ops.ptr(h), ops.ptr(bg), ops.ptr(cg), ops.ptr(mats), ops.ptr(dagg), ops.ptr(dh), ops.ptr(dA), ops.ptr(ws),
+                  ws.numel())
+        if scratch is None:
+            _lib.check(lib.impnn_message_reduce_typed_bwd(*common, B, N, E, D, Vb, 0, _lib.stream_ptr()))
+        else:
+            _lib.check(lib.impnn_message_reduce_typed_bwd_scratch(*common, ops.ptr(scratch), B, N, E, D, Vb, 0,
+                                                                  _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        return dh, dA
+
+    dh0, dA0 = run(None)
+    buf = m.clone()
+    dh1, dA1 = run(buf)
+    dh2, _ = run(buf)          # the buffer is reused as it comes back (a training loop does)
+    close(dh1, dh0.double().cpu(), 5e-6, "dh edge buffer vs atomics")
+    close(dA1, dA0.double().cpu(), 5e-6, "dA edge buffer vs atomics")
+    assert torch.equal(dh1, dh2)
+    if (~valid).any():
+        assert float(buf[~valid].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("D,K,n,sinks", [(32, 8, 6, True), (8, 4, 3, False), (16, 5, 18, True), (64, 8, 3, True),
                                          (128, 8, 12, False), (32, 12, 4, True)])
 def test_type_matrices_of_all_layers_in_one_node(D, K, n, sinks):

@@ -14,10 +14,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--dim", type=int, default=128)
 ap.add_argument("--iters", type=int, default=50)
+ap.add_argument("--explicit-h", action="store_true", help="N = 160, E = 640 molecules (synthetic.make_explicit_h_batch)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 B, D, Vb = a.batch, a.dim, synthetic.DEFAULT_VB
-inp = synthetic.make_batch(B, seed=0)
+inp = synthetic.make_explicit_h_batch(B, seed=0) if a.explicit_h else synthetic.make_batch(B, seed=0)
 conn = torch.from_numpy(inp["cat_connectivity"]).to(dev)
 bond = torch.from_numpy(inp["cat_bond"]).to(dev)
 N, E = inp["cat_atom"].shape[1], conn.shape[1]
