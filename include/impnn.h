@@ -371,9 +371,9 @@ int impnn_message_reduce_typed_bwd(const float* h, const int32_t* bond_ids, cons
                                    int32_t D, int32_t Vb, int32_t sorted_ready, impnn_stream_t stream);
 /*  The same with a (B,E,D) buffer whose rows at masked / out-of-range edges are ZERO - the message buffer an
  *  impnn_bmm_message_typed_sorted call of the same (bond_ids, conn) left behind is one (its other rows are overwritten
- *  here).  atom_dim 64 / 128: the per-edge vectors A_t^T g_e go to their edge slot's row and a slot-order pass adds
- *  them into dh at the source rows - no float atomics on dh (22 M of them at batch 4096, 260 of the kernel's 349 us),
- *  and dh becomes bitwise reproducible.  Other widths: as impnn_message_reduce_typed_bwd, the buffer is not touched. */
+ *  here).  The per-edge vectors A_t^T g_e go to their edge slot's row and a slot-order pass adds them into dh at the
+ *  source rows - no float atomics on dh (22 M of them at atom_dim 128, batch 4096: 260 of the kernel's 349 us), and
+ *  dh becomes bitwise reproducible. */
 int impnn_message_reduce_typed_bwd_scratch(const float* h, const int32_t* bond_ids, const int32_t* conn,
                                            const float* type_mats, const float* dagg, float* dh, float* dtype_mats,
                                            void* workspace, int64_t workspace_bytes, float* edge_scratch, int32_t B,

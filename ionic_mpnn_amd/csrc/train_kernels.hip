@@ -265,9 +265,11 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_kernel(
     const float* __restrict__ h, const int32_t* __restrict__ conn, const float* __restrict__ A,
     const float* __restrict__ dm, float* __restrict__ dh, float* __restrict__ dA, const int32_t* __restrict__ start,
     const int32_t* __restrict__ segbase, const int32_t* __restrict__ order, int N, int E, int D, int Vb,
-    int from_agg) {  // from_agg: dm is the gradient of Reduce's output (B,N,D) and dm of edge e is its row tgt(e)
+    int from_agg, float* __restrict__ du) {  // from_agg: dm is the gradient of Reduce's output (B,N,D) and dm of edge e is its row tgt(e)
+  // du (optional): per-edge vectors to their edge slot's row instead of atomics on dh (see the matrix-core kernel below)
   extern __shared__ __align__(16) float smem[];
   __shared__ int64_t srcrow[kSeg];
+  __shared__ int64_t slot[kSeg];
   const int seg = blockIdx.x;
   if (seg >= segbase[Vb]) return;  // the grid is an upper bound on the number of segments
   int lo = 0, hi = Vb - 1;          // type of this segment: largest t with segbase[t] <= seg
@@ -292,7 +294,10 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_kernel(
     const int64_t grow = from_agg ? (be / E) * N + conn[be * 2 + 1] : be;
     gm[e * D + c] = dm[grow * D + c];
     xm[e * D + c] = h[row * D + c];
-    if (c == 0) srcrow[e] = row;
+    if (c == 0) {
+      srcrow[e] = row;
+      slot[e] = be;
+    }
   }
   __syncthreads();
   const int lanes = (int)blockDim.x / D > 0 ? (int)blockDim.x / D : 1;
@@ -301,7 +306,8 @@ __global__ __launch_bounds__(1024) void bmm_message_typed_bwd_kernel(
     for (int e = el; e < n; e += lanes) {
       float u = 0.f;
       for (int i = 0; i < D; ++i) u = fmaf(gm[e * D + i], As[i * D + j], u);
-      atomicAdd(&dh[srcrow[e] * D + j], u);
+      if (du) du[slot[e] * D + j] = u;
+      else atomicAdd(&dh[srcrow[e] * D + j], u);
     }
   }
 #pragma unroll
@@ -2775,13 +2781,17 @@ int launch_bmm_message_typed_bwd(const float* h, const int32_t* bond_ids, const 
       (void)hipFuncSetAttribute((const void*)bmm_message_typed_bwd_kernel<ACC>,                              \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
     bmm_message_typed_bwd_kernel<ACC><<<(int)max_segs, threads, lds, s>>>(h, conn, A, dm, dh, dA, start, segbase, \
-                                                                           order, N, E, D, Vb, from_agg);   \
+                                                                           order, N, E, D, Vb, from_agg, du);\
   } while (0)
   if (acc <= 1) LAUNCH(1);
   else if (acc <= 4) LAUNCH(4);
   else if (acc <= 16) LAUNCH(16);
   else LAUNCH(64);
 #undef LAUNCH
+  if (du) {
+    if (int rc = check_launch("bmm_message_typed_bwd")) return rc;
+    return launch_reduce_scatter_add(du, conn, 2, dh, B, N, E, D, s, 1);
+  }
   return check_launch("bmm_message_typed_bwd");
 }
 

@@ -104,7 +104,7 @@ def test_message_backward_on_the_matrix_cores_equals_the_valu_kernel(D, Vb, from
 
 
 @pytest.mark.parametrize("D,Vb,B,N,E", [(128, 12, 700, 40, 80), (64, 72, 700, 40, 80), (128, 72, 32, 40, 80), (128, 9, 40, 160, 640),
-                                        (64, 5, 3000, 12, 30)])
+                                        (64, 5, 3000, 12, 30), (32, 72, 900, 40, 80), (16, 7, 50, 9, 14)])
 def test_message_backward_through_the_edge_buffer(D, Vb, B, N, E):
     """impnn_message_reduce_typed_bwd_scratch: per-edge vectors into the (zero-rowed) message buffer, then slot-order sums
     at the source rows on top of what dh holds - the same dh as the atomics form up to f32 addition order, equal bits
