@@ -281,7 +281,7 @@ def time_other_configs(dev, Va, Vb):
 
     # configs[4]: the full training step at atom_dim 128, 6 steps
     D, K, S = 128, 8, 6
-    for B, graphed, iters in ((32, True, 30), (4096, True, 8)):  # (eager launches at batch 4096: 15.8 vs 15.2 ms)
+    for B, graphed, iters in ((32, True, 100), (4096, True, 8)):  # (eager launches at batch 4096: 15.8 vs 15.2 ms)
         inp = synthetic.make_batch(B, seed=0)
         y = np.random.default_rng(0).normal(4.0, 1.0, size=B).astype(np.float32)
         m = model.build_model(Va, Vb, atom_dim=D, bond_dim=K, num_steps=S, device=dev)
