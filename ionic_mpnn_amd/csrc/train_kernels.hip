@@ -1537,10 +1537,12 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
       const float hv = in ? h[src] : 0.f, av = in ? agg[src] : 0.f;
       cs[r * LDC + c] = hv;
       cs[r * LDC + D + c] = av;
+#ifndef IMPNN_DIAG_GUB_NOCOPY
       if (hc && in) {
         hc[row0 * D + t] = hv;
         aggc[row0 * D + t] = av;
       }
+#endif
     }
     const float* crow = cs + (16 * rt + a) * LDC + 4 * q;
     const float* rrow = rhs + (16 * rt + a) * LDR + 4 * q;
@@ -1794,6 +1796,9 @@ __global__ __launch_bounds__(1024) void gated_update_bwd_wide16_kernel(
     };
     // [lo | hi] += A (rows of `arow`, 16 nsl contraction indices) x the nsl slices that start at `base`
     auto passT = [&](const float* base, int nsl, const float* arow) {
+#ifdef IMPNN_DIAG_GUB_NOGEMM  // (knock-out timing builds: tools/gu_pair_bench.py with IMPNN_LIB)
+      return;
+#endif
       f32x4_t preA, preB;
       fetchT(base, 0, preA);
       fetchT(base, 16, preB);
