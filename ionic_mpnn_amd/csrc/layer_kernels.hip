@@ -341,20 +341,26 @@ __global__ __launch_bounds__(512) void bmm_message_typed_d32_kernel(
 // ---------------------------------------------------------------------------------------
 // accumulate: the sums start from what agg holds instead of from zero (the message adjoint's source-row sums on top
 // of the GatedUpdate's dh: launch_bmm_message_typed_bwd with a per-edge buffer).
+// blockIdx.y: a range of `rows_per` target rows.  A row's sum only depends on the order of ITS in-edges, so workgroups that
+// each walk all edge slots and add the rows of their own range give the same bits as one walk - and small batches of
+// large molecules (the explicit-hydrogen shape at the reference's batch of 32: 16 workgroups, accumulators in HBM
+// because 160 x 128 floats x 2 molecules do not fit LDS) get gridDim.y times the threads and LDS accumulators again.
 __global__ void reduce_scatter_kernel(const float* __restrict__ m, const int32_t* __restrict__ tgt,
                                       int tgt_stride, float* __restrict__ agg, int B, int N, int E,
-                                      int D, int mols_per_block, int use_lds, int accumulate) {
+                                      int D, int mols_per_block, int use_lds, int accumulate, int rows_per) {
   extern __shared__ __align__(16) float smem[];
   const int cols = D < (int)blockDim.x ? D : (int)blockDim.x;  // threads per molecule
   const int ml = threadIdx.x / cols;
   const int c0 = threadIdx.x - ml * cols;
   const int b = blockIdx.x * mols_per_block + ml;
   const bool active = ml < mols_per_block && b < B;
-  float* acc = use_lds ? smem + (size_t)ml * N * D : (active ? agg + (int64_t)b * N * D : nullptr);
+  const int n_lo = blockIdx.y * rows_per, n_hi = n_lo + rows_per < N ? n_lo + rows_per : N;
+  // acc[(t - n_lo) * D + column]: the rows [n_lo, n_hi) of this molecule
+  float* acc = use_lds ? smem + (size_t)ml * rows_per * D : (active ? agg + ((int64_t)b * N + n_lo) * D : nullptr);
   if (active) {
     if (use_lds || !accumulate) {
-      const float* ab0 = agg + (int64_t)b * N * D;
-      for (int n = 0; n < N; ++n)
+      const float* ab0 = agg + ((int64_t)b * N + n_lo) * D;
+      for (int n = 0; n < n_hi - n_lo; ++n)
         for (int i = c0; i < D; i += cols) acc[(size_t)n * D + i] = accumulate ? ab0[(size_t)n * D + i] : 0.f;
     }
     const float* mb = m + (int64_t)b * E * D;
@@ -370,25 +376,25 @@ __global__ void reduce_scatter_kernel(const float* __restrict__ m, const int32_t
 #pragma unroll
         for (int u = 0; u < kU; ++u) t[u] = tb[(int64_t)(e + u) * tgt_stride];
 #pragma unroll
-        for (int u = 0; u < kU; ++u) v[u] = (t[u] > 0 && t[u] < N) ? mb[(int64_t)(e + u) * D + c0] : 0.f;
+        for (int u = 0; u < kU; ++u) v[u] = (t[u] > 0 && t[u] >= n_lo && t[u] < n_hi) ? mb[(int64_t)(e + u) * D + c0] : 0.f;
 #pragma unroll
         for (int u = 0; u < kU; ++u)
-          if (t[u] > 0 && t[u] < N) acc[(size_t)t[u] * D + c0] += v[u];
+          if (t[u] > 0 && t[u] >= n_lo && t[u] < n_hi) acc[(size_t)(t[u] - n_lo) * D + c0] += v[u];
       }
       for (; e < E; ++e) {
         const int t = tb[(int64_t)e * tgt_stride];
-        if (t > 0 && t < N) acc[(size_t)t * D + c0] += mb[(int64_t)e * D + c0];
+        if (t > 0 && t >= n_lo && t < n_hi) acc[(size_t)(t - n_lo) * D + c0] += mb[(int64_t)e * D + c0];
       }
     } else {
       for (int e = 0; e < E; ++e) {
         const int t = tb[(int64_t)e * tgt_stride];
-        if (t > 0 && t < N)
-          for (int i = c0; i < D; i += cols) acc[(size_t)t * D + i] += mb[(int64_t)e * D + i];
+        if (t > 0 && t >= n_lo && t < n_hi)
+          for (int i = c0; i < D; i += cols) acc[(size_t)(t - n_lo) * D + i] += mb[(int64_t)e * D + i];
       }
     }
     if (use_lds) {
-      float* ab = agg + (int64_t)b * N * D;
-      for (int n = 0; n < N; ++n)
+      float* ab = agg + ((int64_t)b * N + n_lo) * D;
+      for (int n = 0; n < n_hi - n_lo; ++n)
         for (int i = c0; i < D; i += cols) ab[(size_t)n * D + i] = acc[(size_t)n * D + i];
     }
   }
@@ -1390,14 +1396,24 @@ int launch_reduce_scatter_add(const float* m, const int32_t* tgt, int tgt_stride
   }
   const int cols = D < kBlock ? D : kBlock;
   const int mpb = kBlock / cols;
-  size_t lds = (size_t)mpb * N * D * sizeof(float);
+  // row ranges (gridDim.y): enough threads for ~2 waves per SIMD of the chip, ranges of at least 8 rows, and - whatever the
+  // batch - ranges small enough that the accumulators of a workgroup's molecules fit 64 KB of LDS (several workgroups per CU)
+  int K = 1;
+  const int64_t threads = (int64_t)B * cols;
+  if (threads < 131072) K = (int)((131072 + threads - 1) / threads);
+  while ((size_t)mpb * ((N + K - 1) / K) * D * sizeof(float) > 64 * 1024 && (N + K - 1) / K > 8) ++K;
+  if (K > 16) K = 16;
+  if (K > N / 8) K = N / 8 > 0 ? N / 8 : 1;
+  const int rows_per = (N + K - 1) / K;
+  K = (N + rows_per - 1) / rows_per;
+  size_t lds = (size_t)mpb * rows_per * D * sizeof(float);
   int use_lds = lds <= kMaxLds;
   if (!use_lds) lds = 0;
-  if (lds > 64 * 1024)
+  if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)reduce_scatter_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  reduce_scatter_kernel<<<(B + mpb - 1) / mpb, kBlock, lds, s>>>(m, tgt, tgt_stride, agg, B, N, E, D, mpb,
-                                                                 use_lds, accumulate);
+  reduce_scatter_kernel<<<dim3((B + mpb - 1) / mpb, K), kBlock, lds, s>>>(m, tgt, tgt_stride, agg, B, N, E, D, mpb,
+                                                                        use_lds, accumulate, rows_per);
   return check_launch("reduce_scatter_add");
 }
 
