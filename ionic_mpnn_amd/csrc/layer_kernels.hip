@@ -347,7 +347,8 @@ __global__ __launch_bounds__(512) void bmm_message_typed_d32_kernel(
 // because 160 x 128 floats x 2 molecules do not fit LDS) get gridDim.y times the threads and LDS accumulators again.
 __global__ void reduce_scatter_kernel(const float* __restrict__ m, const int32_t* __restrict__ tgt,
                                       int tgt_stride, float* __restrict__ agg, int B, int N, int E,
-                                      int D, int mols_per_block, int use_lds, int accumulate, int rows_per) {
+                                      int D, int mols_per_block, int use_lds, int accumulate, int rows_per,
+                                      int use_list) {
   extern __shared__ __align__(16) float smem[];
   const int cols = D < (int)blockDim.x ? D : (int)blockDim.x;  // threads per molecule
   const int ml = threadIdx.x / cols;
@@ -357,15 +358,59 @@ __global__ void reduce_scatter_kernel(const float* __restrict__ m, const int32_t
   const int n_lo = blockIdx.y * rows_per, n_hi = n_lo + rows_per < N ? n_lo + rows_per : N;
   // acc[(t - n_lo) * D + column]: the rows [n_lo, n_hi) of this molecule
   float* acc = use_lds ? smem + (size_t)ml * rows_per * D : (active ? agg + ((int64_t)b * N + n_lo) * D : nullptr);
-  if (active) {
-    if (use_lds || !accumulate) {
-      const float* ab0 = agg + ((int64_t)b * N + n_lo) * D;
-      for (int n = 0; n < n_hi - n_lo; ++n)
-        for (int i = c0; i < D; i += cols) acc[(size_t)n * D + i] = accumulate ? ab0[(size_t)n * D + i] : 0.f;
+  // use_list (cols == D, E and N below 65536): a wave per molecule first compacts the slots whose target lies in this
+  // workgroup's row range - (slot << 16 | row - n_lo), in slot order - so the column threads walk only those instead
+  // of testing all E indices each (E = 640, sixteen ranges: 40 tests per row that is added)
+  int32_t* list = reinterpret_cast<int32_t*>(smem + (use_lds ? (size_t)mols_per_block * rows_per * D : 0));
+  int32_t* cnts = list + (size_t)mols_per_block * E;
+  if (use_list) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwave = (int)blockDim.x >> 6;
+    for (int mw = wave; mw < mols_per_block; mw += nwave) {
+      const int bb = blockIdx.x * mols_per_block + mw;
+      int cnt = 0;
+      if (bb < B) {
+        const int32_t* tbb = tgt + (int64_t)bb * E * tgt_stride;
+        for (int e0 = 0; e0 < E; e0 += 64) {
+          const int e = e0 + lane;
+          const int t = e < E ? tbb[(int64_t)e * tgt_stride] : 0;
+          const bool ok = t > 0 && t >= n_lo && t < n_hi;
+          const unsigned long long mask = __ballot(ok);
+          if (ok) list[(size_t)mw * E + cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (e << 16) | (t - n_lo);
+          cnt += __popcll(mask);
+        }
+      }
+      if (lane == 0) cnts[mw] = cnt;
     }
+  }
+  if (active && (use_lds || !accumulate)) {
+    const float* ab0 = agg + ((int64_t)b * N + n_lo) * D;
+    for (int n = 0; n < n_hi - n_lo; ++n)
+      for (int i = c0; i < D; i += cols) acc[(size_t)n * D + i] = accumulate ? ab0[(size_t)n * D + i] : 0.f;
+  }
+  if (use_list) __syncthreads();
+  if (active) {
     const float* mb = m + (int64_t)b * E * D;
     const int32_t* tb = tgt + (int64_t)b * E * tgt_stride;
-    if (cols == D) {  // one column per thread: keep 16 edge rows in flight; adds stay in edge-slot order
+    if (use_list) {  // (cols == D)
+      constexpr int kU = 16;
+      const int32_t* L = list + (size_t)ml * E;
+      const int n = cnts[ml];
+      int i = 0;
+      for (; i + kU <= n; i += kU) {
+        float v[kU];
+        int p[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) p[u] = L[i + u];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) v[u] = mb[(int64_t)((unsigned)p[u] >> 16) * D + c0];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) acc[(size_t)(p[u] & 0xffff) * D + c0] += v[u];
+      }
+      for (; i < n; ++i) {
+        const int p = L[i];
+        acc[(size_t)(p & 0xffff) * D + c0] += mb[(int64_t)((unsigned)p >> 16) * D + c0];
+      }
+    } else if (cols == D) {  // one column per thread: keep 16 edge rows in flight; adds stay in edge-slot order
       constexpr int kU = 16;
       int e = 0;
       for (; e + kU <= E; e += kU) {
@@ -1409,11 +1454,14 @@ int launch_reduce_scatter_add(const float* m, const int32_t* tgt, int tgt_stride
   size_t lds = (size_t)mpb * rows_per * D * sizeof(float);
   int use_lds = lds <= kMaxLds;
   if (!use_lds) lds = 0;
+  const size_t lbytes = sizeof(int32_t) * ((size_t)mpb * E + mpb);
+  const int use_list = cols == D && E > 0 && E < 65536 && N < 65536 && lbytes <= 32 * 1024 && lds + lbytes <= kMaxLds;
+  if (use_list) lds += lbytes;
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)reduce_scatter_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   reduce_scatter_kernel<<<dim3((B + mpb - 1) / mpb, K), kBlock, lds, s>>>(m, tgt, tgt_stride, agg, B, N, E, D, mpb,
-                                                                        use_lds, accumulate, rows_per);
+                                                                        use_lds, accumulate, rows_per, use_list);
   return check_launch("reduce_scatter_add");
 }
 
