@@ -281,8 +281,10 @@ def time_other_configs(dev, Va, Vb):
 
     # configs[4]: the full training step at atom_dim 128, 6 steps
     D, K, S = 128, 8, 6
-    for B, graphed, iters in ((32, True, 100), (4096, True, 8)):  # (eager launches at batch 4096: 15.8 vs 15.2 ms)
-        inp = synthetic.make_batch(B, seed=0)
+    # (eager launches at batch 4096: 15.8 vs 15.2 ms); third entry: the reference's batch at the padded shape of its real
+    # (explicit-hydrogen) data sets, N = 160, E = 640
+    for B, graphed, iters, explicit_h in ((32, True, 100, False), (4096, True, 8, False), (32, True, 100, True)):
+        inp = synthetic.make_explicit_h_batch(B, seed=0) if explicit_h else synthetic.make_batch(B, seed=0)
         y = np.random.default_rng(0).normal(4.0, 1.0, size=B).astype(np.float32)
         m = model.build_model(Va, Vb, atom_dim=D, bond_dim=K, num_steps=S, device=dev)
         m.load_weights(weights.init_weights("viscosity", Va, Vb, atom_dim=D, bond_dim=K, num_steps=S, seed=1))
@@ -292,7 +294,7 @@ def time_other_configs(dev, Va, Vb):
         ms = _gpu_timed(lambda: step(d, y), iters, warm=3)
         rows, edges = executed_counts(inp)
         fwd = S * (12 * D * D * rows + 2 * D * D * edges)
-        out[f"config5_train_step_D128_K8_S6_B{B}"] = {
+        out[("explicit_h_train_step_N160_E640_D128_K8_S6_B%d" if explicit_h else "config5_train_step_D128_K8_S6_B%d") % B] = {
             "ms_per_train_step": ms, "graph_pairs_per_s": B / (ms * 1e-3), "hipgraph": graphed,
             "executed_f32_tflops": 3 * fwd / (ms * 1e-3) / 1e12,
             "frac_of_f32_mfma_peak": 3 * fwd / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
