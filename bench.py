@@ -11,6 +11,8 @@ of synthetic padded graph pairs: BASELINE.json configs[1] (N=40, E=80, D=32, K=8
 per GPU; weak scaling: every rank owns its own 4096 pairs, no data-path collective).
 `--config4`: BASELINE.json configs[3] as worded - 8192 pairs per rank, and every timed step ends with the all-gather
 of the pooled fingerprints and the all-reduce of the loss statistics (RCCL); the no-collective figure stands beside it.
+`--config5`: BASELINE.json configs[4] as worded - the full training step (fwd + bwd + Adam) at atom_dim 128, 6 steps,
+data-parallel over the ranks, the gradient all-reduce inside every timed step (a line of its own: another metric).
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -306,6 +308,73 @@ def time_other_configs(dev, Va, Vb):
     return out
 
 
+def run_config5(args, rank, world, dev, rehearsal, ndev):
+    """--config5: BASELINE.json configs[4] as worded - the full train_viscosity.py step (forward + backward + Adam(1e-3,
+    clipnorm=1.0) + MSE + l2; train_viscosity.py:189,227-230,328-338) at atom_dim 128, 6 message-passing steps, data-parallel
+    over the ranks: every timed step is MPNNModel.train_on_batch on the rank's shard, i.e. it ends with the all-reduce of
+    the flat gradient buffer (RCCL) before the optimizer step.  Eager launches at every N (a captured graph would have to
+    hold the collective); the single-GPU graphed figure is `other_configs.config5_train_step_*` of the default line."""
+    import torch.distributed as dist
+    from ionic_mpnn_amd import model, synthetic, train, weights
+    Va, Vb, D, K, S = synthetic.DEFAULT_VA, synthetic.DEFAULT_VB, 128, 8, 6
+    B = args.batch if args.batch is not None else 4096
+    inp = synthetic.make_batch(B, seed=rank)
+    y = np.random.default_rng(rank).normal(4.0, 1.0, size=B).astype(np.float32)
+    m = model.build_model(Va, Vb, atom_dim=D, bond_dim=K, num_steps=S, device=dev)
+    m.load_weights(weights.init_weights("viscosity", Va, Vb, atom_dim=D, bond_dim=K, num_steps=S, seed=1))
+    m.compile(train.Adam(1e-3, clipnorm=1.0))
+    d = m._to_device(inp)
+    step = lambda: m.train_on_batch(d, y, n_global=B * world)
+    for _ in range(max(args.warmup, 1)):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    loss = float(loss)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    rows, edges = executed_counts(inp)
+    fwd = S * (12 * D * D * rows + 2 * D * D * edges)
+    ms = elapsed / args.steps * 1e3
+    tfl = 3 * fwd / (ms * 1e-3) / 1e12
+    params = int(sum(t.numel() for _, t in m.trainable_variables()))
+    out = {
+        "metric": "molecule-graph pairs/sec (training step: fwd + bwd + Adam), per MI355X batch %d" % B,
+        "value": B * world * args.steps / elapsed, "unit": "graph-pairs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": max(args.warmup, 1), "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[4]: full train_viscosity.py step (forward + backward + Adam(1e-3, "
+                               "clipnorm=1.0) + MSE + l2), atom_dim 128, bond_dim 8, 6 message-passing steps, synthetic padded "
+                               "graphs N<=40 E<=80, batch %d pairs/GPU, eager launches" % B,
+                   "parallelism": "data-parallel x%d: batch-sharded, weights replicated, one all-reduce of the flat gradient "
+                                  "buffer (%d floats) per step before the optimizer step" % (world, params),
+                   "global_batch": B * world, "loss_last": loss, "trainable_parameters": params},
+        "roofline": {"bound": "mfma", "achieved": tfl, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tfl / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "note": "this rank's executed exact-f32 products counted as 3 x the forward's (forward, data gradient, "
+                             "weight gradient) over the whole step; per-kernel figures: profiles/r3_train_config5_*"},
+        "cpu_baseline": None,
+    }
+    if rehearsal:
+        out["config"]["rehearsal"] = f"{world} ranks share {ndev} GPU(s) over gloo - not a scaling number"
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -316,6 +385,10 @@ def main():
     ap.add_argument("--config4", action="store_true",
                     help="BASELINE.json configs[3] as worded: 8192 pairs per rank, every timed step ends with the all-gather of "
                          "the pooled fingerprints and the all-reduce of the loss statistics")
+    ap.add_argument("--config5", action="store_true",
+                    help="BASELINE.json configs[4] as worded: the full training step (fwd + bwd + Adam) at atom_dim 128, 6 steps, "
+                         "data-parallel over the ranks with the gradient all-reduce inside every timed step (default batch 4096 "
+                         "pairs per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the labelled extras for BASELINE.json configs[2] and configs[4]")
@@ -357,6 +430,9 @@ def main():
     if world > 1:
         idist.init_distributed(backend="gloo" if rehearsal else "nccl")
     import torch.distributed as dist
+
+    if args.config5:
+        return run_config5(args, rank, world, dev, rehearsal, ndev)
 
     N, E, D, K, S = 40, 80, 32, 8, args.mp_steps
     B = args.batch if args.batch is not None else (8192 if args.config4 else 4096)

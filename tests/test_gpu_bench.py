@@ -9,6 +9,7 @@ import subprocess
 import sys
 from pathlib import Path
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -62,3 +63,16 @@ def test_two_rank_gloo_rehearsal_of_the_driver_command(extra):
         assert out["config"]["collective_us"] is not None
         assert out["config"]["without_collectives"]["graph_pairs_per_s"] > 0
         assert "configs[3]" in out["config"]["workload"]
+
+
+def test_config5_training_bench_two_rank_rehearsal():
+    """`bench.py --config5 --gpus 2` (BASELINE.json configs[4] as worded: the data-parallel training step with its gradient
+    all-reduce inside the timed loop), two ranks on one GPU over gloo, small batch."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--batch", "64", "--config5"]
+    out = _run(cmd)
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["config"]["global_batch"] == 128 and "configs[4]" in out["config"]["workload"]
+    assert "rehearsal" in out["config"] and out["roofline"]["bound"] == "mfma"
+    assert np.isfinite(out["config"]["loss_last"])
