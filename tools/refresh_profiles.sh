@@ -23,4 +23,6 @@ if [ -f ionic_mpnn_amd/csrc/ab/lib_STAMPS.so ]; then  # (a -DIMPNN_DIAG_WIDE_STA
   IMPNN_LIB=$ROOT/ionic_mpnn_amd/csrc/ab/lib_STAMPS.so python tools/wide_stamps.py --mode f32x3 > gpurun_out/$R/wide_stamps_f32x3.txt 2>&1 || true
 fi
 bash tools/pmc_profile.sh gpurun_out/$R/pmc > /dev/null 2>&1
+bash tools/train_profiles.sh gpurun_out/$R/train > /dev/null 2>&1   # training-step timings + config-5 kernel summaries
+python tools/gu_pair_bench.py > gpurun_out/$R/gu_pair_bench.jsonl 2>> gpurun_out/$R/bench.err
 cat gpurun_out/$R/bench.json
