@@ -2473,7 +2473,11 @@ __device__ __forceinline__ int head_vec_off(int which) {
   return which < 2 ? which * kHdXMax : 2 * kHdXMax + (which - 2) * kHdMax;
 }
 
-__global__ __launch_bounds__(256) void model_head_bwd_kernel(int kind, const float* __restrict__ pc,
+// 1024 threads: the first 256 walk the samples (8 samples x 32 lanes, as the forward kernel), all of them stage the
+// weights, form the parameter gradients' outer products and flush them - the three phases that scale with the packed
+// weight count (25 K floats at atom_dim 128) and made the kernel ~96 us at every batch below 2048, alone on the stream
+// between the two halves of a training step.
+__global__ __launch_bounds__(1024) void model_head_bwd_kernel(int kind, const float* __restrict__ pc,
                                                              const float* __restrict__ pa, const float* __restrict__ T,
                                                              HeadTensors ht, const float* __restrict__ dout,
                                                              float* __restrict__ dpc, float* __restrict__ dpa, int B,
@@ -2486,7 +2490,9 @@ __global__ __launch_bounds__(256) void model_head_bwd_kernel(int kind, const flo
   float* vec = dws + tpad;  // [kHdSPB][kHdVecStride]: the two pooled states (kHdXMax each), then 10 vectors of kHdMax
   float* fpre = vec + kHdSPB * kHdVecStride;
   float* ppre = fpre + kHdSPB * 2 * kHdMax;
-  const int tid = threadIdx.x, sl = tid >> 5, jj = tid & 31;
+  const int tid = threadIdx.x;
+  const bool worker = tid < 32 * kHdSPB;                     // a lane of a sample; the others skip the per-sample loops
+  const int sl = worker ? tid >> 5 : 0, jj = worker ? (tid & 31) : (1 << 30);
   float* my = vec + sl * kHdVecStride;
   auto V = [&](int which) { return my + head_vec_off(which); };
   head_load_weights(ht, ws);
@@ -2498,7 +2504,7 @@ __global__ __launch_bounds__(256) void model_head_bwd_kernel(int kind, const flo
 
   for (int b0 = blockIdx.x * kHdSPB; b0 < B; b0 += gridDim.x * kHdSPB) {
     const int b = b0 + sl;
-    const bool live = b < B;
+    const bool live = worker && b < B;
     __syncthreads();  // the previous group's outer products are done with vec
     // xs of head_forward_mix = vectors kVX0,kVX1 (contiguous)
     for (int g = 0; g < 2; ++g)
@@ -3056,7 +3062,7 @@ int launch_model_head_bwd(int kind, const float* pc, const float* pa, const floa
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)model_head_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int groups = (B + kHdSPB - 1) / kHdSPB;  // bounded grid: every workgroup flushes ~|weights| atomics once
-  model_head_bwd_kernel<<<groups < 512 ? groups : 512, 256, lds, s>>>(kind, pc, pa, T, ht, dout, dpc, dpa, B, D, F, Mx, hl);
+  model_head_bwd_kernel<<<groups < 512 ? groups : 512, 1024, lds, s>>>(kind, pc, pa, T, ht, dout, dpc, dpa, B, D, F, Mx, hl);
   return check_launch("model_head_bwd");
 }
 
