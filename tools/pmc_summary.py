@@ -15,7 +15,13 @@ for f in glob.glob(f"{out}/*/**/*counter_collection.csv", recursive=True):
                      "encoder_typed" if "encoder_typed" in k else "encoder_fused" if "encoder_fused" in k else
                      "plan_stats" if "plan_stats" in k else "plan_chunks" if "plan_chunks" in k else
                      "wide_update" if "wide_update" in k else "wide_message" if "wide_message" in k else
-                     "wide_reduce" if "wide_reduce" in k else None)
+                     "wide_reduce" if "wide_reduce" in k else
+                     "gated_update_bwd_wide16" if "gated_update_bwd_wide16" in k else
+                     "gated_update_wide16" if "gated_update_wide16" in k else
+                     "bmm_message_typed_bwd_mfma" if "bmm_message_typed_bwd_mfma" in k else
+                     "bmm_message_typed_seg_mfma" if "bmm_message_typed_seg_mfma" in k else
+                     "strided_gemm_splitk_big" if "strided_gemm_splitk_big" in k else
+                     "reduce_scatter" if "reduce_scatter_kernel" in k else None)
             if short:
                 acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for kern, cs in acc.items():
